@@ -1,0 +1,206 @@
+/*
+ * inc_mi355x.h -- C-ABI of libinc_mi355x.so: the MI355X (gfx950 / CDNA4) implementation of
+ * intel/neural-compressor's weight-only-quant hot path.
+ *
+ * The reference (INC 3.9) is 100 % Python and has NO FFI for this path; each entry point below
+ * replaces the torch/numpy/numba arithmetic of the cited reference function (file:line relative to
+ * /root/reference).  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers (HBM) unless noted.
+ *   - the caller owns every buffer (torch-allocated, passed as tensor.data_ptr()); the library
+ *     allocates nothing persistent and keeps no state -> thread-safe.
+ *   - every call is asynchronous w.r.t. the host and ordered on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream).
+ *   - return value: INC_OK (0) or a negative INC_ERR_* code; the C side never throws.
+ *   - tensors are dense row-major; "[N,K]" means N rows of K contiguous elements.
+ *   - dtype codes: INC_F32 / INC_F16 / INC_BF16 for floating tensors.
+ */
+#ifndef INC_MI355X_H_
+#define INC_MI355X_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INC_OK 0
+#define INC_ERR_BAD_ARG (-1)     /* null pointer / non-positive size / inconsistent shape          */
+#define INC_ERR_UNSUPPORTED (-2) /* valid request this build does not implement (e.g. bits = 3)    */
+#define INC_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch               */
+#define INC_ERR_WORKSPACE (-4)   /* workspace too small (see *_workspace_bytes)                    */
+
+#define INC_F32 0
+#define INC_F16 1
+#define INC_BF16 2
+
+#define INC_SCHEME_ASYM 0
+#define INC_SCHEME_SYM 1
+
+typedef void* inc_stream_t; /* hipStream_t */
+
+/* ---- library info ------------------------------------------------------------------------- */
+int inc_abi_version(void);                 /* bumps on any signature change                      */
+const char* inc_error_string(int code);    /* static string for an INC_ERR_* code                */
+const char* inc_target_arch(void);         /* "gfx950"                                           */
+
+/* ---- K1/K2: bit packing ------------------------------------------------------------------- *
+ * inc_pack_rows  == INCWeightOnlyLinear.pack_tensor   (weight_only/modules.py:580, :445, :546,
+ *                   numba packers torch/utils/bit_packer.py:35-278):
+ *     packed[r, j] = OR_e ((raw[r, j*n_pack + e] & (2^bits-1)) << (bits*e)),  n_pack = cbits/bits
+ *   raw: int32 [rows, cols]; packed: [rows, ceil(cols/n_pack)] words of `cbits` bits.
+ *   bits in {2,4,8}; cbits in {8,16,32,64}.
+ * inc_unpack_rows == INCWeightOnlyLinear.unpack_tensor (modules.py:587, :468, :558):
+ *     out[r, j*n_pack+e] = (packed[r,j] << (cbits-bits*(e+1))) >>arith (cbits-bits), then & mask
+ *     iff mask_sign != 0 (the reference masks iff the module has `qzeros`); out: int16.
+ */
+int inc_pack_rows(const int32_t* raw, void* packed, int64_t rows, int64_t cols, int bits, int cbits,
+                  inc_stream_t stream);
+int inc_unpack_rows(const void* packed, int16_t* out, int64_t rows, int64_t packed_cols, int bits,
+                    int cbits, int mask_sign, inc_stream_t stream);
+
+/* ---- K1 fused: pack into the "optimum" (HF/AutoGPTQ) layout ------------------------------- *
+ * == INCWeightOnlyLinear.pack with use_optimum_format=True (modules.py:321-375).
+ *   int_weight [N,K] (int32 when in_bytes == 4, int8 when in_bytes == 1); `shift` is added to every
+ *     value before masking (reference: +2^(bits-1) when zp is None, modules.py:329-334).
+ *   scales   [N,G] fp32  -> scales_out [G,N] fp16          (modules.py:346,372)
+ *   zp       [N,G] int32 or NULL.  NULL => every zero point is 2^(bits-1) (sym, modules.py:334).
+ *            qzeros stores zp-1 (modules.py:364) packed along N: qzeros [G, ceil(N/n_pack)] int32.
+ *            (`shift` only moves the weights: pass signed ints with shift=2^(bits-1), or already
+ *            offset codes 0..2^bits-1 with shift=0 -- the GPTQ kernel emits the latter.)
+ *   qweight  [ceil(K/n_pack), N] int32: nibble e of qweight[r, n] = int_weight[n, r*n_pack+e]+shift.
+ */
+int inc_woq_pack(const void* int_weight, int in_bytes, const float* scales, const int32_t* zp,
+                 int32_t* qweight, int32_t* qzeros, uint16_t* scales_out, int64_t N, int64_t K,
+                 int64_t G, int bits, int shift, inc_stream_t stream);
+
+/* ---- K2 fused: unpack the optimum layout -------------------------------------------------- *
+ * == INCWeightOnlyLinear.unpack (modules.py:377-411): int_weight [N,K] int16 (0..2^bits-1),
+ *   zp [N,G] int16 = stored+1, values > 2^bits-1 wrap to 0 (modules.py:407-410).
+ *   Either output pointer may be NULL to skip it.
+ */
+int inc_woq_unpack(const int32_t* qweight, const int32_t* qzeros, int16_t* int_weight, int16_t* zp,
+                   int64_t N, int64_t K, int64_t G, int bits, inc_stream_t stream);
+
+/* ---- K3: recover / dequantize ------------------------------------------------------------- *
+ * == INCWeightOnlyLinear.recover (modules.py:413-443):
+ *     W[n,k] = int8(q[n,k] - zp[n,g(k)]) * scales[n,g(k)],  g(k) = g_idx ? g_idx[k] : k / group_size
+ *   computed exactly in fp32 then rounded ONCE to out_dtype (fp16 reproduces the reference bit for
+ *   bit).  Optimum layout in: qweight [ceil(K/n_pack),N], scales [G,N] fp16, qzeros [G,ceil(N/np)].
+ *   out [N,K] of out_dtype.
+ */
+int inc_woq_dequant(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                    const int32_t* g_idx, void* out, int out_dtype, int64_t N, int64_t K, int64_t G,
+                    int group_size, int bits, inc_stream_t stream);
+
+/* same arithmetic from already-unpacked integers (non-optimum formats, modules.py:270-314):
+ *   int_weight [N,K] int16, scales [N,G] of scale_dtype, zp [N,G] int16 or NULL.               */
+int inc_dequant_ints(const int16_t* int_weight, const void* scales, int scale_dtype,
+                     const int16_t* zp, const int32_t* g_idx, void* out, int out_dtype, int64_t N,
+                     int64_t K, int64_t G, int group_size, inc_stream_t stream);
+
+/* ---- K4: fused INT4/INT8 unpack + group dequant + GEMM ------------------------------------- *
+ * == INCWeightOnlyLinear.forward (modules.py:594-610) == F.linear(x, recover(), bias), without
+ *   ever materialising the dense weight.  x [M,K] and y [M,N] of dtype `xdtype` (INC_BF16 or
+ *   INC_F16), fp32 accumulate; weights dequantised to `xdtype` in registers.
+ *   bias [N] of `xdtype` or NULL.  bits in {4, 8}.  g_idx must be NULL in this ABI version
+ *   (act_order checkpoints: inc_woq_dequant honours g_idx; the fused kernel returns
+ *   INC_ERR_UNSUPPORTED so that a caller can never get a silently wrong product).
+ *   The library picks the MFMA tile kernel (large M) or the split-K GEMV (M <= 16) itself;
+ *   `workspace` (fp32, inc_woq_gemm_workspace_bytes) is only touched by the split-K path.
+ */
+int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16_t* scales,
+                 const int32_t* qzeros, const int32_t* g_idx, const void* bias, void* y, int64_t M,
+                 int64_t N, int64_t K, int64_t G, int group_size, int bits, void* workspace,
+                 int64_t workspace_bytes, inc_stream_t stream);
+
+/* ---- K7: group-wise round-to-nearest quantisation ------------------------------------------ *
+ * == quant_tensor / qdq_weight_sym / qdq_weight_asym (weight_only/utility.py:272-436, :199, :162).
+ *   w [N,K] of `wdtype`, quantised per row in groups of `group_size` along K (tail group = the
+ *   remainder, utility.py:334-376).  scheme INC_SCHEME_SYM / _ASYM, quantile, full_range as the
+ *   reference.  Arithmetic is done in `wdtype` precision exactly like the reference's torch ops
+ *   (every intermediate rounded to wdtype; fp32 for INC_F32).
+ *   Outputs (any may be NULL):
+ *     qdq_out   [N,K] wdtype : fake-quantised weight (may alias w -> the reference's in-place mode)
+ *     int_out   [N,K] int32  : integer codes (sym: -2^(b-1)..2^(b-1)-1, asym: 0..2^b-1)
+ *     scale_out [N,G] fp32, zp_out [N,G] fp32 (asym only; ignored for sym)
+ */
+int inc_groupwise_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_out, float* scale_out,
+                        float* zp_out, int64_t N, int64_t K, int group_size, int bits, int scheme,
+                        float quantile, int full_range, inc_stream_t stream);
+
+/* sum((a-b)^2) over n elements -> *out (fp32, accumulated with atomics: zero it first).
+ * == the loss of search_clip (utility.py:468) and AWQ's output-MSE (awq.py:336-344, 450-458).   */
+int inc_mse_accumulate(const void* a, const void* b, int dtype, int64_t n, float* out,
+                       inc_stream_t stream);
+
+/* ---- K5: GPTQ Hessian accumulation ---------------------------------------------------------- *
+ * == GPTQ.add_batch (weight_only/gptq.py:1111-1141):
+ *     H <- beta*H + alpha * X^T X        (beta = n/(n+b), alpha = 2/(n+b) computed by the caller)
+ *   x [T,K] of `xdtype` (row stride ldx elements), H [K,K] fp32.  Only the tiles on/above the
+ *   diagonal are touched (syrk); call inc_gptq_hessian_finalize once before factorising.
+ *   bf16/fp16 inputs use the bf16/f16 MFMA with fp32 accumulation (products exact);
+ *   fp32 inputs use the exact-fp32 MFMA.
+ */
+int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int64_t ldx, float* H,
+                           float beta, float alpha, inc_stream_t stream);
+
+/* == GPTQ.fasterquant prologue (gptq.py:1186-1189, 1221-1227): mirror the upper triangle to the
+ *   lower, dead[i] = (H[i,i]==0) -> H[i,i]=1, damp = percdamp*mean(diag(H)), H[i,i] += damp.
+ *   dead: uint8 [K] out.  workspace: >= 16 bytes.                                               */
+int inc_gptq_hessian_finalize(float* H, int64_t K, float percdamp, uint8_t* dead, void* workspace,
+                              inc_stream_t stream);
+
+/* == `W = W.float(); W[:, dead] = 0` (gptq.py:1176, 1189): weight of `wdtype` -> fp32 working copy
+ *   with the columns flagged in dead (uint8 [K], may be NULL) zeroed.                           */
+int inc_gptq_prepare_weight(const void* w, int wdtype, float* out, const uint8_t* dead, int64_t N,
+                            int64_t K, inc_stream_t stream);
+
+/* == Quantizer.find_params(weight=True) (gptq.py:1501-1624, int dtype, perchannel, no mse):
+ *   per row n and per group g over columns [col0 + g*group_size, ...) of w [N,K] fp32:
+ *     scale[n, g0+g], zero[n, g0+g]  (fp32 [N,G]) for ngroups groups.
+ *   sym: scale = 2*absmax/maxq, zero = (maxq+1)/2; asym: scale=(max-min)/maxq, zero=round(-min/scale)
+ */
+int inc_gptq_find_params(const float* w, int64_t N, int64_t K, int64_t col0, int group_size,
+                         int ngroups, int bits, int sym, float* scale, float* zero, int64_t G,
+                         int64_t g0, inc_stream_t stream);
+
+/* == the serial column loop of GPTQ.fasterquant for ONE block of columns [i1, i1+count)
+ *   (gptq.py:1250-1299), count <= 128, rows independent:
+ *     for i: q = scale*(clamp(rint(w/scale)+zero,0,maxq)-zero); err=(w-q)/Hinv[i,i];
+ *            W1[:, i:] -= err (x) Hinv[i, i:];
+ *   Un-fused fp32 arithmetic (true divisions, mul-then-sub) == the reference's torch ops.
+ *   w [N,K] fp32 working copy (read only here), Hinv [K,K] fp32 upper Cholesky factor of H^-1,
+ *   scale/zero [N,G] fp32 (group of column c = c / group_size; group_size<=0 -> one group),
+ *   outputs: codes uint8 [N,K] (0..maxq; may be NULL), q_out [N,K] of q_dtype (dequantised,
+ *            gptq.py:1337; may be NULL), err [N,128] fp32 (Err1, consumed by inc_gptq_lazy_update).
+ */
+int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, const float* zero,
+                         uint8_t* codes, void* q_out, int q_dtype, float* err, int64_t N, int64_t K,
+                         int64_t G, int64_t i1, int count, int group_size, int bits,
+                         inc_stream_t stream);
+
+/* == W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:]  (gptq.py:1304), fp32 MFMA.  err [N,128].           */
+int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t N, int64_t K,
+                         int64_t i1, int count, inc_stream_t stream);
+
+/* ---- K8: AWQ statistics ---------------------------------------------------------------------- *
+ * inc_awq_act_abs_sum: out[k] += sum_t |x[t,k]|  (fp32 [K], accumulate; caller divides by T)
+ *   == _get_act_scale (weight_only/awq.py:151-154).
+ * inc_awq_weight_scale: out[k] = sum_n( |w[n,k]| / max_{k' in group(k)} |w[n,k']| )
+ *   == _get_weight_scale (awq.py:131-147).  w [N,K] of wdtype, out fp32 [K].
+ */
+int inc_awq_act_abs_sum(const void* x, int xdtype, int64_t T, int64_t K, float* out,
+                        inc_stream_t stream);
+/* out[k] += sum_n |w[n,k]| / groupmax (zero `out` first; the caller divides by N).
+ * workspace: inc_awq_weight_scale_workspace_bytes (fp32 group maxima [N, K/group_size]).          */
+int64_t inc_awq_weight_scale_workspace_bytes(int64_t N, int64_t K, int group_size);
+int inc_awq_weight_scale(const void* w, int wdtype, int64_t N, int64_t K, int group_size, float* out,
+                         void* workspace, int64_t workspace_bytes, inc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INC_MI355X_H_ */

@@ -1,0 +1,100 @@
+// common.hpp -- shared device helpers for libinc_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/inc_mi355x.h"
+
+#define INC_CHECK_ARG(cond) \
+  do {                      \
+    if (!(cond)) return INC_ERR_BAD_ARG; \
+  } while (0)
+
+#define INC_LAUNCH_RETURN()                          \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    return e__ == hipSuccess ? INC_OK : INC_ERR_LAUNCH; \
+  } while (0)
+
+static inline hipStream_t inc_s(inc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- 16-bit float <-> fp32 (bit-exact, round-to-nearest-even) -------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __uint_as_float(static_cast<uint32_t>(b) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x0040u);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) {
+  _Float16 h;
+  __builtin_memcpy(&h, &b, 2);
+  return static_cast<float>(h);
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+  _Float16 h = static_cast<_Float16>(f);  // v_cvt_f16_f32: RNE
+  uint16_t b;
+  __builtin_memcpy(&b, &h, 2);
+  return b;
+}
+
+// load/store one element of a dtype-coded tensor as fp32
+template <int DT>
+__device__ __forceinline__ float load_as_f32(const void* p, int64_t i) {
+  if constexpr (DT == INC_F32) return static_cast<const float*>(p)[i];
+  else if constexpr (DT == INC_F16) return f16_bits_to_f32(static_cast<const uint16_t*>(p)[i]);
+  else return bf16_bits_to_f32(static_cast<const uint16_t*>(p)[i]);
+}
+template <int DT>
+__device__ __forceinline__ void store_from_f32(void* p, int64_t i, float v) {
+  if constexpr (DT == INC_F32) static_cast<float*>(p)[i] = v;
+  else if constexpr (DT == INC_F16) static_cast<uint16_t*>(p)[i] = f32_to_f16_bits(v);
+  else static_cast<uint16_t*>(p)[i] = f32_to_bf16_bits(v);
+}
+// round an fp32 value to the precision of dtype DT (what a torch op on a DT tensor returns)
+template <int DT>
+__device__ __forceinline__ float round_to(float v) {
+  if constexpr (DT == INC_F32) return v;
+  else if constexpr (DT == INC_F16) return f16_bits_to_f32(f32_to_f16_bits(v));
+  else return bf16_bits_to_f32(f32_to_bf16_bits(v));
+}
+
+// ---- wave64 reductions --------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// dispatch a runtime dtype code to a template parameter
+#define INC_DISPATCH_DTYPE(code, NAME, ...)                  \
+  switch (code) {                                            \
+    case INC_F32: {                                          \
+      constexpr int NAME = INC_F32;                          \
+      __VA_ARGS__;                                           \
+    } break;                                                 \
+    case INC_F16: {                                          \
+      constexpr int NAME = INC_F16;                          \
+      __VA_ARGS__;                                           \
+    } break;                                                 \
+    case INC_BF16: {                                         \
+      constexpr int NAME = INC_BF16;                         \
+      __VA_ARGS__;                                           \
+    } break;                                                 \
+    default:                                                 \
+      return INC_ERR_UNSUPPORTED;                            \
+  }

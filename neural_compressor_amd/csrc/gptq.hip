@@ -1,0 +1,538 @@
+// gptq.hip -- K5/K6: GPTQ Hessian accumulation (MFMA syrk) and the block-column error-compensation loop.
+//
+// Reference (relative to /root/reference/neural_compressor/torch/algorithms/weight_only/gptq.py):
+//   GPTQ.add_batch      :1111-1141   H <- H*n/(n+b) + (sqrt(2/(n+b)) X)^T (sqrt(2/(n+b)) X)
+//   GPTQ.fasterquant    :1143-1351   dead columns, damping, the blocked column loop, lazy update
+//   Quantizer.quantize  :1626-1637   q = clamp(round(x/scale)+zero, 0, maxq); scale*(q-zero)
+//
+// Kernels
+//   hessian_syrk_16bit  bf16/f16 MFMA 32x32x16, fp32 accumulate, 128x128 tile of H per workgroup, upper
+//                       triangle of tiles only.  X is [T,K] row-major (tokens x features) so both MFMA
+//                       operands are X^T: each thread fetches an 8(token) x 8(feature) block with eight
+//                       16-byte row loads (full 128-byte segments per row), transposes it in registers
+//                       and writes eight 16-byte [feature][token] rows into LDS (pitch 144 B: both the
+//                       ds_write_b128 and the fragment ds_read_b128 are bank-conflict free).
+//   hessian_syrk_f32    exact fp32 MFMA 32x32x2 (A/B = one f32 per lane: no transpose needed).
+//   gptq_quant_block    the serial 128-column chain.  One lane owns one weight row; the 128-wide row
+//                       panel lives in 128 VGPRs (fully unrolled), the 128x128 Hinv tile is broadcast
+//                       out of LDS.  Arithmetic is kept un-fused (mul then sub, true divisions) so that
+//                       one block is bit-identical to the reference's torch ops.
+//   gptq_lazy_update    W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] with the exact fp32 MFMA.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---------------------------------------------------------------------------------------------
+// Hessian: H <- beta*H + alpha*X^T X   (16-bit inputs)
+// ---------------------------------------------------------------------------------------------
+constexpr int HB = 128;          // H tile edge (features)
+constexpr int HK = 64;           // tokens per pipeline step
+constexpr int HPITCH = HK + 8;   // LDS row pitch in elements (144 B)
+
+__device__ __forceinline__ void tri_decode(int idx, int nt, int& ti, int& tj) {
+  // idx -> (ti, tj), tj >= ti, row-major over the upper triangle
+  int t = 0, rem = idx;
+  while (rem >= nt - t) { rem -= nt - t; ++t; }
+  ti = t;
+  tj = t + rem;
+}
+
+// one thread's 8(token) x 8(feature) block of X, zero-filled out of range
+__device__ __forceinline__ void load_block8x8(const uint16_t* __restrict__ x, int64_t T, int64_t K,
+                                              int64_t ldx, int64_t t0, int64_t f0, bool vec,
+                                              uint4 (&r)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t t = t0 + i;
+    if (t < T && vec && f0 + 8 <= K) {
+      r[i] = *reinterpret_cast<const uint4*>(x + t * ldx + f0);
+    } else {
+      uint16_t e[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) e[c] = (t < T && f0 + c < K) ? x[t * ldx + f0 + c] : (uint16_t)0;
+      r[i] = make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                        (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
+    }
+  }
+}
+
+// transpose the 8x8 16-bit block held as r[token][4 dwords] and store 8 rows [feature][8 tokens]
+__device__ __forceinline__ void store_block_transposed(uint16_t* lds, int f_local, int t_local,
+                                                       const uint4 (&r)[8]) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&r[0]);  // w[token*4 + m]
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t a = w[(2 * p) * 4 + m], b = w[(2 * p + 1) * 4 + m];
+      lo[p] = (a & 0xffffu) | (b << 16);
+      hi[p] = (a >> 16) | (b & 0xffff0000u);
+    }
+    *reinterpret_cast<uint4*>(lds + (f_local + 2 * m) * HPITCH + t_local) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<uint4*>(lds + (f_local + 2 * m + 1) * HPITCH + t_local) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  }
+}
+
+template <bool IS_BF16>
+__device__ __forceinline__ f32x16 mfma16(const uint4& a, const uint4& b, f32x16 c) {
+  if constexpr (IS_BF16) {
+    bf16x8 fa, fb;
+    __builtin_memcpy(&fa, &a, 16);
+    __builtin_memcpy(&fb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, c, 0, 0, 0);
+  } else {
+    f16x8 fa, fb;
+    __builtin_memcpy(&fa, &a, 16);
+    __builtin_memcpy(&fb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c, 0, 0, 0);
+  }
+}
+
+template <bool IS_BF16>
+__global__ __launch_bounds__(256) void hessian_syrk_16bit_kernel(const uint16_t* __restrict__ x,
+                                                                 int64_t T, int64_t K, int64_t ldx,
+                                                                 float* __restrict__ H, float beta,
+                                                                 float alpha, int nt, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint16_t* smem = reinterpret_cast<uint16_t*>(smem_raw);
+  // [stage][operand A/B][HB][HPITCH]
+  constexpr int OPER = HB * HPITCH;
+  int ti, tj;
+  tri_decode(blockIdx.x, nt, ti, tj);
+  const int64_t i0 = (int64_t)ti * HB, j0 = (int64_t)tj * HB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
+  // staging role: threads 0..127 fetch the A (i) tile, 128..255 the B (j) tile
+  const int oper = tid >> 7, tt = tid & 127;
+  const int t_chunk = tt & 7, f_chunk = tt >> 3;
+  const int64_t fbase = (oper == 0 ? i0 : j0) + f_chunk * 8;
+  const bool vec = vec_ok != 0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (int)((T + HK - 1) / HK);
+  uint4 regs[8];
+  load_block8x8(x, T, K, ldx, (int64_t)t_chunk * 8, fbase, vec, regs);
+  store_block_transposed(smem + (0 * 2 + oper) * OPER, f_chunk * 8, t_chunk * 8, regs);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_block8x8(x, T, K, ldx, (int64_t)(kt + 1) * HK + t_chunk * 8, fbase, vec, regs);
+    const uint16_t* As = smem + (cur * 2 + 0) * OPER + (wr * 64) * HPITCH;
+    const uint16_t* Bs = smem + (cur * 2 + 1) * OPER + (wc * 64) * HPITCH;
+#pragma unroll
+    for (int kk = 0; kk < HK / 16; ++kk) {
+      const int koff = kk * 16 + 8 * (lane >> 5);
+      uint4 a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        a[m] = *reinterpret_cast<const uint4*>(As + (m * 32 + (lane & 31)) * HPITCH + koff);
+        b[m] = *reinterpret_cast<const uint4*>(Bs + (m * 32 + (lane & 31)) * HPITCH + koff);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma16<IS_BF16>(a[m], b[n], acc[m][n]);
+    }
+    if (kt + 1 < nk) store_block_transposed(smem + ((cur ^ 1) * 2 + oper) * OPER, f_chunk * 8, t_chunk * 8, regs);
+    __syncthreads();
+  }
+
+  // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int64_t col = j0 + wc * 64 + n * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < K && col < K) {
+          float* p = H + row * K + col;
+          *p = beta * (*p) + alpha * acc[m][n][r];
+        }
+      }
+    }
+}
+
+// ---- fp32 inputs: exact fp32 MFMA 32x32x2 ------------------------------------------------------
+constexpr int FK = 32;  // tokens per step
+__global__ __launch_bounds__(256) void hessian_syrk_f32_kernel(const float* __restrict__ x, int64_t T,
+                                                               int64_t K, int64_t ldx,
+                                                               float* __restrict__ H, float beta,
+                                                               float alpha, int nt) {
+  __shared__ float As[FK * HB];
+  __shared__ float Bs[FK * HB];
+  int ti, tj;
+  tri_decode(blockIdx.x, nt, ti, tj);
+  const int64_t i0 = (int64_t)ti * HB, j0 = (int64_t)tj * HB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int nk = (int)((T + FK - 1) / FK);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage [FK tokens][128 features] of both operands (coalesced along features)
+    for (int idx = tid; idx < FK * HB; idx += 256) {
+      const int t = idx / HB, f = idx - t * HB;
+      const int64_t tg = (int64_t)kt * FK + t;
+      As[idx] = (tg < T && i0 + f < K) ? x[tg * ldx + i0 + f] : 0.f;
+      Bs[idx] = (tg < T && j0 + f < K) ? x[tg * ldx + j0 + f] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < FK / 2; ++s) {
+      const int k = 2 * s + (lane >> 5);
+      float a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        a[m] = As[k * HB + wr * 64 + m * 32 + (lane & 31)];
+        b[m] = Bs[k * HB + wc * 64 + m * 32 + (lane & 31)];
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int64_t col = j0 + wc * 64 + n * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < K && col < K) {
+          float* p = H + row * K + col;
+          *p = beta * (*p) + alpha * acc[m][n][r];
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: dead columns + damping on the diagonal, then mirror upper -> lower
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hessian_diag_kernel(float* __restrict__ H, int64_t K,
+                                                            float percdamp, uint8_t* __restrict__ dead,
+                                                            float* __restrict__ ws) {
+  __shared__ float part[16];
+  __shared__ float damp_s;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < K; i += blockDim.x) {
+    float d = H[i * K + i];
+    const bool is_dead = (d == 0.f);
+    if (is_dead) { d = 1.f; H[i * K + i] = 1.f; }
+    if (dead) dead[i] = is_dead ? 1 : 0;
+    acc += d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += part[i];
+    damp_s = percdamp * (s / (float)K);
+    if (ws) ws[0] = damp_s;
+  }
+  __syncthreads();
+  const float damp = damp_s;
+  for (int64_t i = threadIdx.x; i < K; i += blockDim.x) H[i * K + i] += damp;
+}
+
+__global__ __launch_bounds__(256) void hessian_mirror_kernel(float* __restrict__ H, int64_t K) {
+  __shared__ float tile[32][33];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj < ti) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t row = (int64_t)ti * 32 + r, col = (int64_t)tj * 32 + tx;
+    tile[r][tx] = (row < K && col < K) ? H[row * K + col] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t row = (int64_t)tj * 32 + r, col = (int64_t)ti * 32 + tx;  // transposed position
+    if (row < K && col < K && row > col) H[row * K + col] = tile[tx][r];
+  }
+}
+
+// W (any dtype) -> fp32 working copy with dead columns zeroed (gptq.py:1176, 1189)
+template <int DT>
+__global__ void gptq_prepare_weight_kernel(const void* __restrict__ w, float* __restrict__ out,
+                                           const uint8_t* __restrict__ dead, int64_t N, int64_t K) {
+  const int64_t total = N * K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i % K;
+    out[i] = (dead && dead[k]) ? 0.f : load_as_f32<DT>(w, i);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the serial column chain for one 128-column block
+// ---------------------------------------------------------------------------------------------
+constexpr int QB = 128;         // columns per block
+constexpr int QROWS = 64;       // rows per workgroup (one wave)
+constexpr int QPITCH = QB + 1;  // fp32 staging pitch
+
+#pragma clang fp contract(off)
+template <int QDT>
+__global__ __launch_bounds__(64) void gptq_quant_block_kernel(
+    const float* __restrict__ w, const float* __restrict__ Hinv, const float* __restrict__ scale,
+    const float* __restrict__ zero, uint8_t* __restrict__ codes, void* __restrict__ q_out,
+    float* __restrict__ err, int64_t N, int64_t K, int64_t G, int64_t i1, int count, int gs, float maxq) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* hs = reinterpret_cast<float*>(smem_raw);     // [QB][QB] Hinv1 tile (upper part used)
+  float* stage = hs + QB * QB;                        // [QROWS][QPITCH]
+  uint8_t* cst = reinterpret_cast<uint8_t*>(stage + QROWS * QPITCH);  // [QROWS][QB+4] codes
+  constexpr int CP = QB + 4;
+  const int lane = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * QROWS;
+  const int64_t row = n0 + lane;
+
+  // Hinv1 -> LDS (zero-padded), W panel -> LDS (coalesced) -> registers
+  for (int idx = lane; idx < QB * QB; idx += 64) {
+    const int r = idx >> 7, c = idx & 127;
+    hs[idx] = (r < count && c < count) ? Hinv[(i1 + r) * K + i1 + c] : (r == c ? 1.f : 0.f);
+  }
+  for (int idx = lane; idx < QROWS * QB; idx += 64) {
+    const int r = idx >> 7, c = idx & 127;
+    stage[r * QPITCH + c] = (n0 + r < N && c < count) ? w[(n0 + r) * K + i1 + c] : 0.f;
+  }
+  __syncthreads();
+  float wr[QB];
+#pragma unroll
+  for (int j = 0; j < QB; ++j) wr[j] = stage[lane * QPITCH + j];
+  __syncthreads();
+
+  const int64_t srow = (row < N ? row : N - 1) * G;
+  // group bookkeeping without per-step divisions: `nb` = next in-block index that starts a group
+  int g = gs > 0 ? (int)(i1 / gs) : 0;
+  int nb = gs > 0 ? (int)(((int64_t)(g + 1)) * gs - i1) : (1 << 30);
+  float s = scale[srow + g], z = zero[srow + g];
+#pragma unroll
+  for (int i = 0; i < QB; ++i) {
+    if (i < count) {
+      if (i == nb) {
+        ++g;
+        nb += gs;
+        s = scale[srow + g];
+        z = zero[srow + g];
+      }
+      const float d = hs[i * QB + i];
+      const float x = wr[i];
+      float t = rintf(x / s) + z;
+      t = fminf(fmaxf(t, 0.f), maxq);
+      const float q = s * (t - z);
+      const float e = (x - q) / d;
+      cst[lane * CP + i] = (uint8_t)t;
+      stage[lane * QPITCH + i] = e;  // Err1 (the panel has been copied to registers)
+      wr[i] = q;
+#pragma unroll
+      for (int j = i + 1; j < QB; ++j) {
+        const float p = e * hs[i * QB + j];
+        wr[j] = wr[j] - p;
+      }
+    } else {
+      stage[lane * QPITCH + i] = 0.f;
+      cst[lane * CP + i] = 0;
+    }
+  }
+  __syncthreads();
+  // Err1 out: [N][128] dense
+  for (int idx = lane; idx < QROWS * QB; idx += 64) {
+    const int r = idx >> 7, c = idx & 127;
+    if (n0 + r < N) err[(n0 + r) * QB + c] = stage[r * QPITCH + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < QB; ++j) stage[lane * QPITCH + j] = wr[j];
+  __syncthreads();
+  for (int idx = lane; idx < QROWS * QB; idx += 64) {
+    const int r = idx >> 7, c = idx & 127;
+    if (n0 + r < N && c < count) {
+      const int64_t o = (n0 + r) * K + i1 + c;
+      if (q_out) store_from_f32<QDT>(q_out, o, stage[r * QPITCH + c]);
+      if (codes) codes[o] = cst[r * CP + c];
+    }
+  }
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------------
+// lazy update: W[:, i2:] -= Err1[N,128] @ Hinv[i1:i1+128, i2:]
+// ---------------------------------------------------------------------------------------------
+constexpr int LT = 128;
+constexpr int LAP = LT + 1;
+__global__ __launch_bounds__(256) void gptq_lazy_update_kernel(float* __restrict__ w,
+                                                               const float* __restrict__ Hinv,
+                                                               const float* __restrict__ err, int64_t N,
+                                                               int64_t K, int64_t i1, int count) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* As = reinterpret_cast<float*>(smem_raw);  // [LT rows][LAP]  (k along the row)
+  float* Bs = As + LT * LAP;                        // [QB k][LT cols]
+  const int64_t i2 = i1 + count;
+  const int64_t c0 = i2 + (int64_t)blockIdx.x * LT, r0 = (int64_t)blockIdx.y * LT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  for (int idx = tid; idx < LT * QB; idx += 256) {
+    const int r = idx >> 7, k = idx & 127;
+    As[r * LAP + k] = (r0 + r < N && k < count) ? err[(r0 + r) * QB + k] : 0.f;
+  }
+  for (int idx = tid; idx < QB * LT; idx += 256) {
+    const int k = idx >> 7, c = idx & 127;
+    Bs[idx] = (k < count && c0 + c < K) ? Hinv[(i1 + k) * K + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll 4
+  for (int s = 0; s < QB / 2; ++s) {
+    const int k = 2 * s + (lane >> 5);
+    float a[2], b[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      a[m] = As[(wr * 64 + m * 32 + (lane & 31)) * LAP + k];
+      b[m] = Bs[k * LT + wc * 64 + m * 32 + (lane & 31)];
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int64_t col = c0 + wc * 64 + n * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = r0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < N && col < K) {
+          float* p = w + row * K + col;
+          *p = *p - acc[m][n][r];
+        }
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int64_t ldx, float* H,
+                           float beta, float alpha, inc_stream_t stream) {
+  INC_CHECK_ARG(x && H && T > 0 && K > 0 && ldx >= K);
+  const int nt = (int)ceil_div64(K, HB);
+  const int ntiles = nt * (nt + 1) / 2;
+  hipStream_t s = inc_s(stream);
+  if (xdtype == INC_F32) {
+    hessian_syrk_f32_kernel<<<ntiles, 256, 0, s>>>((const float*)x, T, K, ldx, H, beta, alpha, nt);
+  } else if (xdtype == INC_BF16 || xdtype == INC_F16) {
+    const int vec_ok = (ldx % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const size_t smem = (size_t)2 * 2 * HB * HPITCH * sizeof(uint16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    if (xdtype == INC_BF16)
+      hessian_syrk_16bit_kernel<true><<<ntiles, 256, smem, s>>>((const uint16_t*)x, T, K, ldx, H, beta, alpha, nt, vec_ok);
+    else
+      hessian_syrk_16bit_kernel<false><<<ntiles, 256, smem, s>>>((const uint16_t*)x, T, K, ldx, H, beta, alpha, nt, vec_ok);
+  } else {
+    return INC_ERR_UNSUPPORTED;
+  }
+  INC_LAUNCH_RETURN();
+}
+
+int inc_gptq_hessian_finalize(float* H, int64_t K, float percdamp, uint8_t* dead, void* workspace,
+                              inc_stream_t stream) {
+  INC_CHECK_ARG(H && K > 0);
+  hipStream_t s = inc_s(stream);
+  hessian_diag_kernel<<<1, 1024, 0, s>>>(H, K, percdamp, dead, (float*)workspace);
+  const unsigned nt = (unsigned)ceil_div64(K, 32);
+  hessian_mirror_kernel<<<dim3(nt, nt), 256, 0, s>>>(H, K);
+  INC_LAUNCH_RETURN();
+}
+
+int inc_gptq_prepare_weight(const void* w, int wdtype, float* out, const uint8_t* dead, int64_t N,
+                            int64_t K, inc_stream_t stream) {
+  INC_CHECK_ARG(w && out && N > 0 && K > 0);
+  int64_t blocks = ceil_div64(N * K, 256);
+  if (blocks > 8192) blocks = 8192;
+  INC_DISPATCH_DTYPE(wdtype, DT, {
+    gptq_prepare_weight_kernel<DT><<<(unsigned)blocks, 256, 0, inc_s(stream)>>>(w, out, dead, N, K);
+  })
+  INC_LAUNCH_RETURN();
+}
+
+int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, const float* zero,
+                         uint8_t* codes, void* q_out, int q_dtype, float* err, int64_t N, int64_t K,
+                         int64_t G, int64_t i1, int count, int group_size, int bits,
+                         inc_stream_t stream) {
+  INC_CHECK_ARG(w && Hinv && scale && zero && err && N > 0 && K > 0 && G > 0);
+  INC_CHECK_ARG(i1 >= 0 && count > 0 && count <= QB && i1 + count <= K && bits >= 1 && bits <= 8);
+  const size_t smem = (size_t)QB * QB * 4 + (size_t)QROWS * QPITCH * 4 + (size_t)QROWS * (QB + 4);
+  const unsigned blocks = (unsigned)ceil_div64(N, QROWS);
+  const float maxq = (float)((1 << bits) - 1);
+  hipStream_t s = inc_s(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gptq_quant_block_kernel<INC_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)gptq_quant_block_kernel<INC_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)gptq_quant_block_kernel<INC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  INC_DISPATCH_DTYPE(q_dtype, DT, {
+    gptq_quant_block_kernel<DT><<<blocks, 64, smem, s>>>(w, Hinv, scale, zero, codes, q_out, err, N, K, G, i1, count, group_size, maxq);
+  })
+  INC_LAUNCH_RETURN();
+}
+
+int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t N, int64_t K,
+                         int64_t i1, int count, inc_stream_t stream) {
+  INC_CHECK_ARG(w && Hinv && err && N > 0 && K > 0 && i1 >= 0 && count > 0 && count <= QB);
+  const int64_t i2 = i1 + count;
+  if (i2 >= K) return INC_OK;  // nothing to the right of the block
+  const size_t smem = (size_t)LT * LAP * 4 + (size_t)QB * LT * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gptq_lazy_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)ceil_div64(K - i2, LT), (unsigned)ceil_div64(N, LT));
+  gptq_lazy_update_kernel<<<grid, 256, smem, inc_s(stream)>>>(w, Hinv, err, N, K, i1, count);
+  INC_LAUNCH_RETURN();
+}
+
+}  // extern "C"

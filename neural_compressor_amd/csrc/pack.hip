@@ -1,0 +1,484 @@
+// pack.hip -- K1/K2/K3: INT2/4/8 bit packing, unpacking and group-wise dequantisation (recover).
+//
+// Replaces the Python loops of INCWeightOnlyLinear.{pack,unpack,recover,pack_tensor,unpack_tensor}
+// (reference neural_compressor/torch/algorithms/weight_only/modules.py:321-592) and the numba
+// packers (neural_compressor/torch/utils/bit_packer.py:35-278).  Integer work: bit-exact.
+//
+// All kernels are HBM-bound byte shuffles.  The optimum-format kernels transpose through LDS so that
+// both the [N,K] side (int32/int16/fp16 rows, contiguous in K) and the [K/n_pack,N] side (packed
+// words, contiguous in N) are accessed with full-cache-line wave transactions.
+#include "common.hpp"
+
+namespace {
+
+constexpr int TILE = 64;           // 64 rows (n) x 64 packed words (kw) per workgroup
+constexpr int TILE_LD = TILE + 1;  // +1 dword pad: conflict-free column reads
+
+// ------------------------------------------------------------------------------------------
+// generic row packer / unpacker (any bits in {2,4,8} x container in {8,16,32,64})
+// ------------------------------------------------------------------------------------------
+template <typename UT>
+__global__ void pack_rows_kernel(const int32_t* __restrict__ raw, UT* __restrict__ packed,
+                                 int64_t rows, int64_t cols, int64_t pcols, int bits, int n_pack) {
+  const int64_t total = rows * pcols;
+  const uint32_t mask = (1u << bits) - 1u;
+  for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total;
+       w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = w / pcols, j = w - r * pcols;
+    const int32_t* src = raw + r * cols + j * n_pack;
+    const int64_t left = cols - j * n_pack;
+    UT word = 0;
+    for (int e = 0; e < n_pack; ++e) {
+      if (e < left) word |= static_cast<UT>(static_cast<UT>(static_cast<uint32_t>(src[e]) & mask) << (bits * e));
+    }
+    packed[w] = word;
+  }
+}
+
+template <typename ST, typename UT>
+__global__ void unpack_rows_kernel(const UT* __restrict__ packed, int16_t* __restrict__ out,
+                                   int64_t rows, int64_t pcols, int bits, int n_pack, int cbits,
+                                   int mask_sign) {
+  const int64_t total = rows * pcols;
+  const int64_t ocols = pcols * n_pack;
+  const ST mask = static_cast<ST>((1u << bits) - 1u);
+  for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total;
+       w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = w / pcols, j = w - r * pcols;
+    const UT word = packed[w];
+    int16_t* dst = out + r * ocols + j * n_pack;
+    for (int e = 0; e < n_pack; ++e) {
+      ST t = static_cast<ST>(static_cast<UT>(word << (cbits - bits * (e + 1))));
+      t = static_cast<ST>(t >> (cbits - bits));  // arithmetic shift, like numpy on a signed dtype
+      if (mask_sign) t = static_cast<ST>(t & mask);
+      dst[e] = static_cast<int16_t>(t);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// optimum-format pack: int_weight [N,K] -> qweight [KW,N]
+// ------------------------------------------------------------------------------------------
+template <int BITS, typename IN_T, bool VEC>
+__global__ __launch_bounds__(256) void woq_pack_qweight_kernel(const IN_T* __restrict__ iw,
+                                                               uint32_t* __restrict__ qweight,
+                                                               int64_t N, int64_t K, int64_t KW,
+                                                               int shift) {
+  constexpr int NP = 32 / BITS;
+  constexpr uint32_t MASK = (1u << BITS) - 1u;
+  __shared__ uint32_t tile[TILE * TILE_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t kw0 = (int64_t)blockIdx.x * TILE, n0 = (int64_t)blockIdx.y * TILE;
+
+  const int64_t kw = kw0 + lane;
+#pragma unroll 4
+  for (int rr = 0; rr < 16; ++rr) {
+    const int row = wave * 16 + rr;
+    const int64_t n = n0 + row;
+    uint32_t word = 0;
+    if (n < N && kw < KW) {
+      const IN_T* src = iw + n * K + kw * NP;
+      if constexpr (VEC) {  // whole word in range, 16-byte aligned int32 rows
+        static_assert(sizeof(IN_T) == 4, "vector path is int32 only");
+        const int4* v = reinterpret_cast<const int4*>(src);
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+          const int4 x = v[q];
+          word |= (static_cast<uint32_t>(x.x + shift) & MASK) << (BITS * (4 * q + 0));
+          word |= (static_cast<uint32_t>(x.y + shift) & MASK) << (BITS * (4 * q + 1));
+          word |= (static_cast<uint32_t>(x.z + shift) & MASK) << (BITS * (4 * q + 2));
+          word |= (static_cast<uint32_t>(x.w + shift) & MASK) << (BITS * (4 * q + 3));
+        }
+      } else {
+        const int64_t left = K - kw * NP;
+#pragma unroll
+        for (int e = 0; e < NP; ++e)
+          if (e < left)
+            word |= (static_cast<uint32_t>(static_cast<int32_t>(src[e]) + shift) & MASK) << (BITS * e);
+      }
+    }
+    tile[row * TILE_LD + lane] = word;
+  }
+  __syncthreads();
+  const int64_t n = n0 + lane;
+#pragma unroll 4
+  for (int rr = 0; rr < 16; ++rr) {
+    const int kwl = wave * 16 + rr;
+    const int64_t kwo = kw0 + kwl;
+    if (kwo < KW && n < N) qweight[kwo * N + n] = tile[lane * TILE_LD + kwl];
+  }
+}
+
+// zp [N,G] int32 (or NULL -> the symmetric zero point 2^(bits-1)) -> qzeros [G, NW] holding zp-1 packed along N
+__global__ void woq_pack_qzeros_kernel(const int32_t* __restrict__ zp, uint32_t* __restrict__ qzeros,
+                                       int64_t N, int64_t G, int64_t NW, int bits, int zconst) {
+  const int n_pack = 32 / bits;
+  const uint32_t mask = (1u << bits) - 1u;
+  const int64_t total = G * NW;
+  for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total;
+       w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = w / NW, j = w - g * NW;
+    uint32_t word = 0;
+    for (int e = 0; e < n_pack; ++e) {
+      const int64_t n = j * n_pack + e;
+      if (n < N) {
+        const int32_t z = (zp ? zp[n * G + g] : zconst) - 1;
+        word |= (static_cast<uint32_t>(z) & mask) << (bits * e);
+      }
+    }
+    qzeros[w] = word;
+  }
+}
+
+// scales [N,G] fp32 -> [G,N] fp16
+__global__ void woq_pack_scales_kernel(const float* __restrict__ s, uint16_t* __restrict__ out,
+                                       int64_t N, int64_t G) {
+  const int64_t total = G * N;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = i / N, n = i - g * N;
+    out[i] = f32_to_f16_bits(s[n * G + g]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// optimum-format unpack: qweight [KW,N] -> int_weight [N,K] int16
+// ------------------------------------------------------------------------------------------
+template <int BITS, bool VEC>
+__global__ __launch_bounds__(256) void woq_unpack_qweight_kernel(const uint32_t* __restrict__ qweight,
+                                                                 int16_t* __restrict__ out, int64_t N,
+                                                                 int64_t K, int64_t KW) {
+  constexpr int NP = 32 / BITS;
+  constexpr uint32_t MASK = (1u << BITS) - 1u;
+  __shared__ uint32_t tile[TILE * TILE_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t kw0 = (int64_t)blockIdx.x * TILE, n0 = (int64_t)blockIdx.y * TILE;
+  {
+    const int64_t n = n0 + lane;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      const int kwl = wave * 16 + rr;
+      const int64_t kw = kw0 + kwl;
+      tile[kwl * TILE_LD + lane] = (kw < KW && n < N) ? qweight[kw * N + n] : 0u;
+    }
+  }
+  __syncthreads();
+  const int64_t kw = kw0 + lane;
+#pragma unroll 4
+  for (int rr = 0; rr < 16; ++rr) {
+    const int row = wave * 16 + rr;
+    const int64_t n = n0 + row;
+    if (n >= N || kw >= KW) continue;
+    const uint32_t word = tile[lane * TILE_LD + row];
+    int16_t* dst = out + n * K + kw * NP;
+    if constexpr (VEC) {
+      static_assert(NP % 8 == 0 || NP == 4, "");
+      if constexpr (NP == 4) {
+        uint2 v;
+        v.x = (word & MASK) | (((word >> BITS) & MASK) << 16);
+        v.y = ((word >> (2 * BITS)) & MASK) | (((word >> (3 * BITS)) & MASK) << 16);
+        *reinterpret_cast<uint2*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int q = 0; q < NP / 8; ++q) {
+          uint32_t p[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int e = 8 * q + 2 * h;
+            p[h] = ((word >> (BITS * e)) & MASK) | (((word >> (BITS * (e + 1))) & MASK) << 16);
+          }
+          reinterpret_cast<uint4*>(dst)[q] = make_uint4(p[0], p[1], p[2], p[3]);
+        }
+      }
+    } else {
+      const int64_t left = K - kw * NP;
+#pragma unroll
+      for (int e = 0; e < NP; ++e)
+        if (e < left) dst[e] = static_cast<int16_t>((word >> (BITS * e)) & MASK);
+    }
+  }
+}
+
+// qzeros [G,NW] -> zp [N,G] int16: stored+1, wrap values above maxq to 0 (modules.py:407-410)
+__global__ void woq_unpack_qzeros_kernel(const uint32_t* __restrict__ qzeros, int16_t* __restrict__ zp,
+                                         int64_t N, int64_t G, int64_t NW, int bits) {
+  const int n_pack = 32 / bits;
+  const uint32_t mask = (1u << bits) - 1u;
+  const int64_t total = N * G;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / G, g = i - n * G;
+    const uint32_t word = qzeros[g * NW + n / n_pack];
+    uint32_t z = ((word >> (bits * (n % n_pack))) & mask) + 1u;
+    if (z > mask) z = 0;
+    zp[i] = static_cast<int16_t>(z);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// recover: optimum layout -> dense [N,K]
+// ------------------------------------------------------------------------------------------
+template <int DT>
+struct out_elem { using type = uint16_t; };
+template <>
+struct out_elem<INC_F32> { using type = float; };
+
+template <int DT>
+__device__ __forceinline__ typename out_elem<DT>::type enc(float v) {
+  if constexpr (DT == INC_F32) return v;
+  else if constexpr (DT == INC_F16) return f32_to_f16_bits(v);
+  else return f32_to_bf16_bits(v);
+}
+
+constexpr int DQ_KT = 128;  // k-extent of one dequant tile
+
+template <int BITS, int DT>
+__global__ __launch_bounds__(256) void woq_dequant_kernel(
+    const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
+    const uint32_t* __restrict__ qzeros, const int32_t* __restrict__ g_idx,
+    typename out_elem<DT>::type* __restrict__ out, int64_t N, int64_t K, int64_t KW, int64_t NW,
+    int group_size) {
+  using OT = typename out_elem<DT>::type;
+  constexpr int NP = 32 / BITS;
+  constexpr uint32_t MASK = (1u << BITS) - 1u;
+  constexpr int KWT = DQ_KT / NP;                      // packed rows per tile
+  constexpr int LD = DQ_KT + (DT == INC_F32 ? 1 : 8);  // padded row pitch (elements)
+  __shared__ OT tile[TILE * LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t k0 = (int64_t)blockIdx.x * DQ_KT, n0 = (int64_t)blockIdx.y * TILE;
+  const int64_t kw0 = k0 / NP;
+  const int64_t n = n0 + lane;
+  // phase 1: lane = n (coalesced packed reads), waves stride over the packed rows of the tile
+  for (int kwl = wave; kwl < KWT; kwl += 4) {
+    const int64_t kw = kw0 + kwl;
+    if (n < N && kw < KW) {
+      const uint32_t word = qweight[kw * N + n];
+      const uint32_t zsh = BITS * (uint32_t)(n % NP);
+      int64_t gprev = -1;
+      float s = 0.f;
+      int32_t z = 0;
+#pragma unroll
+      for (int e = 0; e < NP; ++e) {
+        const int64_t k = kw * NP + e;
+        if (k < K) {
+          const int64_t g = g_idx ? (int64_t)g_idx[k] : k / group_size;
+          if (g != gprev) {
+            s = f16_bits_to_f32(scales[g * N + n]);
+            uint32_t zz = ((qzeros[g * NW + n / NP] >> zsh) & MASK) + 1u;
+            z = (zz > MASK) ? 0 : (int32_t)zz;
+            gprev = g;
+          }
+          const int32_t q = (int32_t)((word >> (BITS * e)) & MASK);
+          const float v = (float)(int8_t)(q - z) * s;  // exact in fp32, one rounding below
+          tile[lane * LD + kwl * NP + e] = enc<DT>(v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // phase 2: rows of 128 contiguous elements, 16 lanes x 8 elements per row
+  const int c8 = (threadIdx.x & 15) * 8;
+  for (int row = threadIdx.x >> 4; row < TILE; row += 16) {
+    const int64_t nn = n0 + row;
+    if (nn >= N) continue;
+    const int64_t k = k0 + c8;
+    OT* dst = out + nn * K + k;
+    const OT* src = &tile[row * LD + c8];
+    bool done = false;
+    if constexpr (DT != INC_F32) {
+      if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        uint4 v;
+        v.x = (uint32_t)src[0] | ((uint32_t)src[1] << 16);
+        v.y = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
+        v.z = (uint32_t)src[4] | ((uint32_t)src[5] << 16);
+        v.w = (uint32_t)src[6] | ((uint32_t)src[7] << 16);
+        *reinterpret_cast<uint4*>(dst) = v;
+        done = true;
+      }
+    }
+    if (!done) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (k + e < K) dst[e] = src[e];
+    }
+  }
+}
+template <int SDT, int DT>
+__global__ void dequant_ints_kernel(const int16_t* __restrict__ iw, const void* __restrict__ scales,
+                                    const int16_t* __restrict__ zp, const int32_t* __restrict__ g_idx,
+                                    typename out_elem<DT>::type* __restrict__ out, int64_t N, int64_t K,
+                                    int64_t G, int group_size) {
+  const int64_t total = N * K;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / K, k = i - n * K;
+    const int64_t g = g_idx ? (int64_t)g_idx[k] : k / group_size;
+    const float s = load_as_f32<SDT>(scales, n * G + g);
+    const int32_t q = iw[i];
+    float v;
+    if (zp) v = (float)(int8_t)(q - (int32_t)zp[n * G + g]) * s;
+    else v = (float)q * s;
+    // torch computes int*scale in the scale dtype: round once to it, then to the output dtype
+    out[i] = enc<DT>(round_to<SDT>(v));
+  }
+}
+
+inline int grid_1d(int64_t total, int block = 256) {
+  int64_t g = ceil_div64(total, block);
+  const int64_t cap = 256 * 8 * 4;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int inc_abi_version(void) { return 1; }
+const char* inc_target_arch(void) { return "gfx950"; }
+const char* inc_error_string(int code) {
+  switch (code) {
+    case INC_OK: return "ok";
+    case INC_ERR_BAD_ARG: return "bad argument (null pointer / non-positive size / inconsistent shape)";
+    case INC_ERR_UNSUPPORTED: return "unsupported configuration";
+    case INC_ERR_LAUNCH: return "HIP kernel launch failed";
+    case INC_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+
+int inc_pack_rows(const int32_t* raw, void* packed, int64_t rows, int64_t cols, int bits, int cbits,
+                  inc_stream_t stream) {
+  INC_CHECK_ARG(raw && packed && rows > 0 && cols > 0);
+  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  if (!(cbits == 8 || cbits == 16 || cbits == 32 || cbits == 64) || cbits < bits) return INC_ERR_UNSUPPORTED;
+  const int n_pack = cbits / bits;
+  const int64_t pcols = ceil_div64(cols, n_pack);
+  const int grid = grid_1d(rows * pcols);
+  hipStream_t s = inc_s(stream);
+  switch (cbits) {
+    case 8: pack_rows_kernel<uint8_t><<<grid, 256, 0, s>>>(raw, (uint8_t*)packed, rows, cols, pcols, bits, n_pack); break;
+    case 16: pack_rows_kernel<uint16_t><<<grid, 256, 0, s>>>(raw, (uint16_t*)packed, rows, cols, pcols, bits, n_pack); break;
+    case 32: pack_rows_kernel<uint32_t><<<grid, 256, 0, s>>>(raw, (uint32_t*)packed, rows, cols, pcols, bits, n_pack); break;
+    default: pack_rows_kernel<uint64_t><<<grid, 256, 0, s>>>(raw, (uint64_t*)packed, rows, cols, pcols, bits, n_pack); break;
+  }
+  INC_LAUNCH_RETURN();
+}
+
+int inc_unpack_rows(const void* packed, int16_t* out, int64_t rows, int64_t packed_cols, int bits,
+                    int cbits, int mask_sign, inc_stream_t stream) {
+  INC_CHECK_ARG(packed && out && rows > 0 && packed_cols > 0);
+  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  if (!(cbits == 8 || cbits == 16 || cbits == 32 || cbits == 64) || cbits < bits) return INC_ERR_UNSUPPORTED;
+  const int n_pack = cbits / bits;
+  const int grid = grid_1d(rows * packed_cols);
+  hipStream_t s = inc_s(stream);
+  switch (cbits) {
+    case 8: unpack_rows_kernel<int8_t, uint8_t><<<grid, 256, 0, s>>>((const uint8_t*)packed, out, rows, packed_cols, bits, n_pack, cbits, mask_sign); break;
+    case 16: unpack_rows_kernel<int16_t, uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)packed, out, rows, packed_cols, bits, n_pack, cbits, mask_sign); break;
+    case 32: unpack_rows_kernel<int32_t, uint32_t><<<grid, 256, 0, s>>>((const uint32_t*)packed, out, rows, packed_cols, bits, n_pack, cbits, mask_sign); break;
+    default: unpack_rows_kernel<int64_t, uint64_t><<<grid, 256, 0, s>>>((const uint64_t*)packed, out, rows, packed_cols, bits, n_pack, cbits, mask_sign); break;
+  }
+  INC_LAUNCH_RETURN();
+}
+
+int inc_woq_pack(const void* int_weight, int in_bytes, const float* scales, const int32_t* zp,
+                 int32_t* qweight, int32_t* qzeros, uint16_t* scales_out, int64_t N, int64_t K,
+                 int64_t G, int bits, int shift, inc_stream_t stream) {
+  INC_CHECK_ARG(int_weight && qweight && N > 0 && K > 0 && G > 0);
+  INC_CHECK_ARG(in_bytes == 4 || in_bytes == 1);
+  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  hipStream_t s = inc_s(stream);
+  const int n_pack = 32 / bits;
+  const int64_t KW = ceil_div64(K, n_pack), NW = ceil_div64(N, n_pack);
+  dim3 grid((unsigned)ceil_div64(KW, TILE), (unsigned)ceil_div64(N, TILE));
+  const bool vec = in_bytes == 4 && (K % n_pack == 0) && (K % 4 == 0) &&
+                   ((reinterpret_cast<uintptr_t>(int_weight) & 15) == 0);
+  uint32_t* qw = reinterpret_cast<uint32_t*>(qweight);
+#define INC_PACK_LAUNCH(B)                                                                              \
+  if (in_bytes == 4) {                                                                                  \
+    if (vec) woq_pack_qweight_kernel<B, int32_t, true><<<grid, 256, 0, s>>>((const int32_t*)int_weight, qw, N, K, KW, shift); \
+    else woq_pack_qweight_kernel<B, int32_t, false><<<grid, 256, 0, s>>>((const int32_t*)int_weight, qw, N, K, KW, shift);    \
+  } else {                                                                                              \
+    woq_pack_qweight_kernel<B, int8_t, false><<<grid, 256, 0, s>>>((const int8_t*)int_weight, qw, N, K, KW, shift);           \
+  }
+  if (bits == 4) { INC_PACK_LAUNCH(4) } else if (bits == 8) { INC_PACK_LAUNCH(8) } else { INC_PACK_LAUNCH(2) }
+#undef INC_PACK_LAUNCH
+  if (qzeros)
+    woq_pack_qzeros_kernel<<<grid_1d(G * NW), 256, 0, s>>>(zp, reinterpret_cast<uint32_t*>(qzeros), N, G, NW, bits, 1 << (bits - 1));
+  if (scales && scales_out)
+    woq_pack_scales_kernel<<<grid_1d(G * N), 256, 0, s>>>(scales, scales_out, N, G);
+  INC_LAUNCH_RETURN();
+}
+
+int inc_woq_unpack(const int32_t* qweight, const int32_t* qzeros, int16_t* int_weight, int16_t* zp,
+                   int64_t N, int64_t K, int64_t G, int bits, inc_stream_t stream) {
+  INC_CHECK_ARG(N > 0 && K > 0 && G > 0);
+  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  hipStream_t s = inc_s(stream);
+  const int n_pack = 32 / bits;
+  const int64_t KW = ceil_div64(K, n_pack), NW = ceil_div64(N, n_pack);
+  if (int_weight) {
+    INC_CHECK_ARG(qweight);
+    dim3 grid((unsigned)ceil_div64(KW, TILE), (unsigned)ceil_div64(N, TILE));
+    const bool vec = (K % n_pack == 0) && (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(int_weight) & 15) == 0);
+    const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
+    if (bits == 4) {
+      if (vec) woq_unpack_qweight_kernel<4, true><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
+      else woq_unpack_qweight_kernel<4, false><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
+    } else if (bits == 8) {
+      if (vec) woq_unpack_qweight_kernel<8, true><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
+      else woq_unpack_qweight_kernel<8, false><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
+    } else {
+      if (vec) woq_unpack_qweight_kernel<2, true><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
+      else woq_unpack_qweight_kernel<2, false><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
+    }
+  }
+  if (zp) {
+    INC_CHECK_ARG(qzeros);
+    woq_unpack_qzeros_kernel<<<grid_1d(N * G), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(qzeros), zp, N, G, NW, bits);
+  }
+  INC_LAUNCH_RETURN();
+}
+
+int inc_woq_dequant(const int32_t* qweight, const uint16_t* scales, const int32_t* qzeros,
+                    const int32_t* g_idx, void* out, int out_dtype, int64_t N, int64_t K, int64_t G,
+                    int group_size, int bits, inc_stream_t stream) {
+  INC_CHECK_ARG(qweight && scales && qzeros && out && N > 0 && K > 0 && G > 0 && group_size > 0);
+  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  hipStream_t s = inc_s(stream);
+  const int n_pack = 32 / bits;
+  const int64_t KW = ceil_div64(K, n_pack), NW = ceil_div64(N, n_pack);
+  dim3 grid((unsigned)ceil_div64(K, DQ_KT), (unsigned)ceil_div64(N, TILE));
+  const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
+  const uint32_t* qz = reinterpret_cast<const uint32_t*>(qzeros);
+#define INC_DQ_LAUNCH(B, D) \
+  woq_dequant_kernel<B, D><<<grid, 256, 0, s>>>(qw, scales, qz, g_idx, (typename out_elem<D>::type*)out, N, K, KW, NW, group_size)
+  if (out_dtype == INC_F32) {
+    if (bits == 4) INC_DQ_LAUNCH(4, INC_F32); else if (bits == 8) INC_DQ_LAUNCH(8, INC_F32); else INC_DQ_LAUNCH(2, INC_F32);
+  } else if (out_dtype == INC_F16) {
+    if (bits == 4) INC_DQ_LAUNCH(4, INC_F16); else if (bits == 8) INC_DQ_LAUNCH(8, INC_F16); else INC_DQ_LAUNCH(2, INC_F16);
+  } else if (out_dtype == INC_BF16) {
+    if (bits == 4) INC_DQ_LAUNCH(4, INC_BF16); else if (bits == 8) INC_DQ_LAUNCH(8, INC_BF16); else INC_DQ_LAUNCH(2, INC_BF16);
+  } else {
+    return INC_ERR_UNSUPPORTED;
+  }
+#undef INC_DQ_LAUNCH
+  INC_LAUNCH_RETURN();
+}
+
+int inc_dequant_ints(const int16_t* int_weight, const void* scales, int scale_dtype,
+                     const int16_t* zp, const int32_t* g_idx, void* out, int out_dtype, int64_t N,
+                     int64_t K, int64_t G, int group_size, inc_stream_t stream) {
+  INC_CHECK_ARG(int_weight && scales && out && N > 0 && K > 0 && G > 0 && group_size > 0);
+  hipStream_t s = inc_s(stream);
+  const int grid = grid_1d(N * K);
+  INC_DISPATCH_DTYPE(scale_dtype, SDT, {
+    INC_DISPATCH_DTYPE(out_dtype, DT, {
+      dequant_ints_kernel<SDT, DT><<<grid, 256, 0, s>>>(int_weight, scales, zp, g_idx,
+                                                       (typename out_elem<DT>::type*)out, N, K, G, group_size);
+    })
+  })
+  INC_LAUNCH_RETURN();
+}
+
+}  // extern "C"

@@ -1,0 +1,319 @@
+// quant.hip -- K7: group-wise round-to-nearest quantisation (RTN / AWQ inner op), GPTQ find_params,
+// and the squared-error reduction used by the clip / scale searches.
+//
+// Reference arithmetic (file:line relative to /root/reference/neural_compressor/torch/algorithms/
+// weight_only/): quant_tensor utility.py:272-436, qdq_weight_sym :199-244, qdq_weight_asym :162-196,
+// search_clip loss :468, Quantizer.find_params gptq.py:1501-1624.
+//
+// HBM-bound streaming kernels.  A "team" of L lanes (L = 2^j <= 64, L*8 >= group length when the group
+// fits) owns one (row, group) pair; every lane moves 8 contiguous elements (16 B bf16 / 32 B fp32) per
+// step, min/max are reduced with xor-shuffles inside the team, so a wave streams 64/L consecutive
+// groups of one row with full-line transactions.
+//
+// torch semantics that are reproduced on purpose:
+//   * every torch op on a bf16/fp16 tensor rounds its result to that dtype (round_to<DT>);
+//   * qdq_weight_asym builds its statistics against an fp32 zeros tensor (utility.py:176-178), so the
+//     asym scale / zero-point are fp32 even for a bf16 weight, the sym ones are in the weight dtype;
+//   * x / scale is a true IEEE division, rounding is half-to-even (rintf).
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+
+template <int DT>
+__device__ __forceinline__ void load8(const void* p, int64_t idx, int nvalid, bool vec, float (&v)[8]) {
+  if (vec && nvalid >= 8) {
+    if constexpr (DT == INC_F32) {
+      const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(p) + idx);
+      const float4 b = *reinterpret_cast<const float4*>(static_cast<const float*>(p) + idx + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+      const uint4 u = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p) + idx);
+      const uint32_t r[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (DT == INC_BF16) {
+          v[2 * i] = __uint_as_float(r[i] << 16);
+          v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+        } else {
+          v[2 * i] = f16_bits_to_f32((uint16_t)(r[i] & 0xffffu));
+          v[2 * i + 1] = f16_bits_to_f32((uint16_t)(r[i] >> 16));
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (i < nvalid) ? load_as_f32<DT>(p, idx + i) : 0.f;
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ void store8(void* p, int64_t idx, int nvalid, bool vec, const float (&v)[8]) {
+  if (vec && nvalid >= 8) {
+    if constexpr (DT == INC_F32) {
+      *reinterpret_cast<float4*>(static_cast<float*>(p) + idx) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(static_cast<float*>(p) + idx + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      uint32_t r[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint16_t lo, hi;
+        if constexpr (DT == INC_BF16) { lo = f32_to_bf16_bits(v[2 * i]); hi = f32_to_bf16_bits(v[2 * i + 1]); }
+        else { lo = f32_to_f16_bits(v[2 * i]); hi = f32_to_f16_bits(v[2 * i + 1]); }
+        r[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+      }
+      *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p) + idx) = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nvalid) store_from_f32<DT>(p, idx + i, v[i]);
+  }
+}
+
+__device__ __forceinline__ void store8_i32(int32_t* p, int64_t idx, int nvalid, bool vec, const int (&v)[8]) {
+  if (vec && nvalid >= 8) {
+    *reinterpret_cast<int4*>(p + idx) = make_int4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<int4*>(p + idx + 4) = make_int4(v[4], v[5], v[6], v[7]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nvalid) p[idx + i] = v[i];
+  }
+}
+
+struct QParams {
+  float scale;  // quantisation step (sign carries the full_range flip)
+  float zp;     // asym zero point (0 for sym)
+  float qmin, qmax;
+};
+
+// ---- group-wise RTN -----------------------------------------------------------------------------
+template <int DT, bool SYM>
+__global__ __launch_bounds__(256) void groupwise_quant_kernel(
+    const void* __restrict__ w, void* qdq, int32_t* __restrict__ iout, float* __restrict__ scale_out,
+    float* __restrict__ zp_out, int64_t N, int64_t K, int64_t G, int gs, int L, int bits,
+    float quantile, int full_range, int vec_ok) {
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & (L - 1);
+  const int team = lane / L;
+  const int teams_per_wave = 64 / L;
+  const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t pair = wave_global * teams_per_wave + team;
+  const bool active = pair < N * G;
+  if (!active) pair = N * G - 1;  // keep the lanes alive for the shuffles, mask the stores
+  const int64_t n = pair / G, g = pair - n * G;
+  const int64_t kbeg = g * gs;
+  const int klen = (int)((K - kbeg) < gs ? (K - kbeg) : gs);
+  const int64_t base = n * K + kbeg;
+  const bool vec = vec_ok != 0;
+
+  float vmax = -INFINITY, vmin = INFINITY;
+  float keep[8];
+  for (int c = tl; c * 8 < klen; c += L) {
+    float v[8];
+    const int nv = klen - c * 8;
+    load8<DT>(w, base + c * 8, nv, vec, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nv) { vmax = fmaxf(vmax, v[i]); vmin = fminf(vmin, v[i]); }
+    if (c == tl) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) keep[i] = v[i];
+    }
+  }
+  for (int o = L >> 1; o > 0; o >>= 1) {
+    vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    vmin = fminf(vmin, __shfl_xor(vmin, o, 64));
+  }
+
+  QParams q;
+  if constexpr (SYM) {
+    // utility.py:216-237 -- statistics stay in the weight dtype
+    float maxq = (float)((1 << (bits - 1)) - 1), minq = -(float)(1 << (bits - 1));
+    if (bits == 1) { maxq = 1.f; minq = 0.f; }
+    const bool flip = fabsf(vmax) > fabsf(vmin);
+    float wmax = fmaxf(fabsf(vmax), fabsf(vmin));
+    wmax = round_to<DT>(wmax * quantile);
+    if (wmax == 0.f) wmax = 1.f;
+    float scale;
+    if (full_range) {
+      scale = round_to<DT>(wmax / (-minq));
+      if (flip) scale = -scale;
+    } else {
+      scale = round_to<DT>(wmax / maxq);
+    }
+    q.scale = scale; q.zp = 0.f; q.qmin = minq; q.qmax = maxq;
+  } else {
+    // utility.py:174-188 -- fp32 statistics (torch.zeros(...) is fp32 and promotes)
+    const float maxq = (float)((1 << bits) - 1);
+    float wmin = fminf(vmin, 0.f) * quantile;
+    float wmax = fmaxf(vmax, 0.f) * quantile;
+    if (wmin == 0.f && wmax == 0.f) { wmin = -1.f; wmax = 1.f; }
+    const float scale = (wmax - wmin) / maxq;
+    q.scale = scale; q.zp = rintf(-wmin / scale); q.qmin = 0.f; q.qmax = maxq;
+  }
+  if (active && tl == 0) {
+    if (scale_out) scale_out[pair] = q.scale;
+    if (!SYM && zp_out) zp_out[pair] = q.zp;
+  }
+
+  for (int c = tl; c * 8 < klen; c += L) {
+    float v[8];
+    const int nv = klen - c * 8;
+    if (c == tl) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = keep[i];
+    } else {
+      load8<DT>(w, base + c * 8, nv, vec, v);
+    }
+    int iv[8];
+    float dq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float t = round_to<DT>(v[i] / q.scale);
+      t = rintf(t);
+      if constexpr (!SYM) t = round_to<DT>(t + q.zp);
+      t = fminf(fmaxf(t, q.qmin), q.qmax);
+      iv[i] = (int)t;
+      if constexpr (!SYM) t = round_to<DT>(t - q.zp);
+      dq[i] = round_to<DT>(t * q.scale);
+    }
+    if (active) {
+      if (iout) store8_i32(iout, base + c * 8, nv, vec, iv);
+      if (qdq) store8<DT>(qdq, base + c * 8, nv, vec, dq);
+    }
+  }
+}
+
+// ---- GPTQ Quantizer.find_params (weight=True, perchannel, int, no mse) ---------------------------
+__global__ __launch_bounds__(256) void gptq_find_params_kernel(
+    const float* __restrict__ w, int64_t N, int64_t K, int64_t col0,
+    int gs, int ngroups, int L, int bits, int sym, float* __restrict__ scale, float* __restrict__ zero,
+    int64_t G, int64_t g0) {
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & (L - 1);
+  const int team = lane / L;
+  const int teams_per_wave = 64 / L;
+  const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t pair = wave_global * teams_per_wave + team;
+  const int64_t total = N * ngroups;
+  const bool active = pair < total;
+  if (!active) pair = total - 1;
+  const int64_t n = pair / ngroups, g = pair - n * ngroups;
+  const int64_t kbeg = col0 + g * gs;
+  const int klen = (int)((K - kbeg) < gs ? (K - kbeg) : gs);
+  float vmax = -INFINITY, vmin = INFINITY;
+  for (int k = tl; k < klen; k += L) {
+    const float x = w[n * K + kbeg + k];
+    vmax = fmaxf(vmax, x);
+    vmin = fminf(vmin, x);
+  }
+  for (int o = L >> 1; o > 0; o >>= 1) {
+    vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    vmin = fminf(vmin, __shfl_xor(vmin, o, 64));
+  }
+  // gptq.py:1547-1571
+  const float maxq = (float)((1 << bits) - 1);
+  float xmin = fminf(vmin, 0.f), xmax = fmaxf(vmax, 0.f);
+  if (sym) {
+    xmax = fmaxf(fabsf(xmin), xmax);
+    if (xmin < 0.f) xmin = -xmax;
+  }
+  if (xmin == 0.f && xmax == 0.f) { xmin = -1.f; xmax = 1.f; }
+  const float s = (xmax - xmin) / maxq;
+  const float z = sym ? (maxq + 1.f) * 0.5f : rintf(-xmin / s);
+  if (active && tl == 0) {
+    scale[n * G + g0 + g] = s;
+    zero[n * G + g0 + g] = z;
+  }
+}
+
+// ---- sum((a-b)^2) ---------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void mse_accumulate_kernel(const void* __restrict__ a,
+                                                             const void* __restrict__ b, int64_t n,
+                                                             float* __restrict__ out, int vec_ok) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  const int64_t nchunk = (n + 7) / 8;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk;
+       c += (int64_t)gridDim.x * blockDim.x) {
+    float va[8], vb[8];
+    const int64_t left = n - c * 8;
+    const int nv = left < 8 ? (int)left : 8;
+    load8<DT>(a, c * 8, nv, vec_ok != 0, va);
+    load8<DT>(b, c * 8, nv, vec_ok != 0, vb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float d = round_to<DT>(va[i] - vb[i]);  // the subtraction happens in the tensor dtype
+      acc += d * d;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+inline int team_lanes(int gs) {
+  int need = (gs + 7) / 8, L = 1;
+  while (L < need && L < 64) L <<= 1;
+  return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int inc_groupwise_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_out, float* scale_out,
+                        float* zp_out, int64_t N, int64_t K, int group_size, int bits, int scheme,
+                        float quantile, int full_range, inc_stream_t stream) {
+  INC_CHECK_ARG(w && N > 0 && K > 0 && bits >= 1 && bits <= 8);
+  int gs = group_size;
+  if (gs <= 0 || gs > K) gs = (int)K;  // utility.py:306-307
+  const int64_t G = ceil_div64(K, gs);
+  const int L = team_lanes(gs);
+  const int64_t waves = ceil_div64(N * G, 64 / L);
+  const int64_t blocks = ceil_div64(waves, 4);
+  const int esz = wdtype == INC_F32 ? 4 : 2;
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int vec_ok = (K % 8 == 0) && (gs % 8 == 0) && al(w) && al(qdq_out) && al(int_out);
+  (void)esz;
+  hipStream_t s = inc_s(stream);
+  INC_DISPATCH_DTYPE(wdtype, DT, {
+    if (scheme == INC_SCHEME_SYM)
+      groupwise_quant_kernel<DT, true><<<(unsigned)blocks, 256, 0, s>>>(w, qdq_out, int_out, scale_out, zp_out, N, K, G, gs, L, bits, quantile, full_range, vec_ok);
+    else
+      groupwise_quant_kernel<DT, false><<<(unsigned)blocks, 256, 0, s>>>(w, qdq_out, int_out, scale_out, zp_out, N, K, G, gs, L, bits, quantile, full_range, vec_ok);
+  })
+  INC_LAUNCH_RETURN();
+}
+
+int inc_gptq_find_params(const float* w, int64_t N, int64_t K, int64_t col0, int group_size,
+                         int ngroups, int bits, int sym, float* scale, float* zero, int64_t G,
+                         int64_t g0, inc_stream_t stream) {
+  INC_CHECK_ARG(w && scale && zero && N > 0 && K > 0 && ngroups > 0 && group_size > 0);
+  INC_CHECK_ARG(col0 >= 0 && col0 < K && g0 >= 0 && g0 + ngroups <= G && bits >= 1 && bits <= 8);
+  int L = 1;
+  while (L < group_size && L < 64) L <<= 1;
+  const int64_t waves = ceil_div64(N * ngroups, 64 / L);
+  gptq_find_params_kernel<<<(unsigned)ceil_div64(waves, 4), 256, 0, inc_s(stream)>>>(
+      w, N, K, col0, group_size, ngroups, L, bits, sym, scale, zero, G, g0);
+  INC_LAUNCH_RETURN();
+}
+
+int inc_mse_accumulate(const void* a, const void* b, int dtype, int64_t n, float* out,
+                       inc_stream_t stream) {
+  INC_CHECK_ARG(a && b && out && n > 0);
+  const int vec_ok = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+  int64_t blocks = ceil_div64(ceil_div64(n, 8), 256);
+  if (blocks > 2048) blocks = 2048;
+  INC_DISPATCH_DTYPE(dtype, DT, {
+    mse_accumulate_kernel<DT><<<(unsigned)blocks, 256, 0, inc_s(stream)>>>(a, b, n, out, vec_ok);
+  })
+  INC_LAUNCH_RETURN();
+}
+
+}  // extern "C"

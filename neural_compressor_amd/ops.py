@@ -1,0 +1,355 @@
+"""Tensor-level wrappers over the C-ABI (device memory and streams come from PyTorch-ROCm, arithmetic does not).
+
+Every function takes torch tensors that already live in HBM (`device.type == "cuda"`, i.e. HIP on ROCm),
+passes `data_ptr()` + sizes + the current HIP stream to libinc_mi355x.so and returns torch tensors.
+Host tensors are rejected: there is no CPU path.
+"""
+
+import torch
+
+from ._lib import INC_BF16, INC_F16, INC_F32, INC_SCHEME_ASYM, INC_SCHEME_SYM, check, lib
+
+_DT = {torch.float32: INC_F32, torch.float16: INC_F16, torch.bfloat16: INC_BF16}
+
+
+def dtype_code(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError as e:
+        raise TypeError(f"unsupported floating dtype {dtype}; expected fp32/fp16/bf16") from e
+
+
+def _dev(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                f"MI355X op got a tensor on {t.device}; tensors must be resident in HBM (device 'cuda' = HIP). "
+                "There is no CPU fallback."
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+        if not t.is_contiguous():
+            raise RuntimeError("MI355X ops need contiguous tensors")
+    return dev
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------------------------------
+# K1/K2 generic row packers
+# ---------------------------------------------------------------------------------------------------
+_CT = {8: torch.int8, 16: torch.int16, 32: torch.int32, 64: torch.int64}
+
+
+def pack_rows(raw, bits, compress_bits):
+    """== INCWeightOnlyLinear.pack_tensor (modules.py:580): [R,C] ints -> [R, ceil(C/n_pack)] words."""
+    raw = raw.to(torch.int32).contiguous()
+    dev = _dev(raw)
+    n_pack = compress_bits // bits
+    rows, cols = raw.shape
+    out = torch.empty((rows, (cols + n_pack - 1) // n_pack), dtype=_CT[compress_bits], device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_pack_rows(_ptr(raw), _ptr(out), rows, cols, bits, compress_bits, _stream()), "inc_pack_rows")
+    return out
+
+
+def unpack_rows(packed, bits, compress_bits, mask_sign):
+    """== INCWeightOnlyLinear.unpack_tensor (modules.py:587): -> int16 [R, C*n_pack]."""
+    packed = packed.contiguous()
+    dev = _dev(packed)
+    n_pack = compress_bits // bits
+    rows, pcols = packed.shape
+    out = torch.empty((rows, pcols * n_pack), dtype=torch.int16, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_unpack_rows(_ptr(packed), _ptr(out), rows, pcols, bits, compress_bits, int(bool(mask_sign)), _stream()),
+            "inc_unpack_rows",
+        )
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# optimum-format pack / unpack / recover
+# ---------------------------------------------------------------------------------------------------
+def woq_pack(int_weight, scales, zp, bits, shift, qweight=None, qzeros=None, scales_out=None):
+    """== INCWeightOnlyLinear.pack (optimum format, modules.py:321-375).
+
+    int_weight [N,K] int32 or int8/uint8; scales [N,G] fp32; zp [N,G] int32 or None (sym -> `shift`).
+    Returns (qweight [K/np, N] int32, qzeros [G, N/np] int32, scales fp16 [G, N]).
+    """
+    N, K = int_weight.shape
+    G = scales.shape[1]
+    n_pack = 32 // bits
+    if int_weight.dtype in (torch.int8, torch.uint8):
+        in_bytes = 1
+    else:
+        int_weight = int_weight.to(torch.int32)
+        in_bytes = 4
+    int_weight = int_weight.contiguous()
+    scales = scales.to(torch.float32).contiguous()
+    zp = None if zp is None else zp.to(torch.int32).contiguous()
+    dev = _dev(int_weight, scales, zp)
+    if qweight is None:
+        qweight = torch.empty(((K + n_pack - 1) // n_pack, N), dtype=torch.int32, device=dev)
+    if qzeros is None:
+        qzeros = torch.empty((G, (N + n_pack - 1) // n_pack), dtype=torch.int32, device=dev)
+    if scales_out is None:
+        scales_out = torch.empty((G, N), dtype=torch.float16, device=dev)
+    _dev(qweight, qzeros, scales_out)
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_woq_pack(
+                _ptr(int_weight), in_bytes, _ptr(scales), _ptr(zp), _ptr(qweight), _ptr(qzeros), _ptr(scales_out),
+                N, K, G, bits, shift, _stream(),
+            ),
+            "inc_woq_pack",
+        )
+    return qweight, qzeros, scales_out
+
+
+def woq_unpack(qweight, qzeros, N, K, G, bits, want_weight=True, want_zp=True):
+    """== INCWeightOnlyLinear.unpack (modules.py:377-411): (int_weight [N,K] int16, zp [N,G] int16)."""
+    dev = _dev(qweight, qzeros)
+    iw = torch.empty((N, K), dtype=torch.int16, device=dev) if want_weight else None
+    zp = torch.empty((N, G), dtype=torch.int16, device=dev) if want_zp else None
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_woq_unpack(_ptr(qweight), _ptr(qzeros), _ptr(iw), _ptr(zp), N, K, G, bits, _stream()),
+            "inc_woq_unpack",
+        )
+    return iw, zp
+
+
+def woq_dequant(qweight, scales, qzeros, g_idx, N, K, group_size, bits, out_dtype=torch.float16):
+    """== INCWeightOnlyLinear.recover (modules.py:413-443) from the optimum layout -> dense [N,K]."""
+    dev = _dev(qweight, scales, qzeros, g_idx)
+    assert scales.dtype == torch.float16, "optimum-format scales are fp16 (modules.py:245)"
+    G = scales.shape[0]
+    out = torch.empty((N, K), dtype=out_dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_woq_dequant(
+                _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(g_idx), _ptr(out), dtype_code(out_dtype),
+                N, K, G, group_size, bits, _stream(),
+            ),
+            "inc_woq_dequant",
+        )
+    return out
+
+
+def dequant_ints(int_weight, scales, zp, g_idx, group_size, out_dtype):
+    """recover() for non-optimum layouts: int16 [N,K], scales [N,G] (any float dtype), zp int16 [N,G] or None."""
+    int_weight = int_weight.to(torch.int16).contiguous()
+    zp = None if zp is None else zp.to(torch.int16).contiguous()
+    scales = scales.contiguous()
+    dev = _dev(int_weight, scales, zp, g_idx)
+    N, K = int_weight.shape
+    G = scales.shape[1]
+    out = torch.empty((N, K), dtype=out_dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_dequant_ints(
+                _ptr(int_weight), _ptr(scales), dtype_code(scales.dtype), _ptr(zp), _ptr(g_idx), _ptr(out),
+                dtype_code(out_dtype), N, K, G, group_size, _stream(),
+            ),
+            "inc_dequant_ints",
+        )
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# K4 fused GEMM
+# ---------------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(dev, nbytes):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = buf
+    return buf
+
+
+def woq_gemm(x2d, qweight, scales, qzeros, bias, N, K, group_size, bits, g_idx=None):
+    """y[M,N] = x[M,K] @ dequant(qweight)^T + bias, fused (== INCWeightOnlyLinear.forward, modules.py:594-610)."""
+    dev = _dev(x2d, qweight, scales, qzeros, bias, g_idx)
+    if x2d.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError("woq_gemm computes in bf16 or fp16")
+    if bias is not None and bias.dtype != x2d.dtype:
+        bias = bias.to(x2d.dtype)
+    M = x2d.shape[0]
+    G = scales.shape[0]
+    y = torch.empty((M, N), dtype=x2d.dtype, device=dev)
+    nbytes = lib.inc_woq_gemm_workspace_bytes(M, N, K)
+    ws = _workspace(dev, nbytes) if nbytes > 0 else None
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_woq_gemm(
+                _ptr(x2d), dtype_code(x2d.dtype), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(g_idx), _ptr(bias),
+                _ptr(y), M, N, K, G, group_size, bits, _ptr(ws), 0 if ws is None else ws.numel(), _stream(),
+            ),
+            "inc_woq_gemm",
+        )
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------
+# K7 group-wise RTN
+# ---------------------------------------------------------------------------------------------------
+def groupwise_quant(w, bits, group_size, scheme, quantile=1.0, full_range=False, return_int=False, inplace=True):
+    """== quant_tensor (utility.py:272-436) for dtype "int".
+
+    return_int=False: fake-quantises `w` (in place when `inplace`) and returns it.
+    return_int=True : returns (int_weight int32 [N,K], scale fp32 [N,G], zp fp32 [N,G] or None); `w` is untouched.
+    """
+    dev = _dev(w)
+    N, K = w.shape
+    gs = K if (group_size == -1 or K < group_size) else group_size
+    G = (K + gs - 1) // gs
+    sym = scheme == "sym"
+    scale = torch.empty((N, G), dtype=torch.float32, device=dev)
+    zp = None if sym else torch.empty((N, G), dtype=torch.float32, device=dev)
+    if return_int:
+        iw = torch.empty((N, K), dtype=torch.int32, device=dev)
+        qdq = None
+    else:
+        iw = None
+        qdq = w if inplace else torch.empty_like(w)
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_groupwise_quant(
+                _ptr(w), dtype_code(w.dtype), _ptr(qdq), _ptr(iw), _ptr(scale), _ptr(zp), N, K, gs, bits,
+                INC_SCHEME_SYM if sym else INC_SCHEME_ASYM, float(quantile), int(bool(full_range)), _stream(),
+            ),
+            "inc_groupwise_quant",
+        )
+    if return_int:
+        return iw, scale, zp
+    return qdq
+
+
+def mse_accumulate(a, b, out=None):
+    """out += sum((a-b)^2) (fp32 scalar tensor on device)."""
+    dev = _dev(a, b)
+    assert a.dtype == b.dtype and a.numel() == b.numel()
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_mse_accumulate(_ptr(a), _ptr(b), dtype_code(a.dtype), a.numel(), _ptr(out), _stream()), "inc_mse_accumulate")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# K5/K6 GPTQ
+# ---------------------------------------------------------------------------------------------------
+def gptq_hessian_accum(H, x2d, beta, alpha):
+    """H <- beta*H + alpha * x^T x on the upper-triangular tiles (== GPTQ.add_batch, gptq.py:1111-1141)."""
+    dev = _dev(H)
+    if x2d.device.type != "cuda":
+        raise RuntimeError("calibration activations must be resident in HBM")
+    assert x2d.dim() == 2 and x2d.stride(1) == 1, "x must be [T,K] with unit inner stride"
+    T, K = x2d.shape
+    assert H.shape == (K, K) and H.dtype == torch.float32
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_gptq_hessian_accum(
+                x2d.data_ptr(), dtype_code(x2d.dtype), T, K, x2d.stride(0), _ptr(H), float(beta), float(alpha), _stream()
+            ),
+            "inc_gptq_hessian_accum",
+        )
+    return H
+
+
+def gptq_hessian_finalize(H, percdamp):
+    """mirror + dead-column fix + damping (gptq.py:1186-1189, 1221-1227). Returns the uint8 dead mask [K]."""
+    dev = _dev(H)
+    K = H.shape[0]
+    dead = torch.empty(K, dtype=torch.uint8, device=dev)
+    ws = torch.empty(4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_gptq_hessian_finalize(_ptr(H), K, float(percdamp), _ptr(dead), _ptr(ws), _stream()), "inc_gptq_hessian_finalize")
+    return dead
+
+
+def gptq_prepare_weight(w, dead=None):
+    """W.float() with dead columns zeroed (gptq.py:1176, 1189)."""
+    w = w.contiguous()
+    dev = _dev(w, dead)
+    N, K = w.shape
+    out = torch.empty((N, K), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_gptq_prepare_weight(_ptr(w), dtype_code(w.dtype), _ptr(out), _ptr(dead), N, K, _stream()), "inc_gptq_prepare_weight")
+    return out
+
+
+def gptq_find_params(w32, col0, group_size, ngroups, bits, sym, scale, zero, g0):
+    dev = _dev(w32, scale, zero)
+    N, K = w32.shape
+    G = scale.shape[1]
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_gptq_find_params(_ptr(w32), N, K, col0, group_size, ngroups, bits, int(bool(sym)), _ptr(scale), _ptr(zero), G, g0, _stream()),
+            "inc_gptq_find_params",
+        )
+
+
+def gptq_quant_block(w32, hinv, scale, zero, codes, q_out, err, i1, count, group_size, bits):
+    dev = _dev(w32, hinv, scale, zero, codes, q_out, err)
+    N, K = w32.shape
+    G = scale.shape[1]
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_gptq_quant_block(
+                _ptr(w32), _ptr(hinv), _ptr(scale), _ptr(zero), _ptr(codes), _ptr(q_out),
+                dtype_code(q_out.dtype) if q_out is not None else INC_F32, _ptr(err), N, K, G, i1, count,
+                group_size, bits, _stream(),
+            ),
+            "inc_gptq_quant_block",
+        )
+
+
+def gptq_lazy_update(w32, hinv, err, i1, count):
+    dev = _dev(w32, hinv, err)
+    N, K = w32.shape
+    with torch.cuda.device(dev):
+        check(lib.inc_gptq_lazy_update(_ptr(w32), _ptr(hinv), _ptr(err), N, K, i1, count, _stream()), "inc_gptq_lazy_update")
+
+
+# ---------------------------------------------------------------------------------------------------
+# K8 AWQ statistics
+# ---------------------------------------------------------------------------------------------------
+def awq_act_abs_sum(x2d, out):
+    dev = _dev(x2d, out)
+    T, K = x2d.shape
+    with torch.cuda.device(dev):
+        check(lib.inc_awq_act_abs_sum(_ptr(x2d), dtype_code(x2d.dtype), T, K, _ptr(out), _stream()), "inc_awq_act_abs_sum")
+    return out
+
+
+def awq_weight_scale(w, group_size):
+    """== _get_weight_scale (awq.py:131-147): mean over rows of |w|/groupmax|w| -> [K] in w.dtype."""
+    w = w.contiguous()
+    dev = _dev(w)
+    N, K = w.shape
+    out = torch.zeros(K, dtype=torch.float32, device=dev)
+    nbytes = lib.inc_awq_weight_scale_workspace_bytes(N, K, group_size)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_awq_weight_scale(_ptr(w), dtype_code(w.dtype), N, K, group_size, _ptr(out), _ptr(ws), nbytes, _stream()),
+            "inc_awq_weight_scale",
+        )
+    return (out / N).to(w.dtype)

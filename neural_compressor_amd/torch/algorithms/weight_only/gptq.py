@@ -1,0 +1,524 @@
+"""GPTQ on the MI355X: Hessian accumulation on the matrix cores, the blocked column loop as HIP kernels.
+
+Reference: neural_compressor/torch/algorithms/weight_only/gptq.py
+  trace_gptq_target_blocks :68    find_layers :144
+  RAWGPTQuantizer          :184   prepare_for_calibration :399, execute_quantization :568
+  GPTQ                     :1089  add_batch :1111, fasterquant :1143
+  Quantizer.find_params    :1501  quantize :1626
+  GPTQuantizer             :1651
+
+The orchestration (capture block-0 inputs, per block: hooks + forward over all calibration batches ->
+fasterquant per Linear -> second forward with the quantised weights -> pack) is the reference's, kept in
+Python.  The arithmetic is not:
+  * add_batch      -> inc_gptq_hessian_accum   (bf16/f16 MFMA syrk, fp32 accumulate; one H per DISTINCT input:
+                      q/k/v and gate/up see the same activations, the reference recomputes X^T X for each)
+  * fasterquant    -> inc_gptq_hessian_finalize, inc_gptq_prepare_weight, inc_gptq_find_params,
+                      inc_gptq_quant_block (serial 128-column chain, one lane per weight row),
+                      inc_gptq_lazy_update (fp32 MFMA); the Cholesky trio is the hipSOLVER library call that
+                      torch.linalg dispatches to on ROCm (SURVEY.md section 8, row K6').
+  * export         -> the column loop already emits the integer codes; quant_weight_w_scale (reference
+                      utility.py:483) is not needed; packing is inc_woq_pack on device.
+Everything stays resident in HBM between the steps (no block.cpu() / .cpu() round trips as in :766-783).
+"""
+
+import math
+import time
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ....common.utils import logger
+from ...utils.utility import get_accelerator, get_model_device, set_module
+from ..base_algorithm import Quantizer as INCQuantizer
+from .modules import MI355XWeightOnlyLinear
+
+try:
+    import transformers
+
+    _Conv1D = transformers.Conv1D
+    SUPPORTED_LAYERS = (nn.Linear, transformers.Conv1D)
+except Exception:  # pragma: no cover
+    _Conv1D = None
+    SUPPORTED_LAYERS = (nn.Linear,)
+
+QBLOCK = 128  # columns per inc_gptq_quant_block launch
+
+
+# ---------------------------------------------------------------------------------------------------
+# model structure
+# ---------------------------------------------------------------------------------------------------
+def is_leaf(module):
+    return next(module.children(), None) is None
+
+
+def trace_gptq_target_blocks(module, module_types=(torch.nn.ModuleList, torch.nn.Sequential)):
+    """Locate the transformer stack (first ModuleList / Sequential), what precedes it and what follows it."""
+    blocks = {"embeddings": {}, "transformers_pre": {}, "transformers_name": "", "transformers": [], "transformers_post": {}}
+    found = False
+    for n, m in module.named_modules():
+        if type(m) in module_types:
+            if not found:
+                blocks["transformers_name"] = n
+                blocks["transformers"] = m
+                found = True
+        elif (is_leaf(m) and not found) or "Embedding" in type(m).__name__:
+            blocks["embeddings"][n] = m
+        elif found and n.find(blocks["transformers_name"]) == -1:
+            blocks["transformers_post"]["name"] = n
+            blocks["transformers_post"]["layer"] = m
+    return blocks
+
+
+def find_layers(module, layers=SUPPORTED_LAYERS, name=""):
+    """{relative name: module} of every quantisable layer below `module`."""
+    if isinstance(module, tuple(layers)):
+        return {name: module}
+    res = {}
+    for child_name, child in module.named_children():
+        res.update(find_layers(child, layers=layers, name=name + "." + child_name if name else child_name))
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-layer solver
+# ---------------------------------------------------------------------------------------------------
+class HessianAccumulator:
+    """H = (2/n) sum_batches X^T X in the reference's running-mean form (gptq.py:1136-1141), fp32 [K,K] in HBM.
+
+    One accumulator may be shared by several layers that see the same input tensor."""
+
+    def __init__(self, columns, device):
+        self.columns = columns
+        self.device = device
+        self.H = None  # allocated on the first batch: aliased layers never allocate theirs
+        self.nsamples = 0
+        self.finalized = None  # (Hinv, dead, perm) cache keyed by (percdamp, act_order)
+
+    def add_batch(self, inp):
+        if inp.dim() == 2:
+            inp = inp.unsqueeze(0)
+        b = inp.shape[0]
+        x2d = inp.reshape(-1, inp.shape[-1])
+        if x2d.stride(-1) != 1:
+            x2d = x2d.contiguous()
+        if self.H is None:
+            self.H = torch.zeros((self.columns, self.columns), dtype=torch.float32, device=x2d.device)
+        beta = self.nsamples / (self.nsamples + b)
+        self.nsamples += b
+        ops.gptq_hessian_accum(self.H, x2d, beta, 2.0 / self.nsamples)
+
+    def inverse_factor(self, percdamp, act_order):
+        """Upper Cholesky factor of (H + damp I)^-1 (gptq.py:1186-1231); consumes H.  Cached so that layers
+        sharing the accumulator factorise once."""
+        key = (float(percdamp), bool(act_order))
+        if self.finalized is not None and self.finalized[0] == key:
+            return self.finalized[1:]
+        assert self.finalized is None, "an accumulator can only be finalised with one (percdamp, act_order) setting"
+        H = self.H
+        if H is None:  # no calibration data reached this layer: H = 0 -> every column is "dead" (H = I after the fix)
+            H = torch.zeros((self.columns, self.columns), dtype=torch.float32, device=self.device)
+        dead = ops.gptq_hessian_finalize(H, percdamp)
+        perm = None
+        if act_order:
+            perm = torch.argsort(torch.diagonal(H), descending=True)
+            H = H[perm][:, perm].contiguous()
+        L = torch.linalg.cholesky(H)
+        Hi = torch.cholesky_inverse(L)
+        del L
+        Hinv = torch.linalg.cholesky(Hi, upper=True).contiguous()
+        del Hi
+        self.H = None
+        self.finalized = (key, Hinv, dead, perm)
+        return Hinv, dead, perm
+
+
+class GPTQ:
+    """One Linear under GPTQ (interface of the reference's class GPTQ, gptq.py:1089)."""
+
+    def __init__(self, layer, W=None, device="cuda", accumulator=None):
+        self.layer = layer
+        self.device = device
+        self.is_conv1d = _Conv1D is not None and isinstance(layer, _Conv1D)
+        w = layer.weight if W is None else W
+        shape = w.shape
+        self.rows, self.columns = (shape[1], shape[0]) if self.is_conv1d else (shape[0], shape[1])
+        self.acc = accumulator or HessianAccumulator(self.columns, device)
+        self.perm = None
+        self.cfg = {}
+
+    # the reference's Quantizer.configure (gptq.py:1375) copies the per-layer dict onto the quantizer
+    def configure(self, weight_config_this_layer):
+        self.cfg = dict(weight_config_this_layer)
+
+    @property
+    def H(self):
+        return self.acc.H
+
+    @property
+    def nsamples(self):
+        return self.acc.nsamples
+
+    def add_batch(self, inp, out=None):
+        self.acc.add_batch(inp)
+
+    def fasterquant(self, W, blocksize=128, percdamp=0.01, groupsize=-1, act_order=False, hybrid_order=False,
+                    fp8_aware=False, static_groups=False):
+        """Returns (scale [N,G] fp32, scale_bf16_to_fp8, zero [N,G] fp32, Q [weight shape, weight dtype]);
+        the integer codes (uint8 [N,K], original column order) are left in `self.codes`."""
+        if hybrid_order or fp8_aware:
+            raise NotImplementedError("hybrid_order / fp8_aware are Gaudi W4A8 options outside the MI355X scope")
+        if act_order and static_groups:
+            raise NotImplementedError("act_order together with static_groups is not implemented yet")
+        bits = int(self.cfg.get("bits", 4))
+        sym = bool(self.cfg.get("sym", False))
+        if self.cfg.get("mse", False):
+            raise NotImplementedError("use_mse_search for GPTQ is not implemented yet")
+        if self.cfg.get("dtype", "int") != "int" or self.cfg.get("use_double_quant", False):
+            raise NotImplementedError("GPTQ on MI355X quantises to plain integer formats")
+        weight_shape, weight_dtype = W.shape, W.dtype
+        if self.is_conv1d:
+            W = W.t()
+        W = W.contiguous()
+        N, K = W.shape
+        tick = time.time()
+
+        Hinv, dead, perm = self.acc.inverse_factor(percdamp, act_order)
+        gs = K if (groupsize == -1 or groupsize >= K) else int(groupsize)
+        G = math.ceil(K / gs)
+        scale = torch.empty((N, G), dtype=torch.float32, device=W.device)
+        zero = torch.empty((N, G), dtype=torch.float32, device=W.device)
+
+        if groupsize == -1:
+            # per-channel parameters come from W before dead columns are zeroed (gptq.py:1180-1189 order)
+            w32 = ops.gptq_prepare_weight(W, None)
+            ops.gptq_find_params(w32, 0, K, 1, bits, sym, scale, zero, 0)
+            del w32
+        w32 = ops.gptq_prepare_weight(W, dead)
+        if static_groups:
+            ops.gptq_find_params(w32, 0, gs, G, bits, sym, scale, zero, 0)
+        if act_order:
+            w32 = w32[:, perm].contiguous()
+            self.perm = perm.clone()
+
+        codes = torch.empty((N, K), dtype=torch.uint8, device=W.device)
+        Q = torch.empty((N, K), dtype=weight_dtype, device=W.device)
+        err = torch.empty((N, QBLOCK), dtype=torch.float32, device=W.device)
+        dynamic_groups = groupsize != -1 and not static_groups
+        kernel_gs = gs if groupsize != -1 else 0
+        blocksize = int(blocksize) if blocksize and blocksize > 0 else K
+        i1 = 0
+        while i1 < K:
+            ref_end = min((i1 // blocksize + 1) * blocksize, K)  # end of the reference's block (gptq.py:1250)
+            count = min(QBLOCK, ref_end - i1)
+            if dynamic_groups and i1 % blocksize == 0:
+                # groups that START inside this reference block read the global W as it is now (gptq.py:1266-1272)
+                g_first = -(-i1 // gs)
+                g_last = (ref_end - 1) // gs
+                if g_last >= g_first:
+                    ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first)
+            ops.gptq_quant_block(w32, Hinv, scale, zero, codes, Q, err, i1, count, kernel_gs, bits)
+            ops.gptq_lazy_update(w32, Hinv, err, i1, count)
+            i1 += count
+        logger.debug("fasterquant %dx%d issued in %.3fs", N, K, time.time() - tick)
+
+        if act_order:
+            invperm = torch.argsort(perm)
+            Q = Q[:, invperm].contiguous()
+            codes = codes[:, invperm].contiguous()
+        self.codes = codes
+        if self.is_conv1d:
+            Q = Q.t().contiguous()
+        Q = Q.reshape(weight_shape)
+        return scale, torch.tensor([-1]), zero, Q
+
+    def free(self):
+        self.acc = None
+        self.codes = None
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole-model driver
+# ---------------------------------------------------------------------------------------------------
+def _to_device(obj, device):
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_device(o, device) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _to_device(v, device) for k, v in obj.items()}
+    return obj
+
+
+class RAWGPTQuantizer(object):
+    """Block-by-block GPTQ driver (reference gptq.py:184)."""
+
+    def __init__(self, model, weight_config={}, nsamples=128, use_max_length=True, max_seq_length=2048, device=None,
+                 use_layer_wise=False, model_path="", quant_lm_head=False, dataloader=None, use_block_wise=False,
+                 *args, **kwargs):
+        self.model = model
+        self.gptq_related_blocks = trace_gptq_target_blocks(self.model)
+        self.dtype = next(iter(self.model.parameters())).dtype
+        self.weight_config = weight_config
+        self.quant_lm_head = quant_lm_head
+        if quant_lm_head:
+            raise NotImplementedError("quant_lm_head=True for GPTQ is not implemented yet on MI355X")
+        self.check_layer_config()
+        self.device = torch.device(get_accelerator(device or "auto").current_device_name())
+        self.is_ready = False
+        # layer-wise / block-wise modes stream weights from disk to save host RAM: irrelevant with 288 GB HBM
+        self.use_layer_wise = False
+        self.use_block_wise = False
+        self.use_max_length = use_max_length
+        self.max_seq_length = max_seq_length
+        self.nsamples = nsamples
+        self.share_hessians = kwargs.get("share_hessians", True)
+        self.block_callback = kwargs.get("block_callback", None)  # used by the multi-GPU driver
+
+    # -- config handling (reference :330-398) --------------------------------------------------------
+    _DEFAULTS = dict(
+        dtype="int", bits=4, group_size=128, block_size=128, percdamp=0.01, sym=False, act_order=False,
+        hybrid_order=False, fp8_aware=False, static_groups=False, true_sequential=False, perchannel=True, mse=False,
+        use_double_quant=False, double_quant_dtype="int", double_quant_bits=4, double_quant_group_size=128,
+        double_quant_sym=False,
+    )
+
+    def check_layer_config(self):
+        for layer_name, config in self.weight_config.items():
+            for key, default in self._DEFAULTS.items():
+                config[key] = config.get(key, default)
+            if config["dtype"] != "int" and "int" in config["dtype"]:
+                config["bits"] = int(config["dtype"].lstrip("int"))
+                config["dtype"] = "int"
+
+    def get_layer_config(self, layer_name):
+        import re
+
+        config = self.weight_config.get(layer_name, None)
+        if config is not None:
+            return config
+        for pattern, cfg in self.weight_config.items():
+            if re.compile(pattern).findall(layer_name):
+                return cfg
+        return None
+
+    def get_full_layer_name(self, sub_layer_name, block_idx):
+        return ".".join([self.gptq_related_blocks["transformers_name"], str(block_idx), sub_layer_name])
+
+    @staticmethod
+    def track_hidden_states(data):
+        if isinstance(data, torch.Tensor):
+            return data
+        if isinstance(data, (tuple, list)):
+            return data[0]
+        return data
+
+    # -- calibration capture (reference :399-482) ------------------------------------------------------
+    @torch.no_grad()
+    def prepare_for_calibration(self):
+        self.cache_key_arguments = {"batch_num": 0}
+        self.cache_positional_arguments = []
+        self.is_ready = True
+        quantizer = self
+
+        def forward(layer, *args, **kwargs):
+            quantizer.cache_key_arguments["batch_num"] += 1
+            for arg, val in kwargs.items():
+                if isinstance(val, torch.Tensor) or arg in ["alibi", "position_embeddings"]:
+                    quantizer.cache_key_arguments.setdefault(arg, []).append(val)
+            for idx, item in enumerate(args):
+                if idx + 1 > len(quantizer.cache_positional_arguments):
+                    quantizer.cache_positional_arguments.append([])
+                quantizer.cache_positional_arguments[idx].append(item)
+            raise ValueError  # the reference's control flow: abort the model forward after block 0's inputs are seen
+
+        # the whole model lives in HBM on MI355X (no per-block host<->device shuttling)
+        self.model.to(self.device)
+        first_block = self.gptq_related_blocks["transformers"][0]
+        self.forward_cache = first_block.forward
+        first_block.forward = partial(forward, first_block)
+        self.orig_model_forward_cache = self.model.forward
+        model_forward_cache = self.model.forward
+        device = self.device
+
+        def model_forward(model, *args, **kwargs):
+            try:
+                model_forward_cache(*_to_device(args, device), **_to_device(kwargs, device))
+            except ValueError:
+                pass
+
+        self.model.forward = partial(model_forward, self.model)
+
+    @torch.no_grad()
+    def remove_prepare_for_calibration(self):
+        self.model.forward = self.orig_model_forward_cache
+        self.gptq_related_blocks["transformers"][0].forward = self.forward_cache
+        logger.info("GPTQ quantization prepared.")
+
+    def gather_single_batch_from_dict(self, data_dict, idx):
+        return {k: v[idx] for k, v in data_dict.items()}
+
+    def gather_single_batch_from_list(self, data_list, idx):
+        return [item[idx] for item in data_list]
+
+    def find_true_sequential_config(self):
+        for cfg in self.weight_config.values():
+            if cfg.get("true_sequential", None) is not None:
+                return cfg["true_sequential"]
+        return False
+
+    @staticmethod
+    def analyze_true_sequential(module):
+        layers = list(find_layers(module))
+        if "q" in layers[0].lower() and "k" in layers[0].lower():
+            qkv, post = [layers[0]], layers[1:]
+        else:
+            qkv, post = layers[0:3], layers[3:]
+        return [qkv] + [[layer] for layer in post]
+
+    # -- block forward over every calibration batch ----------------------------------------------------
+    def _run_block(self, block, on_output=None):
+        batch_num = self.cache_key_arguments.pop("batch_num")
+        for j in range(batch_num):
+            kw = self.gather_single_batch_from_dict(self.cache_key_arguments, j)
+            pos = self.gather_single_batch_from_list(self.cache_positional_arguments, j)
+            out = self.track_hidden_states(block(*pos, **kw))
+            if on_output is not None:
+                on_output(j, out)
+        self.cache_key_arguments["batch_num"] = batch_num
+
+    # -- the main loop (reference :568-887) ----------------------------------------------------------------
+    @torch.no_grad()
+    def execute_quantization(self, means=None, stds=None):
+        true_sequential = self.find_true_sequential_config()
+        blocks = self.gptq_related_blocks["transformers"]
+        seq_map = self.analyze_true_sequential(blocks[0])
+        for p in self.model.parameters():
+            p.requires_grad = False
+        for block_idx in range(len(blocks)):
+            t0 = time.time()
+            block = blocks[block_idx].to(self.device)
+            self.quantize_block(block, block_idx, seq_map if true_sequential else None)
+            if self.block_callback is not None:
+                self.block_callback(block_idx, block)
+            logger.info("Quantized block %d / %d in %.2fs", block_idx + 1, len(blocks), time.time() - t0)
+        logger.info("Quantization done")
+        return self.model
+
+    @torch.no_grad()
+    def quantize_block(self, block, block_idx, seq_map=None):
+        sub_layers = find_layers(block)
+        sequentials = seq_map if seq_map else [list(sub_layers.keys())]
+        for sequential in sequentials:
+            layers = {}
+            for name in sequential:
+                full = self.get_full_layer_name(name, block_idx)
+                if self.get_layer_config(full) is None:
+                    logger.warning("%s can be quantized but excluded from quantization configs.", full)
+                else:
+                    layers[name] = sub_layers[name]
+            # Step 2.2: one GPTQ object per layer (reference :650-668)
+            solvers = {}
+            for name, layer in layers.items():
+                solvers[name] = GPTQ(layer, device=self.device)
+                solvers[name].configure(self.get_layer_config(self.get_full_layer_name(name, block_idx)))
+            # Step 2.3: hooks feeding the Hessians (reference :670-688).  Layers that receive the very same input
+            # tensor in a forward (q/k/v, gate/up) share one accumulator instead of recomputing X^T X.
+            live, alias = {}, {}
+            share = self.share_hessians
+
+            def make_hook(name):
+                def hook(_, inp, out):
+                    x = inp[0].data
+                    key = (x.data_ptr(), tuple(x.shape), x.dtype, x._version)
+                    if share and key in live:
+                        owner = live[key][0]
+                        if alias.setdefault(name, owner) != owner:
+                            raise RuntimeError(f"{name}: input sharing changed between calibration batches")
+                        return
+                    if alias.get(name) is not None:
+                        raise RuntimeError(f"{name}: input sharing changed between calibration batches")
+                    live[key] = (name, x)  # keeps x alive so its address cannot be recycled inside this forward
+                    solvers[name].add_batch(x)
+
+                return hook
+
+            handles = [layers[n].register_forward_hook(make_hook(n)) for n in layers]
+            self._run_block(block, on_output=lambda j, out: live.clear())
+            for h in handles:
+                h.remove()
+            for name, owner in alias.items():
+                if (
+                    solvers[name].columns == solvers[owner].columns
+                    and solvers[name].cfg["percdamp"] == solvers[owner].cfg["percdamp"]
+                    and solvers[name].cfg["act_order"] == solvers[owner].cfg["act_order"]
+                ):
+                    solvers[name].acc = solvers[owner].acc
+                else:  # pragma: no cover - different damping per layer: cannot share the factorisation
+                    raise RuntimeError(f"{name} shares its input with {owner} but not its GPTQ settings; pass share_hessians=False")
+            # Step 2.4: solve (reference :690-747)
+            results = {}
+            for name, layer in layers.items():
+                cfg = solvers[name].cfg
+                scale, _, zp, Q = solvers[name].fasterquant(
+                    layer.weight.data, blocksize=cfg["block_size"], percdamp=cfg["percdamp"], groupsize=cfg["group_size"],
+                    act_order=cfg["act_order"], hybrid_order=cfg["hybrid_order"], fp8_aware=cfg["fp8_aware"],
+                    static_groups=cfg["static_groups"],
+                )
+                layer.weight.data = Q
+                results[name] = dict(scale=scale, zero=None if cfg["sym"] else zp, perm=solvers[name].perm, codes=solvers[name].codes)
+                solvers[name].free()
+            del solvers
+            # Step 2.5: outputs of the quantised block become the next block's inputs (reference :749-762)
+            def replace(j, out):
+                if "hidden_states" in self.cache_key_arguments:
+                    self.cache_key_arguments["hidden_states"][j] = out
+                else:
+                    self.cache_positional_arguments[0][j] = out
+
+            self._run_block(block, on_output=replace)
+            # Step 2.6: export to the packed module (reference :769-849) -- on device, from the emitted codes
+            for name, layer in layers.items():
+                cfg = self.get_layer_config(self.get_full_layer_name(name, block_idx))
+                r = results[name]
+                if isinstance(layer, nn.Linear):
+                    in_features, out_features = layer.in_features, layer.out_features
+                else:
+                    in_features, out_features = layer.weight.shape[0], layer.weight.shape[1]
+                new_module = MI355XWeightOnlyLinear(
+                    in_features, out_features, dtype=cfg["dtype"], bits=cfg["bits"], group_size=cfg["group_size"],
+                    zp=r["zero"] is not None, bias=layer.bias is not None, g_idx=r["perm"] is not None, device=self.device,
+                )
+                new_module.pack_codes(r["codes"], r["scale"], r["zero"], layer.bias, g_idx=r["perm"])
+                set_module(block, name, new_module)
+            del results
+
+
+class GPTQuantizer(INCQuantizer):
+    """Algorithm plug-in (reference gptq.py:1651)."""
+
+    def __init__(self, quant_config={}):
+        super().__init__(quant_config)
+
+    @torch.no_grad()
+    def prepare(self, model, nsamples=128, max_seq_length=2048, use_max_length=True, device=None, use_layer_wise=False,
+                model_path=None, quant_lm_head=False, use_block_wise=False, *args, **kwargs):
+        assert isinstance(model, torch.nn.Module), "only support torch module"
+        self.model_device = get_model_device(model)
+        self.gptq_quantizer = RAWGPTQuantizer(
+            model, weight_config=self.quant_config, nsamples=nsamples, use_max_length=use_max_length,
+            max_seq_length=max_seq_length, device=device, use_layer_wise=use_layer_wise, model_path=model_path,
+            quant_lm_head=quant_lm_head, use_block_wise=use_block_wise,
+            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback")},
+        )
+        self.gptq_quantizer.prepare_for_calibration()
+        return self.gptq_quantizer.model
+
+    @torch.no_grad()
+    def convert(self, model, *args, **kwargs):
+        self.gptq_quantizer.model = model
+        self.gptq_quantizer.remove_prepare_for_calibration()
+        q_model = self.gptq_quantizer.execute_quantization()
+        logger.info("GPTQ quantizing done.")
+        return q_model

@@ -1,0 +1,315 @@
+"""The weight-only Linear operator for MI355X.
+
+Drop-in for the reference's operator classes (neural_compressor/torch/algorithms/weight_only/modules.py):
+  WeightOnlyLinear (abstract)        :91-154
+  INCWeightOnlyLinear                :157-627   -> MI355XWeightOnlyLinear (alias INCWeightOnlyLinear)
+  UnpackedWeightOnlyLinearParams     :74-88
+  MulLinear                          :907-949
+
+Same constructor, same buffers (`qweight`, `scales`, `qzeros`, `bias`, `g_idx`, `scale_bf16_to_fp8`) with the
+same shapes / dtypes, so state_dicts round-trip with the reference and with HF / AutoGPTQ checkpoints.  What
+changes is where the arithmetic runs: pack / unpack / recover are HIP kernels over HBM-resident tensors
+(no per-nibble device syncs, no Python loop over K), and forward is a fused INT4->bf16 dequant-GEMM on the
+matrix cores instead of "recover once, cache the dense weight, F.linear".  There is no CPU path: tensors
+must live on a HIP device.
+"""
+
+import math
+from abc import abstractmethod
+
+import torch
+
+from .... import ops
+from ....common.utils import logger
+
+
+class UnpackedWeightOnlyLinearParams(dict):
+    """Unpacked tensors of a packed module: int_weight, scales, scale_bf16_to_fp8, zp, g_idx, bias."""
+
+    def __init__(self, unpack_weight, scales, scale_bf16_to_fp8, unpack_zp, **kwargs):
+        super().__init__(int_weight=unpack_weight, scales=scales, scale_bf16_to_fp8=scale_bf16_to_fp8, zp=unpack_zp, **kwargs)
+
+    def to(self, device):
+        for key, value in self.items():
+            if isinstance(value, torch.Tensor):
+                self[key] = value.to(device)
+        return self
+
+
+class WeightOnlyLinear(torch.nn.Module):
+    """Abstract operator: a device class implements pack / unpack / forward (reference modules.py:91)."""
+
+    def __init__(self, in_features, out_features, dtype, bits, group_size, device, scale_dtype, **kwargs):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.dtype = dtype
+        self.bits = bits
+        self.group_size = group_size if group_size != -1 else in_features
+        self.device = device
+        self.scale_dtype = scale_dtype
+        self.kwargs = kwargs
+
+    @abstractmethod
+    def pack(self, *args, **kwargs):
+        raise NotImplementedError(f"{self.__class__.__name__} doesn't implement `pack` function. ")
+
+    @abstractmethod
+    def unpack(self, *args, **kwargs):
+        raise NotImplementedError(f"{self.__class__.__name__} doesn't implement `unpack` function. ")
+
+    @abstractmethod
+    def forward(self, input):
+        raise NotImplementedError(f"{self.__class__.__name__} doesn't implement `forward` function. ")
+
+    def extra_repr(self):
+        return "in_features={}, out_features={}, bits={}, group_size={}, bias={}".format(
+            self.in_features, self.out_features, self.bits, self.group_size, self.bias is not None
+        )
+
+
+_CBITS = {torch.int8: 8, torch.int16: 16, torch.int32: 32, torch.int64: 64}
+
+
+def _hip_device(device):
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(
+            f"MI355XWeightOnlyLinear needs a HIP device ('cuda[:N]'), got '{device}'. There is no CPU implementation; "
+            "construct the module with device='cuda'."
+        )
+    return dev
+
+
+class MI355XWeightOnlyLinear(WeightOnlyLinear):
+    """Packed-weight Linear whose pack / unpack / recover / forward are HIP kernels (gfx950)."""
+
+    def __init__(
+        self,
+        in_features,
+        out_features,
+        dtype="int",
+        bits=4,
+        group_size=32,
+        zp=False,
+        bias=False,
+        scale_dtype=torch.float32,
+        compression_dtype=torch.int32,
+        compression_dim=1,
+        g_idx=False,
+        device="cuda",
+        use_optimum_format=True,
+        **kwargs,
+    ):
+        super().__init__(in_features, out_features, dtype, bits, group_size, device, scale_dtype=scale_dtype, **kwargs)
+        if "int" not in self.dtype:
+            raise NotImplementedError(f"dtype={dtype}: only integer weight-only formats are in scope (SURVEY.md section 8)")
+        assert bits in (2, 4, 8), f"bits={bits}: the HIP packers implement 2, 4 and 8 bits"
+        dev = _hip_device(device)
+        self.use_optimum_format = use_optimum_format
+        self.compression_dim = compression_dim
+        assert compression_dtype in _CBITS, f"Only support torch.int8|16|32|64 as compressed dtype. but got {compression_dtype}"
+        assert compression_dim in (0, 1), "Only support 0 or 1 as compression dimension, 0 is output channel, 1 is input channel."
+        K, N, gs = in_features, out_features, self.group_size
+        G = math.ceil(K / gs)
+        self.register_buffer("scale_bf16_to_fp8", torch.zeros(1, dtype=torch.bfloat16, device=dev))
+        if self.use_optimum_format:
+            self.float_type = torch.float16
+            self.compression_dtype = torch.int32
+            self.compress_bits = 32
+            self.n_pack = 32 // bits
+            self.register_buffer("scales", torch.zeros((G, N), dtype=self.float_type, device=dev))
+            self.register_buffer("qweight", torch.zeros((math.ceil(K / self.n_pack), N), dtype=torch.int32, device=dev))
+            self.register_buffer("qzeros", torch.zeros((G, math.ceil(N / self.n_pack)), dtype=torch.int32, device=dev))
+            self.register_buffer("bias", torch.zeros(N, dtype=self.float_type, device=dev))
+        else:
+            self.compression_dtype = compression_dtype
+            self.compress_bits = _CBITS[compression_dtype]
+            self.n_pack = self.compress_bits // bits
+            self.float_type = scale_dtype
+            self.register_buffer("scales", torch.zeros((N, G), dtype=self.float_type, device=dev))
+            if compression_dim == 1:
+                self.register_buffer("qweight", torch.zeros((N, math.ceil(K / self.n_pack)), dtype=compression_dtype, device=dev))
+                if zp:
+                    self.register_buffer("qzeros", torch.zeros((N, math.ceil(G / self.n_pack)), dtype=compression_dtype, device=dev))
+            else:
+                self.register_buffer("qweight", torch.zeros((math.ceil(N / self.n_pack), K), dtype=compression_dtype, device=dev))
+                if zp:
+                    self.register_buffer("qzeros", torch.zeros((math.ceil(N / self.n_pack), G), dtype=compression_dtype, device=dev))
+            if bias:
+                self.register_buffer("bias", torch.zeros(N, dtype=self.float_type, device=dev))
+            else:
+                self.bias = None
+        if g_idx:
+            self.register_buffer("g_idx", torch.zeros(K, dtype=torch.int32, device=dev))
+        else:
+            self.g_idx = None
+
+    # ------------------------------------------------------------------------------------------------
+    def pack(self, int_weight, scales, zp, bias, scale_bf16_to_fp8=None, g_idx=None, **kwargs):
+        """Pack integer weights (reference modules.py:321-375); arguments are NOT mutated (the reference
+        adds the sym shift / subtracts 1 from zp in place)."""
+        dev = self.qweight.device
+        N, K = self.out_features, self.in_features
+        if bias is not None:
+            assert hasattr(self, "bias"), "bias is not set when initializing."
+            self.bias = bias.detach().to(dev).type(self.float_type)
+        if g_idx is not None:
+            assert hasattr(self, "g_idx"), "g_idx is not set when initializing."
+            g = g_idx.to(dev).type(torch.int32)
+            if self.use_optimum_format:
+                g = (torch.argsort(g) // self.group_size).type(torch.int32)  # modules.py:341-344 (index plumbing)
+            self.g_idx = g.contiguous()
+        if scale_bf16_to_fp8 is not None:
+            self.scale_bf16_to_fp8 = scale_bf16_to_fp8.to(dev).type(self.float_type)
+        int_weight = int_weight.to(dev)
+        scales = scales.to(dev)
+        zp = None if zp is None else zp.to(dev)
+        if self.use_optimum_format:
+            assert tuple(scales.shape) == (N, self.scales.shape[0]), f"{scales.shape} Scale shape is mismatched."
+            shift = 2 ** (self.bits - 1) if zp is None else 0
+            ops.woq_pack(
+                int_weight, scales, zp, self.bits, shift, qweight=self.qweight, qzeros=self.qzeros, scales_out=self.scales
+            )
+            return
+        # non-optimum layouts (modules.py:270-314): generic row packer + layout transposes
+        assert scales.shape == self.scales.shape, f"{scales.shape} != {self.scales.shape} Scale shape is mismatched."
+        self.scales = scales.type(self.float_type).contiguous()
+        iw = int_weight.to(torch.int32)
+        if self.compression_dim == 0:
+            iw = iw.T.contiguous()
+        packed = ops.pack_rows(iw, self.bits, self.compress_bits)
+        if self.compression_dim == 0:
+            packed = packed.T.contiguous()
+        assert packed.shape == self.qweight.shape, "output channels mismatch, please check."
+        self.qweight.copy_(packed)
+        if zp is not None:
+            assert hasattr(self, "qzeros"), "zp is not set when initializing."
+            z = zp.to(torch.int32)
+            if self.compression_dim == 0:
+                z = z.T.contiguous()
+            pz = ops.pack_rows(z, self.bits, self.compress_bits)
+            if self.compression_dim == 0:
+                pz = pz.T.contiguous()
+            self.qzeros.copy_(pz)
+
+    def pack_codes(self, codes, scales, zp, bias, g_idx=None):
+        """MI355X-native fast path (optimum format only): pack already-offset codes 0..2^bits-1 (uint8 [N,K], what
+        the GPTQ column-loop kernel emits) instead of int32 signed ints.  Produces bit-identical buffers to
+        `pack(codes - 2^(bits-1), scales, None, ...)` for sym and `pack(codes, scales, zp, ...)` for asym."""
+        assert self.use_optimum_format, "pack_codes writes the optimum layout"
+        dev = self.qweight.device
+        if bias is not None:
+            self.bias = bias.detach().to(dev).type(self.float_type)
+        if g_idx is not None:
+            assert hasattr(self, "g_idx"), "g_idx is not set when initializing."
+            g = g_idx.to(dev).type(torch.int32)
+            self.g_idx = (torch.argsort(g) // self.group_size).type(torch.int32).contiguous()
+        ops.woq_pack(codes, scales, zp, self.bits, 0, qweight=self.qweight, qzeros=self.qzeros, scales_out=self.scales)
+
+    def unpack(self):
+        """Reference modules.py:377-411 -> UnpackedWeightOnlyLinearParams (int16 ints, as the reference)."""
+        N, K = self.out_features, self.in_features
+        if self.use_optimum_format:
+            G = self.scales.shape[0]
+            iw, zp = ops.woq_unpack(self.qweight, self.qzeros, N, K, G, self.bits)
+            scales = self.scales.T.contiguous()
+        else:
+            has_zp = hasattr(self, "qzeros")
+            qw = self.qweight if self.compression_dim == 1 else self.qweight.T.contiguous()
+            iw = ops.unpack_rows(qw.contiguous(), self.bits, self.compress_bits, has_zp)
+            if self.compression_dim == 0:
+                iw = iw.T.contiguous()
+            iw = iw[:N, :K].contiguous()
+            zp = None
+            if has_zp:
+                qz = self.qzeros if self.compression_dim == 1 else self.qzeros.T.contiguous()
+                zp = ops.unpack_rows(qz.contiguous(), self.bits, self.compress_bits, True)
+                if self.compression_dim == 0:
+                    zp = zp.T.contiguous()
+                zp = zp[: self.scales.shape[0], : self.scales.shape[1]].contiguous()
+            scales = self.scales
+        return UnpackedWeightOnlyLinearParams(iw, scales, self.scale_bf16_to_fp8, zp, g_idx=self.g_idx, bias=self.bias)
+
+    def recover(self, dtype=None):
+        """Dense weight [N,K] (reference modules.py:413-443).  Default dtype = float_type (fp16 in optimum format)."""
+        out_dtype = dtype or self.float_type
+        if self.use_optimum_format:
+            return ops.woq_dequant(
+                self.qweight, self.scales, self.qzeros, self.g_idx, self.out_features, self.in_features,
+                self.group_size, self.bits, out_dtype=out_dtype,
+            )
+        p = self.unpack()
+        return ops.dequant_ints(p["int_weight"], p["scales"], p["zp"], self.g_idx, self.group_size, out_dtype)
+
+    def forward(self, input):
+        """y = x W^T + b with W dequantised on the fly (reference modules.py:594-610).
+
+        bf16 / fp16 inputs are computed in their own dtype (fp32 accumulate); any other dtype is cast to fp16,
+        which is what the reference does on an accelerator (`input.type(self.weight.dtype)` with an fp16 weight).
+        """
+        x = input
+        if x.dtype not in (torch.bfloat16, torch.float16):
+            x = x.to(torch.float16)
+        lead = x.shape[:-1]
+        x2d = x.reshape(-1, self.in_features)
+        if not x2d.is_contiguous():
+            x2d = x2d.contiguous()
+        trivial_g_idx = self.g_idx is None or getattr(self, "_g_idx_trivial", None)
+        if trivial_g_idx is None:
+            ref = torch.arange(self.in_features, device=self.g_idx.device, dtype=torch.int32) // self.group_size
+            trivial_g_idx = bool(torch.equal(self.g_idx.to(torch.int32), ref))
+            self._g_idx_trivial = trivial_g_idx
+        if self.use_optimum_format and self.bits in (4, 8) and trivial_g_idx and self.group_size % self.n_pack == 0:
+            y = ops.woq_gemm(
+                x2d, self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features,
+                self.group_size, self.bits,
+            )
+        else:
+            # act_order (per-element g_idx), 2-bit or non-optimum layouts: HIP dequant + dense library GEMM
+            w = self.recover(dtype=x2d.dtype)
+            b = None if self.bias is None else self.bias.to(x2d.dtype)
+            y = torch.nn.functional.linear(x2d, w, b)
+        return y.reshape(*lead, self.out_features)
+
+    def extra_repr(self):
+        s = super().extra_repr()
+        if self.use_optimum_format:
+            s += ", use_optimum_format=True"
+        return s
+
+
+# the reference's class name for the non-Gaudi device class; code that imports it keeps working
+INCWeightOnlyLinear = MI355XWeightOnlyLinear
+
+
+class MulLinear(torch.nn.Module):
+    """Linear with a per-input-channel multiplier in front (AWQ scale that cannot be folded upstream,
+    reference modules.py:907-949)."""
+
+    def __init__(self, module, input_scale=None):
+        super().__init__()
+        if input_scale is None:
+            input_scale = torch.empty(module.in_features)
+        self.register_buffer("input_scale", input_scale)
+        self.add_module("linear", module)
+
+    @property
+    def weight(self):
+        return self.linear.weight
+
+    @weight.setter
+    def weight(self, weight):
+        self.linear.weight = weight
+
+    def forward(self, X):
+        return self.linear(torch.mul(X, self.input_scale))
+
+    def _update_linear(self):
+        """Fold the multiplier into the weight and return the plain Linear."""
+        self.linear.weight.mul_(self.input_scale.view(1, -1).to(self.linear.weight.dtype))
+        return self.linear
+
+    def _recover_linear(self):
+        self.linear.weight.div_(self.input_scale.view(1, -1).to(self.linear.weight.dtype))
+        return self.linear

@@ -1,0 +1,102 @@
+"""RTN: per-Linear group-wise round-to-nearest + pack, all on the MI355X.
+
+Reference: neural_compressor/torch/algorithms/weight_only/rtn.py:68-270 (RTNQuantizer.convert).
+Per nn.Linear / transformers.Conv1D found in `quant_config`: optional clip search (utility.search_clip),
+`quant_tensor(return_int=True)` -> `MI355XWeightOnlyLinear(...).pack(int_weight, scale, zp, bias)` ->
+`set_module`.  Weights are moved to HBM layer by layer; every arithmetic step is a HIP kernel.
+"""
+
+import torch
+
+from ....common.utils import logger
+from ...utils.utility import WOQ_WHITE_LIST, get_accelerator, get_model_device, set_module
+from ..base_algorithm import Quantizer
+from .modules import MI355XWeightOnlyLinear
+from .utility import quant_tensor, search_clip
+
+try:
+    import transformers
+
+    _Conv1D = transformers.Conv1D
+except Exception:  # pragma: no cover
+    _Conv1D = ()
+
+
+class RTNQuantizer(Quantizer):
+    """`quant_config`: {op_name: {dtype, bits, scheme, group_size, group_dim, use_full_range, use_mse_search, ...}}."""
+
+    def __init__(self, quant_config=None):
+        super().__init__(quant_config)
+
+    @torch.no_grad()
+    def prepare(self, model, *args, **kwargs):
+        return model  # RTN needs no calibration (reference rtn.py:58-66)
+
+    @torch.no_grad()
+    def convert(self, model, dtype="int", bits=4, scheme="sym", group_size=32, group_dim=1, quantile=1.0,
+                use_full_range=False, use_mse_search=False, use_layer_wise=False, model_path="",
+                quant_lm_head=False, *args, **kwargs):
+        weight_config = self.quant_config
+        device = torch.device(get_accelerator(kwargs.pop("device", "auto")).current_device_name())
+        model_device = get_model_device(model)
+        use_optimum_format = kwargs.get("use_optimum_format", True)
+        if use_layer_wise:
+            # the reference's layer-wise mode saves HOST memory by streaming a checkpoint; with 288 GB of HBM the
+            # whole model is resident, so the flag is accepted and ignored.
+            logger.debug("use_layer_wise is ignored on MI355X")
+        assert isinstance(model, torch.nn.Module), "only support torch module"
+        for name, m in list(model.named_modules()):
+            if not isinstance(m, WOQ_WHITE_LIST) or name not in weight_config:
+                continue
+            cfg = weight_config[name]
+            dtype = cfg.get("dtype", "int")
+            if dtype == "fp32":
+                continue
+            bits = cfg.get("bits", 4)
+            if dtype != "int" and "int" in dtype:
+                bits = int(dtype.lstrip("int"))
+                dtype = "int"
+            if dtype != "int":
+                raise NotImplementedError(f"RTN dtype={dtype} is outside the MI355X hot-path scope (integer formats only)")
+            if cfg.get("use_double_quant", False):
+                raise NotImplementedError("double_quant is outside the MI355X hot-path scope")
+            group_size = cfg["group_size"]
+            scheme = cfg["scheme"]
+            quantile = cfg.get("quantile", 1.0)
+            group_dim = cfg["group_dim"]
+            use_full_range = cfg["use_full_range"]
+            use_mse_search = cfg["use_mse_search"]
+            logger.debug("RTN %s: bits=%s group_size=%s scheme=%s quantile=%s", name, bits, group_size, scheme, quantile)
+
+            m.to(device)
+            is_conv1d = isinstance(m, _Conv1D) if _Conv1D else False
+            transpose = (group_dim == 0) ^ is_conv1d  # reference rtn.py:208-214
+            weight = m.weight.detach()
+            weight = weight.T.contiguous() if transpose else weight.contiguous()
+            if use_mse_search:
+                quantile = search_clip(m, bits, group_size, scheme, dtype, use_full_range)
+            int_weight, scale, zp = quant_tensor(
+                weight, dtype=dtype, bits=bits, group_size=group_size, scheme=scheme, quantile=quantile,
+                return_int=True, full_range=use_full_range,
+            )
+            if transpose:
+                int_weight = int_weight.t().contiguous()
+                scale = scale.t().contiguous()
+                zp = zp.t().contiguous() if zp is not None else None
+            if is_conv1d:
+                in_features, out_features = m.weight.shape[0], m.weight.shape[1]
+                int_weight = int_weight.t().contiguous()
+                scale = scale.t().contiguous()
+                zp = zp.t().contiguous() if zp is not None else None
+            else:
+                in_features, out_features = m.in_features, m.out_features
+            new_module = MI355XWeightOnlyLinear(
+                in_features, out_features, dtype=dtype, bits=bits, group_size=group_size, zp=zp is not None,
+                bias=m.bias is not None, use_optimum_format=use_optimum_format, device=device,
+            )
+            new_module.pack(int_weight, scale, zp, m.bias)
+            if name == "":
+                return new_module
+            set_module(model, name, new_module)
+            m.to(model_device)  # the float module is dropped; keep the caller's placement semantics
+        return model

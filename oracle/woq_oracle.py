@@ -1,0 +1,417 @@
+"""CPU oracle for the weight-only-quant hot path -- TEST INFRASTRUCTURE ONLY.
+
+A restatement of the reference's algorithm (intel/neural-compressor v3.9, paths relative to
+/root/reference/neural_compressor/torch/algorithms/weight_only/) in numpy (integer / byte work) and CPU torch
+ops (floating point: the reference's own arithmetic library, incl. LAPACK potrf/potri through torch.linalg).
+Nothing under neural_compressor_amd/ imports this module; only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg do, as the checker / reported baseline -- never as the product path.
+
+Pinning: every function here is checked against outputs of the unmodified reference (imported from
+/root/reference in the build container) by tests/golden/make_golden.py -> tests/golden/*.npz, and the
+fixtures are re-checked by tests/test_oracle_golden.py (runs without the reference and without a GPU).
+"""
+
+import math
+
+import numpy as np
+import torch
+
+# =====================================================================================================
+# bit packing (integer, bit-exact)
+# =====================================================================================================
+_NP_INT = {8: np.int8, 16: np.int16, 32: np.int32, 64: np.int64}
+
+
+def pack_rows(raw, bits, cbits=32):
+    """modules.py:528-544 (pack_tensor_with_numpy_impl) == numba packers bit_packer.py:35-278.
+
+    raw [R,C] ints -> [R, ceil(C/n_pack)] words of `cbits` bits; element e of word j sits at bits [e*bits, (e+1)*bits).
+    """
+    raw = np.asarray(raw)
+    n_pack = cbits // bits
+    dt = _NP_INT[cbits]
+    R, C = raw.shape
+    out = np.zeros((R, math.ceil(C / n_pack)), dtype=dt)
+    mask = np.uint8(2**bits - 1)
+    for j in range(out.shape[1]):
+        tmp = raw[:, n_pack * j : n_pack * (j + 1)].astype(dt)
+        tmp &= mask
+        for e in range(tmp.shape[1]):
+            tmp[:, e] = np.left_shift(tmp[:, e], bits * e)
+            out[:, j] |= tmp[:, e]
+    return out
+
+
+def unpack_rows(packed, bits, cbits=32, mask_sign=True):
+    """modules.py:558-578 (unpack_tensor_with_numpy): arithmetic shifts on the signed container, `& mask` iff the
+    module has qzeros; int16 out."""
+    packed = np.asarray(packed)
+    n_pack = cbits // bits
+    out = np.zeros((packed.shape[0], packed.shape[1] * n_pack), dtype=np.int16)
+    mask = np.uint8(2**bits - 1)
+    for j in range(packed.shape[1]):
+        for e in range(n_pack):
+            tmp = packed[:, j]
+            tmp = np.left_shift(tmp, cbits - bits * (e + 1))
+            tmp = np.right_shift(tmp, cbits - bits)
+            if mask_sign:
+                tmp = tmp & mask
+            out[:, j * n_pack + e] = tmp.astype(np.int16)
+    return out
+
+
+def woq_pack_optimum(int_weight, scales, zp, bits):
+    """INCWeightOnlyLinear.pack, optimum format (modules.py:321-375).
+
+    int_weight [N,K] ints (sym: signed, zp None; asym: 0..2^b-1 with zp [N,G]); scales [N,G] float.
+    -> qweight [ceil(K/np), N] int32, qzeros [G, ceil(N/np)] int32, scales fp16 [G, N].
+    """
+    iw = np.asarray(int_weight).astype(np.int32).copy()
+    scales = np.asarray(scales, dtype=np.float32)
+    if zp is None:  # :329-334
+        shift = 2 ** (bits - 1)
+        iw = iw + shift
+        z = np.zeros(scales.shape, dtype=np.int32) + shift
+    else:
+        z = np.asarray(zp).astype(np.int32).copy()
+    qweight = pack_rows(iw, bits, 32)  # [N, K/np]   :357
+    z = z - 1  # :364
+    qzeros = pack_rows(z.T.copy(), bits, 32)  # [G, N/np]  :365-371
+    return np.ascontiguousarray(qweight.T), qzeros, np.ascontiguousarray(scales.astype(np.float16).T)  # :372-375
+
+
+def woq_unpack_optimum(qweight, qzeros, N, K, G, bits):
+    """INCWeightOnlyLinear.unpack (modules.py:377-411) -> (int_weight [N,K] int16, zp [N,G] int16)."""
+    w = unpack_rows(np.ascontiguousarray(np.asarray(qweight).T), bits, 32, True)[:N, :K]
+    z = unpack_rows(np.asarray(qzeros), bits, 32, True)  # [G, N]
+    z = np.ascontiguousarray(z.T)[:N, :G].astype(np.int16)
+    z = z + 1  # :407-410
+    z = np.where(z > (2**bits - 1), 0, z).astype(np.int16)
+    return w, z
+
+
+def woq_recover(qweight, scales_f16, qzeros, N, K, bits, group_size, g_idx=None):
+    """INCWeightOnlyLinear.recover (modules.py:413-443) -> fp16 [N,K]: int8(w - zp[g]) * scales[g] in fp16."""
+    G = scales_f16.shape[0]
+    w, z = woq_unpack_optimum(qweight, qzeros, N, K, G, bits)
+    s = np.ascontiguousarray(np.asarray(scales_f16).T)  # [N,G] fp16
+    if g_idx is None:
+        g_idx = np.arange(K) // group_size
+    g_idx = np.asarray(g_idx).astype(np.int64)
+    d = (w.astype(np.int16) - z[:, g_idx].astype(np.int16)).astype(np.int8)
+    return (d.astype(np.float32) * s[:, g_idx].astype(np.float32)).astype(np.float16)
+
+
+# =====================================================================================================
+# group-wise RTN (float; torch CPU ops like the reference)
+# =====================================================================================================
+def qdq_weight_sym(weight, bits=4, quantile=1.0, return_int=False, full_range=False):
+    """utility.py:199-244 (operates in place on `weight` [rows, group])."""
+    maxq = torch.tensor(2 ** (bits - 1) - 1)
+    minq = torch.tensor(-(2 ** (bits - 1)))
+    if bits == 1:
+        maxq = torch.tensor(2 ** (bits - 1))
+        minq = torch.tensor(2 ** (bits - 1) - 1)
+    max_val = torch.max(weight, 1)[0]
+    min_val = torch.min(weight, 1)[0]
+    flip_flag = torch.abs(max_val) > torch.abs(min_val)
+    wmax = torch.max(torch.abs(max_val), torch.abs(min_val))
+    wmax = wmax * quantile
+    wmax[wmax == 0] = 1
+    if full_range:
+        scale = wmax / (-minq)
+        scale = torch.where(flip_flag, -scale, scale)
+    else:
+        scale = wmax / maxq
+    scale.unsqueeze_(dim=-1)
+    weight.div_(scale)
+    weight.round_()
+    weight.clamp_(minq, maxq)
+    if return_int:
+        return weight, scale, None
+    return weight.mul_(scale)
+
+
+def qdq_weight_asym(weight, bits=4, quantile=1.0, return_int=False):
+    """utility.py:162-196."""
+    maxq = torch.tensor(2**bits - 1)
+    zeros = torch.zeros(weight.shape[0])
+    wmin = torch.minimum(weight.min(1)[0], zeros)
+    wmax = torch.maximum(weight.max(1)[0], zeros)
+    wmin = wmin * quantile
+    wmax = wmax * quantile
+    tmp = (wmin == 0) & (wmax == 0)
+    wmin[tmp] = -1
+    wmax[tmp] = +1
+    scale = (wmax - wmin) / maxq
+    zp = torch.round(-wmin / scale)
+    scale.unsqueeze_(dim=-1)
+    zp.unsqueeze_(dim=-1)
+    weight.div_(scale)
+    weight.round_()
+    weight.add_(zp)
+    weight.clamp_(0, maxq)
+    if return_int:
+        return weight, scale, zp
+    weight.sub_(zp)
+    return weight.mul_(scale)
+
+
+def quant_tensor(weight, bits=4, group_size=-1, scheme="asym", quantile=1.0, return_int=False, full_range=False):
+    """utility.py:272-436 for dtype "int", no double quant.  NOT in place (works on a clone).
+
+    Returns the fake-quantised weight, or (int_weight, scale [N,G], zp [N,G] | None) when return_int.
+    """
+    weight = weight.clone()
+
+    def actor(w):
+        if scheme == "sym":
+            return qdq_weight_sym(w, bits, quantile, return_int, full_range)
+        return qdq_weight_asym(w, bits, quantile, return_int)
+
+    if group_size == -1 or weight.shape[1] < group_size:
+        group_size = weight.shape[1]
+    orig_shape = weight.shape
+    if weight.shape[1] % group_size == 0:
+        res = actor(weight.reshape(-1, group_size))
+        if return_int:
+            w, scale, zp = res
+            return (w.reshape(orig_shape), scale.reshape(orig_shape[0], -1), None if zp is None else zp.reshape(orig_shape[0], -1))
+        return res.reshape(orig_shape)
+    split = weight.shape[1] // group_size * group_size  # :334-376 tail group
+    r1 = actor(weight[:, :split].reshape(-1, group_size))
+    r2 = actor(weight[:, split:].clone())
+    if return_int:
+        w1, s1, z1 = r1
+        w2, s2, z2 = r2
+        w = torch.cat([w1.reshape(orig_shape[0], split), w2], dim=1)
+        scale = torch.cat([s1.reshape(orig_shape[0], -1), s2], dim=1)
+        zp = None if z1 is None else torch.cat([z1.reshape(orig_shape[0], -1), z2], dim=1)
+        return w, scale, zp
+    return torch.cat([r1.reshape(orig_shape[0], split), r2], dim=1)
+
+
+def search_clip(weight, bits=4, group_size=32, scheme="asym", full_range=False):
+    """utility.py:439-480 on a weight tensor."""
+    best_error, best_ratio = float("inf"), None
+    n_grid, max_shrink = 200, 0.2
+    for i_s in range(int(max_shrink * n_grid)):
+        ratio = 1 - i_s / n_grid
+        q = quant_tensor(weight, bits=bits, group_size=group_size, scheme=scheme, full_range=full_range, quantile=ratio)
+        loss = (weight - q).float().pow(2).mean()
+        if loss < best_error:
+            best_error, best_ratio = loss, ratio
+    return best_ratio
+
+
+# =====================================================================================================
+# GPTQ
+# =====================================================================================================
+class GPTQQuantParams:
+    """Quantizer.find_params / quantize for dtype int, perchannel, weight=True, no mse (gptq.py:1501-1637)."""
+
+    def __init__(self, bits=4, sym=False):
+        self.bits, self.sym = bits, sym
+        self.maxq = 2**bits - 1
+        self.scale = torch.zeros(1)
+        self.zero = torch.zeros(1)
+
+    def find_params(self, x):
+        x = x.flatten(1)
+        tmp = torch.zeros(x.shape[0])
+        xmin = torch.minimum(x.min(1)[0], tmp)
+        xmax = torch.maximum(x.max(1)[0], tmp)
+        if self.sym:
+            xmax = torch.maximum(torch.abs(xmin), xmax)
+            neg = xmin < 0
+            if torch.any(neg):
+                xmin[neg] = -xmax[neg]
+        z = (xmin == 0) & (xmax == 0)
+        xmin[z] = -1
+        xmax[z] = +1
+        self.scale = (xmax - xmin) / self.maxq
+        if self.sym:
+            self.zero = torch.full_like(self.scale, (self.maxq + 1) / 2)
+        else:
+            self.zero = torch.round(-xmin / self.scale)
+        self.scale = self.scale.reshape(-1, 1)
+        self.zero = self.zero.reshape(-1, 1)
+
+    def quantize(self, x):
+        q = torch.clamp(torch.round(x / self.scale) + self.zero, 0, self.maxq)
+        return self.scale * (q - self.zero)
+
+    def ready(self):
+        return torch.all(self.scale != 0)
+
+
+def gptq_add_batch(H, nsamples, inp):
+    """GPTQ.add_batch (gptq.py:1111-1141); returns (H, nsamples)."""
+    if len(inp.shape) == 2:
+        inp = inp.unsqueeze(0)
+    tmp = inp.shape[0]
+    if len(inp.shape) == 3:
+        inp = inp.reshape((-1, inp.shape[-1]))
+    inp = inp.t()
+    H = H * (nsamples / (nsamples + tmp))
+    nsamples += tmp
+    inp = math.sqrt(2 / nsamples) * inp.float()
+    H = H + inp.matmul(inp.t())
+    return H, nsamples
+
+
+def gptq_hinv(H, percdamp=0.01):
+    """gptq.py:1186-1189, 1221-1231 -> (Hinv upper Cholesky factor of the damped inverse, dead mask). H is copied."""
+    H = H.clone()
+    dead = torch.diag(H) == 0
+    H[dead, dead] = 1
+    damp = percdamp * torch.mean(torch.diag(H))
+    diag = torch.arange(H.shape[0])
+    H[diag, diag] += damp
+    H = torch.linalg.cholesky(H)
+    H = torch.cholesky_inverse(H)
+    H = torch.linalg.cholesky(H, upper=True)
+    return H, dead
+
+
+def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, groupsize=-1, act_order=False,
+                     static_groups=False, Hinv=None):
+    """GPTQ.fasterquant (gptq.py:1143-1351) for int dtype.  Returns dict(scale [N,G], zero [N,G], Q fp32 [N,K], perm).
+
+    `Hinv` (optional) injects a precomputed factor so the column loop can be tested in isolation.
+    """
+    W = W.clone().float()
+    quantizer = GPTQQuantParams(bits, sym)
+    columns = W.shape[1]
+    if not quantizer.ready():
+        quantizer.find_params(W)
+    H = H.clone()
+    dead = torch.diag(H) == 0
+    H[dead, dead] = 1
+    W[:, dead] = 0
+    groups = []
+    if static_groups:
+        import copy
+
+        for i in range(0, columns, groupsize):
+            q = copy.deepcopy(quantizer)
+            q.find_params(W[:, i : i + groupsize])
+            groups.append(q)
+    perm = None
+    if act_order:
+        perm = torch.argsort(torch.diag(H), descending=True)
+        W = W[:, perm]
+        H = H[perm][:, perm]
+    Q = torch.zeros_like(W)
+    if Hinv is None:
+        damp = percdamp * torch.mean(torch.diag(H))
+        diag = torch.arange(columns)
+        H[diag, diag] += damp
+        H = torch.linalg.cholesky(H)
+        H = torch.cholesky_inverse(H)
+        Hinv = torch.linalg.cholesky(H, upper=True)
+    scale, zero = [], []
+    for i1 in range(0, columns, blocksize):
+        i2 = min(i1 + blocksize, columns)
+        count = i2 - i1
+        W1 = W[:, i1:i2].clone()
+        Q1 = torch.zeros_like(W1)
+        Err1 = torch.zeros_like(W1)
+        Hinv1 = Hinv[i1:i2, i1:i2]
+        for i in range(count):
+            w = W1[:, i]
+            d = Hinv1[i, i]
+            if groupsize != -1:
+                if not static_groups:
+                    if (i1 + i) % groupsize == 0:
+                        quantizer.find_params(W[:, (i1 + i) : (i1 + i + groupsize)])
+                        scale.append(quantizer.scale)
+                        zero.append(quantizer.zero)
+                else:
+                    idx = i1 + i
+                    if act_order:
+                        idx = perm[idx]
+                    quantizer = groups[idx // groupsize]
+            q = quantizer.quantize(w.unsqueeze(1)).flatten()
+            Q1[:, i] = q
+            err1 = (w - q) / d
+            W1[:, i:] -= err1.unsqueeze(1).matmul(Hinv1[i, i:].unsqueeze(0))
+            Err1[:, i] = err1
+        Q[:, i1:i2] = Q1
+        W[:, i2:] -= Err1.matmul(Hinv[i1:i2, i2:])
+    if act_order:
+        Q = Q[:, torch.argsort(perm)]
+    # NB with static_groups the reference never appends to `scale` (gptq.py:1273-1277), so it returns only the
+    # LAST group's parameters (:1341-1345) -- restated as is; only Q is meaningful in that mode.
+    if scale == []:
+        scale.append(quantizer.scale)
+        zero.append(quantizer.zero)
+    return dict(scale=torch.cat(scale, dim=1), zero=torch.cat(zero, dim=1), Q=Q, perm=perm)
+
+
+def quant_weight_w_scale(weight, scale, zp=None, group_size=-1):
+    """utility.py:483-537 for int dtype: ints = round(W/scale (+zp)) per group (NOT in place)."""
+    weight = weight.clone()
+    if group_size == -1:
+        return weight.div_(scale).round_() if zp is None else weight.div_(scale).add_(zp).round_()
+    int_weight = torch.zeros(weight.shape)
+    leng = weight.shape[1] // group_size
+    tail = weight.shape[1] % group_size != 0
+    for i in range(leng):
+        t = weight[:, i * group_size : (i + 1) * group_size].div_(scale[:, i].unsqueeze(1))
+        if zp is not None:
+            t.add_(zp[:, i].unsqueeze(1))
+        int_weight[:, i * group_size : (i + 1) * group_size].copy_(t.round_())
+    if tail:
+        t = weight[:, leng * group_size :].div_(scale[:, -1].unsqueeze(1))
+        if zp is not None:
+            t.add_(zp[:, -1].unsqueeze(1))
+        int_weight[:, leng * group_size :].copy_(t.round_())
+    return int_weight
+
+
+def gptq_export_ints(Q, scale, zero, sym, group_size, perm=None):
+    """The export step of RAWGPTQuantizer.execute_quantization (gptq.py:795-813): int32 weights for pack()."""
+    Q = Q.clone()
+    if perm is not None:
+        Q = Q[:, perm]
+    ints = quant_weight_w_scale(Q, scale, None if sym else zero, group_size)
+    if perm is not None:
+        ints = ints[:, torch.argsort(perm)]
+    return ints.type(torch.int32)
+
+
+# =====================================================================================================
+# AWQ statistics
+# =====================================================================================================
+def awq_weight_scale(weight, q_group_size=-1):
+    """awq.py:131-147."""
+    org_shape = weight.shape
+    if q_group_size > 0:
+        weight = weight.view(-1, q_group_size)
+    scale = weight.abs() / weight.abs().amax(dim=1, keepdim=True)
+    return scale.view(org_shape).mean(0)
+
+
+def awq_act_scale(input_val):
+    """awq.py:151-154."""
+    tmp = torch.cat([x.abs().view(-1, x.shape[-1]) for x in input_val], dim=0)
+    return tmp.mean(0)
+
+
+# =====================================================================================================
+# forward
+# =====================================================================================================
+def woq_linear(x, qweight, scales_f16, qzeros, bias, N, K, bits, group_size, compute_dtype=torch.bfloat16, g_idx=None):
+    """INCWeightOnlyLinear.forward (modules.py:594-610) == F.linear(x, recover(), bias), evaluated in fp32 on the
+    weight rounded to `compute_dtype` (SURVEY.md 8(c) comparator (4))."""
+    w = torch.from_numpy(woq_recover(qweight, scales_f16, qzeros, N, K, bits, group_size, g_idx).astype(np.float32))
+    # recover() is exact-product-then-round-to-fp16; the kernels round the exact product to compute_dtype instead
+    G = scales_f16.shape[0]
+    iw, z = woq_unpack_optimum(qweight, qzeros, N, K, G, bits)
+    gi = (np.arange(K) // group_size) if g_idx is None else np.asarray(g_idx)
+    d = (iw.astype(np.int16) - z[:, gi].astype(np.int16)).astype(np.int8).astype(np.float32)
+    s = np.ascontiguousarray(np.asarray(scales_f16).T).astype(np.float32)[:, gi]
+    w = torch.from_numpy(d * s).to(compute_dtype).float()
+    y = torch.nn.functional.linear(x.to(compute_dtype).float(), w, None if bias is None else bias.float())
+    return y

@@ -1,0 +1,119 @@
+"""CPU: the oracle restatement must reproduce the outputs of the unmodified reference stored in tests/golden/."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import woq_oracle as O
+
+
+def test_kat_pack(golden):
+    qw, qz, sc = O.woq_pack_optimum(golden["kat_ints"], np.full((8, 2), 0.5, np.float32), None, 4)
+    assert np.array_equal(qw, golden["kat_qweight"])
+    assert np.array_equal(qz, golden["kat_qzeros"])
+    assert np.array_equal(sc.view(np.uint16), golden["kat_scales"].view(np.uint16))
+    # SURVEY 8(c) literal KAT: row0 = -8..7 -> 0x76543210 / 0xFEDCBA98, sym qzeros = 0x77777777
+    u = qw.view(np.uint32)
+    assert u[0, 0] == 0x76543210 and u[1, 0] == 0xFEDCBA98
+    assert np.all(qz.view(np.uint32) == 0x77777777)
+    rec = O.woq_recover(qw, sc, qz, 8, 16, 4, 8)
+    assert np.array_equal(rec, golden["kat_recover"])
+
+
+@pytest.mark.parametrize("tag,N,K,gs,bits", [("m4sym", 24, 64, 32, 4), ("m4asym", 20, 96, 32, 4), ("m8sym", 16, 64, 64, 8), ("m8asym", 16, 64, 32, 8)])
+def test_module_pack_unpack_recover(golden, tag, N, K, gs, bits):
+    zp = golden[f"{tag}_zp"] if f"{tag}_zp" in golden.files else None
+    qw, qz, sc = O.woq_pack_optimum(golden[f"{tag}_int"], golden[f"{tag}_scale"], zp, bits)
+    assert np.array_equal(qw, golden[f"{tag}_qweight"])
+    assert np.array_equal(qz, golden[f"{tag}_qzeros"])
+    assert np.array_equal(sc.view(np.uint16), golden[f"{tag}_scales16"].view(np.uint16))
+    G = sc.shape[0]
+    iw, z = O.woq_unpack_optimum(qw, qz, N, K, G, bits)
+    assert np.array_equal(iw, golden[f"{tag}_unpack_int"])
+    assert np.array_equal(z, golden[f"{tag}_unpack_zp"])
+    assert np.array_equal(O.woq_recover(qw, sc, qz, N, K, bits, gs), golden[f"{tag}_recover"])
+
+
+@pytest.mark.parametrize("bits", [2, 4, 8])
+@pytest.mark.parametrize("cbits", [8, 16, 32, 64])
+def test_pack_rows_all_containers(golden, bits, cbits):
+    packed = O.pack_rows(golden["rows_raw"], bits, cbits)
+    assert np.array_equal(packed, golden[f"rows_b{bits}_c{cbits}"])
+    assert np.array_equal(O.unpack_rows(packed, bits, cbits, mask_sign=False), golden[f"rows_b{bits}_c{cbits}_unpack_signed"])
+
+
+QT_CASES = {
+    "qt_sym4_g32": dict(bits=4, group_size=32, scheme="sym"),
+    "qt_asym4_g32": dict(bits=4, group_size=32, scheme="asym"),
+    "qt_sym4_g128_tail": dict(bits=4, group_size=128, scheme="sym"),
+    "qt_asym4_g128_tail": dict(bits=4, group_size=128, scheme="asym"),
+    "qt_sym8_pc": dict(bits=8, group_size=-1, scheme="sym"),
+    "qt_asym8_pc": dict(bits=8, group_size=-1, scheme="asym"),
+    "qt_sym4_full": dict(bits=4, group_size=32, scheme="sym", full_range=True),
+    "qt_sym4_q09": dict(bits=4, group_size=32, scheme="sym", quantile=0.9),
+    "qt_asym4_q085": dict(bits=4, group_size=32, scheme="asym", quantile=0.85),
+    "qt_sym3_g32": dict(bits=3, group_size=32, scheme="sym"),
+}
+
+
+@pytest.mark.parametrize("tag", list(QT_CASES))
+def test_quant_tensor(golden, tag):
+    w = torch.from_numpy(golden["qt_w"])
+    kw = QT_CASES[tag]
+    assert np.array_equal(O.quant_tensor(w, **kw).numpy(), golden[f"{tag}_qdq"])
+    iw, sc, zp = O.quant_tensor(w, return_int=True, **kw)
+    assert np.array_equal(iw.numpy(), golden[f"{tag}_int"])
+    assert np.array_equal(sc.numpy(), golden[f"{tag}_scale"])
+    if zp is not None:
+        assert np.array_equal(zp.numpy(), golden[f"{tag}_zp"])
+
+
+@pytest.mark.parametrize("tag,scheme", [("qtbf16_sym", "sym"), ("qtbf16_asym", "asym")])
+def test_quant_tensor_bf16(golden, tag, scheme):
+    w = torch.from_numpy(golden["qtbf16_w"]).to(torch.bfloat16)
+    assert np.array_equal(O.quant_tensor(w, bits=4, group_size=128, scheme=scheme).float().numpy(), golden[f"{tag}_qdq"])
+    iw, sc, zp = O.quant_tensor(w, bits=4, group_size=128, scheme=scheme, return_int=True)
+    assert np.array_equal(iw.float().numpy(), golden[f"{tag}_int"])
+    assert np.array_equal(sc.float().numpy(), golden[f"{tag}_scale"])
+
+
+def test_search_clip(golden):
+    w = torch.from_numpy(golden["qt_w"])
+    assert O.search_clip(w, bits=4, group_size=32, scheme="sym") == float(golden["clip_sym4_g32"])
+    assert O.search_clip(w, bits=4, group_size=128, scheme="asym") == float(golden["clip_asym4_g128"])
+
+
+GQ_CASES = {
+    "gq_sym_g32": dict(bits=4, sym=True, blocksize=128, groupsize=32),
+    "gq_asym_g32": dict(bits=4, sym=False, blocksize=128, groupsize=32),
+    "gq_sym_pc": dict(bits=4, sym=True, blocksize=128, groupsize=-1),
+    "gq_sym_g128_2blk": dict(bits=4, sym=True, blocksize=128, groupsize=128),
+    "gq_sym_g32_blk2048": dict(bits=4, sym=True, blocksize=2048, groupsize=32),
+    "gq_sym_act": dict(bits=4, sym=True, blocksize=128, groupsize=32, act_order=True),
+    "gq_sym8_g64": dict(bits=8, sym=True, blocksize=128, groupsize=64),
+}
+
+
+@pytest.mark.parametrize("tag", list(GQ_CASES))
+def test_gptq_layer(golden, tag):
+    kw = GQ_CASES[tag]
+    W = torch.from_numpy(golden[f"{tag}_W"])
+    X = torch.from_numpy(golden[f"{tag}_X"])
+    H, n = torch.zeros(W.shape[1], W.shape[1]), 0
+    for j in range(X.shape[0]):
+        H, n = O.gptq_add_batch(H, n, X[j : j + 1])
+    assert np.array_equal(H.numpy(), golden[f"{tag}_H"])
+    r = O.gptq_fasterquant(W, H, **kw)
+    assert np.array_equal(r["scale"].numpy(), golden[f"{tag}_scale"])
+    assert np.array_equal(r["zero"].numpy(), golden[f"{tag}_zero"])
+    assert np.array_equal(r["Q"].numpy(), golden[f"{tag}_Q"])
+    ints = O.gptq_export_ints(r["Q"], r["scale"], r["zero"], kw["sym"], kw["groupsize"], r["perm"])
+    assert np.array_equal(ints.numpy(), golden[f"{tag}_ints"].astype(np.int32))
+
+
+def test_awq_stats(golden):
+    w = torch.from_numpy(golden["awq_w"])
+    assert np.array_equal(O.awq_weight_scale(w, 32).numpy(), golden["awq_wscale_g32"])
+    assert np.array_equal(O.awq_weight_scale(w, -1).numpy(), golden["awq_wscale_pc"])
+    x = torch.from_numpy(golden["awq_x"])
+    assert np.array_equal(O.awq_act_scale([x[i : i + 1] for i in range(x.shape[0])]).numpy(), golden["awq_xscale"])
