@@ -98,5 +98,9 @@ class RTNQuantizer(Quantizer):
             if name == "":
                 return new_module
             set_module(model, name, new_module)
-            m.to(model_device)  # the float module is dropped; keep the caller's placement semantics
+        # MI355X-first: the quantised model lives in HBM (the packed modules have no host implementation); the
+        # reference moves everything back to `model_device` (rtn.py:262-266).
+        if model_device != device:
+            logger.info("RTN: moving the quantised model from %s to %s", model_device, device)
+        model.to(device)
         return model

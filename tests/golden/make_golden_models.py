@@ -1,0 +1,78 @@
+"""Model-level golden fixtures from the UNMODIFIED reference (build container only):
+
+    python tests/golden/make_golden_models.py
+
+  gptq_tiny_llama.npz : prepare -> run_fn -> convert of the reference on tests/model_zoo.tiny_llama (fp32, CPU)
+                        -> per-module qweight / scales / qzeros + logits of the quantised model
+  rtn_tiny_llama.npz  : quantize(model, RTNConfig(...)) -> same buffers
+"""
+
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from make_golden import REF, _install_stubs  # noqa: E402
+
+
+def dump_modules(q, out):
+    n = 0
+    for name, mod in q.named_modules():
+        if type(mod).__name__ == "INCWeightOnlyLinear":
+            out[f"{name}.qweight"] = mod.qweight.numpy()
+            out[f"{name}.qzeros"] = mod.qzeros.numpy()
+            out[f"{name}.scales"] = mod.scales.numpy()
+            n += 1
+    out["n_modules"] = np.int64(n)
+
+
+def main():
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import torch
+    from neural_compressor.torch.quantization import GPTQConfig, RTNConfig, convert, prepare, quantize
+
+    from tests.model_zoo import calib_ids, tiny_llama
+
+    ids = calib_ids()
+
+    def run_fn(model):
+        for x in ids:
+            model(x)
+
+    tmp = tempfile.mkdtemp()  # GPTQConfig(model_path=<existing dir>) quirk, gptq.py:277
+    for tag, kw in {
+        "sym_g32": dict(bits=4, group_size=32, use_sym=True, block_size=128),
+        "asym_g32": dict(bits=4, group_size=32, use_sym=False, block_size=128),
+    }.items():
+        model = tiny_llama()
+        cfg = GPTQConfig(model_path=tmp, **kw)
+        model = prepare(model, cfg)
+        run_fn(model)
+        q = convert(model)
+        out = {}
+        dump_modules(q, out)
+        with torch.no_grad():
+            out["logits"] = q(ids[0]).logits.float().numpy()
+        np.savez_compressed(os.path.join(HERE, f"gptq_tiny_llama_{tag}.npz"), **out)
+        print(tag, "modules:", int(out["n_modules"]))
+
+    model = tiny_llama()
+    q = quantize(model, RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
+    out = {}
+    dump_modules(q, out)
+    with torch.no_grad():
+        out["logits"] = q(ids[0]).logits.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "rtn_tiny_llama_asym_g32.npz"), **out)
+    print("rtn modules:", int(out["n_modules"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the collective bookkeeping of the multi-GPU calibration paths."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neural_compressor_amd import distributed as D
+
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    # --- mode "sample": sharded running-mean Hessians combine to the global one
+    g = torch.Generator().manual_seed(0)
+    K, n_total = 24, 5
+    xs = [torch.randn(1, 16, K, generator=g) for _ in range(n_total)]
+    mine = D.shard_samples(n_total, rank, world)
+    H, n = torch.zeros(K, K), 0
+    for j in mine:  # reference running form, gptq.py:1136-1141
+        x = xs[j].reshape(-1, K)
+        H = H * (n / (n + 1))
+        n += 1
+        H = H + (2.0 / n) * x.t() @ x
+    H, n_all = D.allreduce_hessian(H, n)
+    Href, m = torch.zeros(K, K), 0
+    for x in xs:
+        x = x.reshape(-1, K)
+        Href = Href * (m / (m + 1))
+        m += 1
+        Href = Href + (2.0 / m) * x.t() @ x
+    ok_h = n_all == n_total and torch.allclose(H, Href, rtol=1e-5, atol=1e-6)
+    # --- mode "layer": ownership + activation broadcast
+    owners = [D.owner_of_block(b, world) for b in range(5)]
+    acts = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(2, 3, 4) if rank == 1 else None
+    got = D.broadcast_calibration(acts, src=1, shape=(2, 3, 4), dtype=torch.float32, device="cpu")
+    ok_b = torch.equal(got, torch.arange(24, dtype=torch.float32).reshape(2, 3, 4))
+    t = D.barrier_max_time(float(rank + 1), device="cpu")
+    out[rank] = (ok_h, ok_b, owners, D.blocks_of_rank(5, rank, world), t)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gloo_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    for rank in range(world):
+        ok_h, ok_b, owners, mine, t = res[rank]
+        assert ok_h and ok_b
+        assert owners == [0, 1, 0, 1, 0]
+        assert mine == ([0, 2, 4] if rank == 0 else [1, 3])
+        assert t == 2.0
+
+
+def test_single_process_paths_are_identity():
+    from neural_compressor_amd import distributed as D
+
+    H = torch.ones(3, 3)
+    H2, n = D.allreduce_hessian(H, 4)
+    assert H2 is H and n == 4
+    assert D.shard_samples(10, 1, 4) == [3, 4, 5]
+    assert sum(len(D.shard_samples(10, r, 4)) for r in range(4)) == 10
+    assert D.barrier_max_time(1.5) == 1.5

@@ -1,0 +1,445 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the oracle and the reference's golden vectors.
+
+Bars (BASELINE.json north_star / SURVEY.md 8(c)):
+  * integer work (pack / unpack / zero points / int codes): bit-exact (np.array_equal)
+  * fp16 scales and fp16 recover(): bit-exact when fed the same fp32 scales
+  * RTN scales / fake-quantised weights in fp32: bit-exact vs the reference's CPU arithmetic
+  * GPTQ: Hessian rel-Frobenius <= 1e-5 (fp32 path) ; with the oracle's Hinv injected, one 128-column block is
+    bit-exact; multi-block layers: >= 99.5 % identical codes and dequantised weights within 1e-3 relative (Frobenius)
+  * fused GEMM vs F.linear on the same bf16-rounded weights in fp32: rel-Frobenius <= 1e-3 (tolerance from north_star)
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import woq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+def rel_fro(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------
+# K1 / K2 / K3
+# ---------------------------------------------------------------------------------------------------
+def test_kat_pack_unpack_recover(hip, golden):
+    from neural_compressor_amd import ops
+
+    ints = _t(golden["kat_ints"], hip)
+    scales = torch.full((8, 2), 0.5, device=hip)
+    qw, qz, sc = ops.woq_pack(ints, scales, None, 4, 8)
+    assert np.array_equal(qw.cpu().numpy(), golden["kat_qweight"])
+    assert np.array_equal(qz.cpu().numpy(), golden["kat_qzeros"])
+    assert np.array_equal(sc.cpu().numpy().view(np.uint16), golden["kat_scales"].view(np.uint16))
+    rec = ops.woq_dequant(qw, sc, qz, None, 8, 16, 8, 4, out_dtype=torch.float16)
+    assert np.array_equal(rec.cpu().numpy(), golden["kat_recover"])
+
+
+@pytest.mark.parametrize("tag,N,K,gs,bits", [("m4sym", 24, 64, 32, 4), ("m4asym", 20, 96, 32, 4), ("m8sym", 16, 64, -1, 8), ("m8asym", 16, 64, 32, 8)])
+def test_module_against_reference_golden(hip, golden, tag, N, K, gs, bits):
+    """MI355XWeightOnlyLinear.pack/unpack/recover == the reference's INCWeightOnlyLinear, buffer for buffer."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    zp = _t(golden[f"{tag}_zp"], hip) if f"{tag}_zp" in golden.files else None
+    iw = _t(golden[f"{tag}_int"], hip, torch.int32)
+    sc = _t(golden[f"{tag}_scale"], hip)
+    m = MI355XWeightOnlyLinear(K, N, bits=bits, group_size=gs, zp=zp is not None, device=hip)
+    iw_before = iw.clone()
+    m.pack(iw, sc, zp, None)
+    assert torch.equal(iw, iw_before), "pack() must not mutate its arguments"
+    assert np.array_equal(m.qweight.cpu().numpy(), golden[f"{tag}_qweight"])
+    assert np.array_equal(m.qzeros.cpu().numpy(), golden[f"{tag}_qzeros"])
+    assert np.array_equal(m.scales.cpu().numpy().view(np.uint16), golden[f"{tag}_scales16"].view(np.uint16))
+    up = m.unpack()
+    assert np.array_equal(up["int_weight"].cpu().numpy(), golden[f"{tag}_unpack_int"])
+    assert np.array_equal(up["zp"].cpu().numpy(), golden[f"{tag}_unpack_zp"])
+    assert np.array_equal(m.recover().cpu().numpy(), golden[f"{tag}_recover"])  # fp16, bit for bit
+    # bf16 recover: one rounding of the exact product
+    exact = golden[f"{tag}_recover"].astype(np.float32)
+    bf = m.recover(dtype=torch.bfloat16).float().cpu()
+    assert (bf - torch.from_numpy(exact)).abs().max() <= torch.from_numpy(np.abs(exact)).max() * 2**-7
+
+
+@pytest.mark.parametrize("bits", [2, 4, 8])
+@pytest.mark.parametrize("cbits", [8, 16, 32, 64])
+def test_pack_rows_all_containers(hip, golden, bits, cbits):
+    """The reference's 12-way pack/unpack test (test/torch/algorithms/weight_only/test_woq_module.py:10-52)."""
+    from neural_compressor_amd import ops
+
+    raw = _t(golden["rows_raw"], hip)
+    packed = ops.pack_rows(raw, bits, cbits)
+    assert np.array_equal(packed.cpu().numpy(), golden[f"rows_b{bits}_c{cbits}"])
+    un = ops.unpack_rows(packed, bits, cbits, False)
+    assert np.array_equal(un.cpu().numpy(), golden[f"rows_b{bits}_c{cbits}_unpack_signed"])
+
+
+@pytest.mark.parametrize("N,K,gs,bits,sym", [(4096, 4096, 128, 4, True), (1000, 1576, 128, 4, False), (257, 520, 64, 8, False), (64, 72, 8, 2, True)])
+def test_pack_roundtrip_large_and_ragged(hip, N, K, gs, bits, sym):
+    """Full-size + ragged shapes: pack -> unpack is the identity, and equals the numpy oracle on a slice."""
+    from neural_compressor_amd import ops
+
+    g = torch.Generator().manual_seed(N + K)
+    lo, hi = (-(2 ** (bits - 1)), 2 ** (bits - 1)) if sym else (0, 2**bits)
+    iw = torch.randint(lo, hi, (N, K), generator=g, dtype=torch.int32)
+    G = -(-K // gs)
+    sc = torch.rand(N, G, generator=g) * 0.1 + 0.01
+    zp = None if sym else torch.randint(0, 2**bits, (N, G), generator=g, dtype=torch.int32)
+    qw, qz, s16 = ops.woq_pack(iw.to(hip), sc.to(hip), None if zp is None else zp.to(hip), bits, 2 ** (bits - 1) if sym else 0)
+    ui, uz = ops.woq_unpack(qw, qz, N, K, G, bits)
+    expect = iw + (2 ** (bits - 1) if sym else 0)
+    assert torch.equal(ui.cpu().to(torch.int32), expect)
+    ez = torch.full((N, G), 2 ** (bits - 1), dtype=torch.int32) if sym else zp
+    ez = torch.where(ez - 1 < 0, torch.zeros_like(ez), ez)  # zp==0 is stored as -1 -> 2^b-1 -> wraps to 0 on unpack
+    assert torch.equal(uz.cpu().to(torch.int32), ez)
+    rows = slice(0, min(N, 96))
+    oqw, oqz, osc = O.woq_pack_optimum(iw[rows].numpy(), sc[rows].numpy(), None if zp is None else zp[rows].numpy(), bits)
+    assert np.array_equal(qw[:, rows].cpu().numpy(), oqw)
+    assert np.array_equal(s16[:, rows].cpu().numpy().view(np.uint16), osc.view(np.uint16))
+    if N >= 96 and 96 % (32 // bits) == 0:
+        assert np.array_equal(qz[:, : 96 // (32 // bits)].cpu().numpy(), oqz)
+    rec = ops.woq_dequant(qw, s16, qz, None, N, K, gs, bits, out_dtype=torch.float16)
+    orec = O.woq_recover(oqw, osc, oqz, rows.stop, K, bits, gs)
+    assert np.array_equal(rec[rows].cpu().numpy(), orec)
+
+
+def test_dequant_with_g_idx(hip):
+    from neural_compressor_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    N, K, gs = 48, 256, 32
+    iw = torch.randint(0, 16, (N, K), generator=g, dtype=torch.int32)
+    sc = torch.rand(N, K // gs, generator=g) * 0.1 + 0.01
+    zp = torch.randint(1, 16, (N, K // gs), generator=g, dtype=torch.int32)
+    perm = torch.randperm(K, generator=g)
+    g_idx = (torch.argsort(perm) // gs).to(torch.int32)
+    qw, qz, s16 = ops.woq_pack(iw.to(hip), sc.to(hip), zp.to(hip), 4, 0)
+    rec = ops.woq_dequant(qw, s16, qz, g_idx.to(hip), N, K, gs, 4, out_dtype=torch.float16)
+    orec = O.woq_recover(qw.cpu().numpy(), s16.cpu().numpy(), qz.cpu().numpy(), N, K, 4, gs, g_idx.numpy())
+    assert np.array_equal(rec.cpu().numpy(), orec)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K7 RTN
+# ---------------------------------------------------------------------------------------------------
+QT_CASES = {
+    "qt_sym4_g32": dict(bits=4, group_size=32, scheme="sym"),
+    "qt_asym4_g32": dict(bits=4, group_size=32, scheme="asym"),
+    "qt_sym4_g128_tail": dict(bits=4, group_size=128, scheme="sym"),
+    "qt_asym4_g128_tail": dict(bits=4, group_size=128, scheme="asym"),
+    "qt_sym8_pc": dict(bits=8, group_size=-1, scheme="sym"),
+    "qt_asym8_pc": dict(bits=8, group_size=-1, scheme="asym"),
+    "qt_sym4_full": dict(bits=4, group_size=32, scheme="sym", full_range=True),
+    "qt_sym4_q09": dict(bits=4, group_size=32, scheme="sym", quantile=0.9),
+    "qt_asym4_q085": dict(bits=4, group_size=32, scheme="asym", quantile=0.85),
+    "qt_sym3_g32": dict(bits=3, group_size=32, scheme="sym"),
+}
+
+
+@pytest.mark.parametrize("tag", list(QT_CASES))
+def test_quant_tensor_vs_reference_golden(hip, golden, tag):
+    """fp32 weights: ints, scales, zero points and the fake-quantised weight are bit-identical to the reference."""
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    kw = QT_CASES[tag]
+    w = _t(golden["qt_w"], hip)
+    q = quant_tensor(w.clone(), **kw)
+    assert np.array_equal(q.cpu().numpy(), golden[f"{tag}_qdq"])
+    iw, sc, zp = quant_tensor(w.clone(), return_int=True, **kw)
+    assert np.array_equal(iw.cpu().numpy(), golden[f"{tag}_int"].astype(np.int32))
+    assert np.array_equal(sc.cpu().numpy(), golden[f"{tag}_scale"])
+    if zp is not None:
+        assert np.array_equal(zp.cpu().numpy(), golden[f"{tag}_zp"])
+    # in-place contract of the reference (test_woq_utility.py:5-14)
+    w2 = w.clone()
+    assert quant_tensor(w2, **kw).data_ptr() == w2.data_ptr()
+
+
+@pytest.mark.parametrize("tag,scheme", [("qtbf16_sym", "sym"), ("qtbf16_asym", "asym")])
+def test_quant_tensor_bf16_matches_torch_bf16_semantics(hip, golden, tag, scheme):
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    w = _t(golden["qtbf16_w"], hip, torch.bfloat16)
+    q = quant_tensor(w.clone(), bits=4, group_size=128, scheme=scheme)
+    assert np.array_equal(q.float().cpu().numpy(), golden[f"{tag}_qdq"])
+    iw, sc, zp = quant_tensor(w.clone(), bits=4, group_size=128, scheme=scheme, return_int=True)
+    assert np.array_equal(iw.cpu().numpy(), golden[f"{tag}_int"].astype(np.int32))
+    assert np.array_equal(sc.cpu().numpy(), golden[f"{tag}_scale"])
+
+
+@pytest.mark.parametrize("shape", [(512, 300), (1024, 1024), (4096, 4096)])
+def test_quant_tensor_vs_oracle_sizes(hip, shape):
+    """The reference's own size sweep (1024 / 512 / 300, test_woq_utility.py) plus the BASELINE 4096x4096."""
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    g = torch.Generator().manual_seed(shape[0])
+    w = torch.randn(*shape, generator=g) * 0.02
+    for scheme in ("sym", "asym"):
+        iw, sc, zp = quant_tensor(w.to(hip), bits=4, group_size=128, scheme=scheme, return_int=True)
+        oi, os_, oz = O.quant_tensor(w, bits=4, group_size=128, scheme=scheme, return_int=True)
+        assert torch.equal(iw.cpu(), oi.to(torch.int32))
+        assert torch.equal(sc.cpu(), os_)
+        if oz is not None:
+            assert torch.equal(zp.cpu(), oz)
+
+
+def test_search_clip_matches_reference(hip, golden):
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import search_clip
+
+    lin = torch.nn.Linear(300, 12, bias=False)
+    lin.weight.data.copy_(torch.from_numpy(golden["qt_w"]))
+    lin.to(hip)
+    assert search_clip(lin, bits=4, group_size=32, scheme="sym") == pytest.approx(float(golden["clip_sym4_g32"]), abs=0.0051)
+    assert search_clip(lin, bits=4, group_size=128, scheme="asym") == pytest.approx(float(golden["clip_asym4_g128"]), abs=0.0051)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K5 / K6 GPTQ
+# ---------------------------------------------------------------------------------------------------
+GQ_CASES = {
+    "gq_sym_g32": dict(bits=4, sym=True, blocksize=128, groupsize=32),
+    "gq_asym_g32": dict(bits=4, sym=False, blocksize=128, groupsize=32),
+    "gq_sym_pc": dict(bits=4, sym=True, blocksize=128, groupsize=-1),
+    "gq_sym_g128_2blk": dict(bits=4, sym=True, blocksize=128, groupsize=128),
+    "gq_sym_g32_blk2048": dict(bits=4, sym=True, blocksize=2048, groupsize=32),
+    "gq_sym8_g64": dict(bits=8, sym=True, blocksize=128, groupsize=64),
+}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-6), (torch.float16, 2e-6)])
+def test_hessian_accum(hip, dtype, tol):
+    """H after 3 batches vs the oracle's add_batch on the same (dtype-rounded) activations."""
+    from neural_compressor_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    K = 328  # not a multiple of the 128 tile
+    H = torch.zeros(K, K, device=hip)
+    Ho, n = torch.zeros(K, K), 0
+    nsamp = 0
+    for b, seq in ((1, 200), (2, 96), (1, 77)):
+        x = (torch.randn(b, seq, K, generator=g)).to(dtype)
+        x[..., 5] = 0  # a dead column
+        beta = nsamp / (nsamp + b)
+        nsamp += b
+        ops.gptq_hessian_accum(H, x.to(hip).reshape(-1, K), beta, 2.0 / nsamp)
+        Ho, n = O.gptq_add_batch(Ho, n, x.float())
+    iu = torch.triu_indices(K, K)
+    got = H.cpu()[iu[0], iu[1]]
+    assert rel_fro(got, Ho[iu[0], iu[1]]) <= tol
+    dead = ops.gptq_hessian_finalize(H, 0.01)
+    Hf = H.cpu()
+    assert torch.equal(Hf, Hf.t()), "finalize must mirror the upper triangle"
+    assert dead.cpu()[5] == 1 and int(dead.sum()) == 1
+    Hd = Ho.clone()
+    Hd[5, 5] = 1
+    damp = 0.01 * torch.mean(torch.diag(Hd))
+    assert float((torch.diag(Hf) - (torch.diag(Hd) + damp)).abs().max()) <= 1e-5 * float(torch.diag(Hd).abs().max())
+
+
+@pytest.mark.parametrize("tag", list(GQ_CASES))
+def test_gptq_column_loop_with_injected_hinv(hip, golden, tag):
+    """Column loop in isolation (SURVEY 8(c) comparator (5)): feed the oracle's Hinv, compare codes / scales / Q."""
+    from neural_compressor_amd import ops
+
+    kw = GQ_CASES[tag]
+    W = torch.from_numpy(golden[f"{tag}_W"])
+    Href = torch.from_numpy(golden[f"{tag}_H"])
+    Hinv, dead = O.gptq_hinv(Href, 0.01)
+    N, K = W.shape
+    bits, sym, gs_cfg, blocksize = kw["bits"], kw["sym"], kw["groupsize"], kw["blocksize"]
+    gs = K if gs_cfg == -1 else gs_cfg
+    G = -(-K // gs)
+    w32 = ops.gptq_prepare_weight(W.to(hip), dead.to(torch.uint8).to(hip))
+    hinv = Hinv.contiguous().to(hip)
+    scale = torch.empty(N, G, device=hip)
+    zero = torch.empty(N, G, device=hip)
+    codes = torch.empty(N, K, dtype=torch.uint8, device=hip)
+    Q = torch.empty(N, K, device=hip)
+    err = torch.empty(N, 128, device=hip)
+    if gs_cfg == -1:
+        ops.gptq_find_params(w32, 0, K, 1, bits, sym, scale, zero, 0)
+    i1 = 0
+    while i1 < K:
+        ref_end = min((i1 // blocksize + 1) * blocksize, K)
+        count = min(128, ref_end - i1)
+        if gs_cfg != -1 and i1 % blocksize == 0:
+            g_first, g_last = -(-i1 // gs), (ref_end - 1) // gs
+            ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first)
+        ops.gptq_quant_block(w32, hinv, scale, zero, codes, Q, err, i1, count, gs if gs_cfg != -1 else 0, bits)
+        ops.gptq_lazy_update(w32, hinv, err, i1, count)
+        i1 += count
+    ref_scale, ref_zero, ref_Q = golden[f"{tag}_scale"], golden[f"{tag}_zero"], golden[f"{tag}_Q"]
+    ref_ints = golden[f"{tag}_ints"].astype(np.int32) + (2 ** (bits - 1) if sym else 0)
+    got_codes = codes.cpu().numpy().astype(np.int32)
+    match = float((got_codes == ref_ints).mean())
+    if K <= 128:
+        # a single block: identical un-fused fp32 arithmetic -> bit-exact
+        assert np.array_equal(scale.cpu().numpy(), ref_scale)
+        assert np.array_equal(zero.cpu().numpy(), ref_zero)
+        assert match == 1.0, f"codes differ: {match}"
+        assert np.array_equal(Q.cpu().numpy(), ref_Q)
+    else:
+        # the lazy update is a GEMM whose summation order differs from MKL's: allow rounding-tie flips
+        assert match >= 0.995, f"only {match:.4f} of the codes match"
+        assert rel_fro(scale.cpu(), torch.from_numpy(ref_scale)) <= 1e-3
+        assert rel_fro(Q.cpu(), torch.from_numpy(ref_Q)) <= 2e-2  # a flipped code moves one weight by one step
+        # first block is untouched by any lazy update -> exact
+        assert np.array_equal(got_codes[:, :128], ref_ints[:, :128])
+
+
+@pytest.mark.parametrize("tag", ["gq_sym_g32", "gq_asym_g32", "gq_sym_pc", "gq_sym_g128_2blk", "gq_sym_act", "gq_sym8_g64"])
+def test_gptq_layer_end_to_end(hip, golden, tag):
+    """add_batch -> fasterquant -> pack through the Python mirror classes vs the reference's golden outputs."""
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import GPTQ
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    cfgs = dict(GQ_CASES, gq_sym_act=dict(bits=4, sym=True, blocksize=128, groupsize=32, act_order=True))
+    kw = cfgs[tag]
+    W = torch.from_numpy(golden[f"{tag}_W"])
+    X = torch.from_numpy(golden[f"{tag}_X"])
+    N, K = W.shape
+    layer = torch.nn.Linear(K, N, bias=False).to(hip)
+    layer.weight.data.copy_(W)
+    gq = GPTQ(layer, device=hip)
+    gq.configure(dict(bits=kw["bits"], sym=kw["sym"], dtype="int", mse=False))
+    for j in range(X.shape[0]):
+        gq.add_batch(X[j : j + 1].to(hip))
+    scale, _, zero, Q = gq.fasterquant(
+        layer.weight.data, blocksize=kw["blocksize"], percdamp=0.01, groupsize=kw["groupsize"], act_order=kw.get("act_order", False)
+    )
+    ref_ints = golden[f"{tag}_ints"].astype(np.int32) + (2 ** (kw["bits"] - 1) if kw["sym"] else 0)
+    match = float((gq.codes.cpu().numpy().astype(np.int32) == ref_ints).mean())
+    assert match >= 0.99, f"only {match:.4f} of the codes match the reference"
+    assert rel_fro(scale.cpu(), torch.from_numpy(golden[f"{tag}_scale"])) <= 1e-3
+    if not kw["sym"]:
+        assert float((zero.cpu() != torch.from_numpy(golden[f"{tag}_zero"])).float().mean()) <= 0.01
+    assert rel_fro(Q.cpu(), torch.from_numpy(golden[f"{tag}_Q"])) <= 3e-2
+    # export: pack_codes == the reference's pack() on the same integers
+    gs = kw["groupsize"]
+    perm = gq.perm
+    m = MI355XWeightOnlyLinear(K, N, bits=kw["bits"], group_size=gs, zp=not kw["sym"], g_idx=perm is not None, device=hip)
+    m.pack_codes(gq.codes, scale, None if kw["sym"] else zero, None, g_idx=perm)
+    signed = gq.codes.cpu().to(torch.int32) - (2 ** (kw["bits"] - 1) if kw["sym"] else 0)
+    oqw, oqz, osc = O.woq_pack_optimum(signed.numpy(), scale.cpu().numpy(), None if kw["sym"] else zero.cpu().numpy(), kw["bits"])
+    assert np.array_equal(m.qweight.cpu().numpy(), oqw)
+    assert np.array_equal(m.qzeros.cpu().numpy(), oqz)
+    assert np.array_equal(m.scales.cpu().numpy().view(np.uint16), osc.view(np.uint16))
+
+
+def test_gptq_full_size_layer_properties(hip):
+    """BASELINE size (4096x4096, g128, sym): size-independent properties -- every dequantised weight lies on its
+    group's grid, codes are in range, GPTQ's output error (X W^T) beats RTN's, pack->recover reproduces Q."""
+    from neural_compressor_amd import ops
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import GPTQ
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    torch.manual_seed(0)
+    N = K = 4096
+    layer = torch.nn.Linear(K, N, bias=False, device=hip, dtype=torch.bfloat16)
+    layer.weight.data.normal_(0, 0.02)
+    W0 = layer.weight.data.clone()
+    gq = GPTQ(layer, device=hip)
+    gq.configure(dict(bits=4, sym=True, dtype="int", mse=False))
+    xs = []
+    for j in range(4):
+        x = torch.randn(1, 512, K, device=hip, dtype=torch.bfloat16)
+        x[..., ::41] *= 20
+        xs.append(x)
+        gq.add_batch(x)
+    scale, _, zero, Q = gq.fasterquant(W0, blocksize=128, percdamp=0.01, groupsize=128)
+    codes = gq.codes
+    assert int(codes.max()) <= 15
+    grid = (codes.float() - 8.0) * scale.repeat_interleave(128, dim=1)
+    assert torch.equal(grid.to(torch.bfloat16), Q), "Q must be scale*(code-zero) rounded to the weight dtype"
+    X = torch.cat(xs, 1)[0].float()
+    rtn = ops.groupwise_quant(W0.float().clone(), 4, 128, "sym")
+    e_gptq = (X @ (Q.float() - W0.float()).t()).pow(2).mean()
+    e_rtn = (X @ (rtn - W0.float()).t()).pow(2).mean()
+    assert e_gptq < e_rtn, f"GPTQ output error {e_gptq} should beat RTN {e_rtn} (reference test_gptq.py:62-80)"
+    m = MI355XWeightOnlyLinear(K, N, bits=4, group_size=128, device=hip)
+    m.pack_codes(codes, scale, None, None)
+    rec = m.recover(dtype=torch.float32)
+    s16 = scale.to(torch.float16).float().repeat_interleave(128, dim=1)
+    assert torch.equal(rec, (codes.float() - 8.0) * s16)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K4 fused GEMM
+# ---------------------------------------------------------------------------------------------------
+def _packed_layer(hip, N, K, gs, bits, sym, seed, bias=True):
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(hip)
+    iw, sc, zp = quant_tensor(w, bits=bits, group_size=gs, scheme="sym" if sym else "asym", return_int=True)
+    m = MI355XWeightOnlyLinear(K, N, bits=bits, group_size=gs, zp=zp is not None, bias=bias, device=hip)
+    b = (torch.randn(N, generator=g) * 0.1).to(hip) if bias else None
+    m.pack(iw, sc, zp, b)
+    return m
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,gs,bits,sym", [
+    (1, 512, 1024, 128, 4, True), (16, 320, 640, 64, 4, False), (7, 256, 512, 128, 8, False),
+    (200, 384, 512, 128, 4, True), (512, 1000, 1576, 128, 4, False), (130, 256, 320, 32, 8, True),
+])
+def test_fused_gemm_vs_oracle(hip, dtype, M, N, K, gs, bits, sym):
+    m = _packed_layer(hip, N, K, gs, bits, sym, seed=M + N)
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(dtype)
+    y = m(x.to(hip))
+    assert y.dtype == dtype and y.shape == (M, N)
+    ref = O.woq_linear(x, m.qweight.cpu().numpy(), m.scales.cpu().numpy(), m.qzeros.cpu().numpy(), m.bias.cpu().to(dtype), N, K, bits, gs, compute_dtype=dtype)
+    # output rounding to 16 bits dominates: compare against the reference rounded the same way
+    assert rel_fro(y.float().cpu(), ref) <= 4e-3
+    assert rel_fro(y.float().cpu(), ref.to(dtype).float()) <= 1e-3
+
+
+@pytest.mark.parametrize("M", [1, 16, 512, 4096])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
+def test_fused_gemm_baseline_shapes(hip, M, N, K):
+    """BASELINE shapes: fused kernel == HIP dequant (verified against the oracle above) + fp32 matmul, <= 1e-3."""
+    m = _packed_layer(hip, N, K, 128, 4, True, seed=N + K, bias=False)
+    m.bias = None
+    torch.manual_seed(M)
+    x = torch.randn(M, K, device=hip, dtype=torch.bfloat16)
+    y = m(x)
+    w = m.recover(dtype=torch.bfloat16).float()
+    ref = x.float() @ w.t()
+    assert rel_fro(y.float(), ref.to(torch.bfloat16).float()) <= 1e-3
+    # linearity: f(2x) == 2 f(x) exactly in floating point (power-of-two scaling)
+    assert torch.equal(m(x * 2), y * 2)
+
+
+def test_forward_matches_reference_accelerator_semantics(hip):
+    """fp32 input -> cast to fp16 and fp16 out, as the reference does on an accelerator (modules.py:605)."""
+    m = _packed_layer(hip, 128, 256, 32, 4, True, seed=5)
+    x = torch.randn(3, 5, 256, device=hip)
+    y = m(x)
+    assert y.dtype == torch.float16 and y.shape == (3, 5, 128)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K8 AWQ statistics
+# ---------------------------------------------------------------------------------------------------
+def test_awq_stats(hip, golden):
+    from neural_compressor_amd import ops
+
+    w = _t(golden["awq_w"], hip)
+    assert torch.allclose(ops.awq_weight_scale(w, 32).cpu(), torch.from_numpy(golden["awq_wscale_g32"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ops.awq_weight_scale(w, -1).cpu(), torch.from_numpy(golden["awq_wscale_pc"]), rtol=1e-5, atol=1e-6)
+    x = _t(golden["awq_x"], hip)
+    out = torch.zeros(128, device=hip)
+    ops.awq_act_abs_sum(x.reshape(-1, 128), out)
+    assert torch.allclose((out / 60).cpu(), torch.from_numpy(golden["awq_xscale"]), rtol=1e-5, atol=1e-6)
