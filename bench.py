@@ -24,6 +24,7 @@ import time
 
 import torch
 
+T_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -123,25 +124,49 @@ def bench_dequant_gemm(device, shapes, iters=20):
     return res
 
 
-def cpu_baseline():
-    """The oracle (a restatement of the reference's CPU arithmetic) timed on this host: a bounded sample of the same
-    workload, extrapolated to the 32-block job (the full CPU run is ~8 h)."""
+def _cpu_baseline_worker(threads):
+    """Runs in a child process: times the oracle (CPU restatement of the reference) on a bounded sample."""
     from oracle import woq_oracle as O
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
     K = 4096
     x = torch.randn(1, 2048, K, generator=g)
     H, n = torch.zeros(K, K), 0
+    H, n = O.gptq_add_batch(H, n, x)  # untimed warm-up (thread pool, page faults)
     t0 = time.time()
-    for _ in range(2):
+    reps = 3
+    for _ in range(reps):
         H, n = O.gptq_add_batch(H, n, x)
-    t_add = (time.time() - t0) / 2
+    t_add = (time.time() - t0) / reps
     W = torch.randn(4096, K, generator=g) * 0.02
     t0 = time.time()
     O.gptq_fasterquant(W, H, bits=4, sym=True, blocksize=128, percdamp=0.01, groupsize=128)
     t_fq = time.time() - t0
+    print(json.dumps(dict(t_add=t_add, t_fq=t_fq)), flush=True)
+
+
+def cpu_baseline(timeout_s=240):
+    """The oracle (a restatement of the reference's CPU arithmetic) timed on this host's cores: a bounded sample of the
+    same workload (one [1,2048,4096] add_batch, one 4096x4096 fasterquant), extrapolated to the 32-block job (the full
+    CPU run is ~8 h).  Runs in a child process under a hard timeout so that a host with an
+    unusual CPU quota can never stall the bench line."""
+    import subprocess
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 32))  # torch's intra-op pool stops scaling on these shapes well before 32 threads
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench._cpu_baseline_worker({threads})"
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        m = json.loads(line)
+    except Exception as e:  # timeout / crash: report it, never fake a number
+        return dict(value=None, unit="s", cores=threads, kind="port", sample=f"CPU baseline failed or timed out after {timeout_s}s: {type(e).__name__}")
+    t_add, t_fq = m["t_add"], m["t_fq"]
     # per block as the reference does it (7 separate Hessians, gptq.py:670-688): 6 inputs of K=4096, 1 of K=11008
     r = (11008 / 4096) ** 2
     hess = 128 * (6 * t_add + r * t_add)
@@ -149,10 +174,10 @@ def cpu_baseline():
     solve = 4 * t_fq + 2 * t_fq * (11008 / 4096) + t_fq * (11008 / 4096) ** 2
     per_block = hess + solve
     return dict(
-        value=round(32 * per_block, 1), unit="s", cores=cores, kind="port",
-        sample=(f"oracle (CPU restatement of the reference) on this host: GPTQ.add_batch [1,2048,4096] fp32 = {t_add:.3f} s, "
-                f"GPTQ.fasterquant 4096x4096 g128 = {t_fq:.2f} s; extrapolated to 32 blocks x (128 samples x 7 Hessians "
-                f"+ 7 solves), block forwards excluded"),
+        value=round(32 * per_block, 1), unit="s", cores=threads, kind="port",
+        sample=(f"oracle (CPU restatement of the reference) on this host, {threads} threads: GPTQ.add_batch [1,2048,4096] fp32 = "
+                f"{t_add:.3f} s, GPTQ.fasterquant 4096x4096 g128 = {t_fq:.2f} s; extrapolated to 32 blocks x (128 samples x 7 "
+                f"Hessians + 7 solves), block forwards excluded"),
         add_batch_s=round(t_add, 4), fasterquant_s=round(t_fq, 3),
     )
 
@@ -168,6 +193,9 @@ def main():
     ap.add_argument("--no-gemm", action="store_true")
     args = ap.parse_args()
 
+    def note(msg):  # progress on stderr: the single JSON line on stdout stays clean
+        print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
     from neural_compressor_amd import distributed as D
     from neural_compressor_amd import ops
     from neural_compressor_amd.torch.quantization import GPTQConfig, prepare
@@ -178,6 +206,7 @@ def main():
     device = torch.device("cuda", local_rank)
 
     n_blocks = args.warmup + args.steps
+    note(f"building {n_blocks}-block Llama-2-7B-shaped model on {device}")
     model = build_model(n_blocks, device)
     g = torch.Generator().manual_seed(1)
     ids = [torch.randint(0, 32000, (1, args.seq), generator=g) for _ in range(args.samples)]
@@ -187,6 +216,7 @@ def main():
     with torch.no_grad():
         for x in ids:  # run_fn: embeddings only, block-0 inputs captured in HBM (gptq.py:413-433 semantics)
             model(x.to(device))
+    note("calibration inputs captured")
     rq = model.quantizer.gptq_quantizer
     rq.remove_prepare_for_calibration()
     blocks = rq.gptq_related_blocks["transformers"]
@@ -210,6 +240,8 @@ def main():
     with torch.no_grad():
         for i in range(args.warmup):
             one_step(i)
+            torch.cuda.synchronize()
+            note(f"warmup block {i} done")
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -222,6 +254,7 @@ def main():
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
         clock.enabled = False
+    note(f"timed region done: {elapsed:.2f}s for {args.steps} blocks")
     elapsed = D.barrier_max_time(elapsed, device=device)
     ms_per_step = elapsed * 1e3 / args.steps
     value = 32.0 * elapsed / (args.steps * world)
@@ -255,8 +288,10 @@ def main():
         del model, rq, blocks
         torch.cuda.empty_cache()
         result["dequant_gemm"] = bench_dequant_gemm(device, shapes)
+        note("dequant-GEMM shapes timed")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
+        note("cpu baseline done")
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

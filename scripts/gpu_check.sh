@@ -15,11 +15,11 @@ if [[ $what == tests || $what == all ]]; then
   tail -5 gpurun_out/smoke.log
 fi
 if [[ $what == bench || $what == all ]]; then
-  timeout 1200 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.log 2> gpurun_out/bench.err
+  timeout 480 python bench.py --steps 2 --warmup 1 > gpurun_out/bench.log 2> gpurun_out/bench.err
   echo "bench exit $?"; tail -3 gpurun_out/bench.log; tail -5 gpurun_out/bench.err
 fi
 if [[ $what == prof || $what == all ]]; then
-  ( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r1 -- python "$OLDPWD/bench.py" --steps 1 --warmup 1 --samples 32 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2> "$OLDPWD/gpurun_out/prof_bench.err" )
+  ( cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r1 -- python "$OLDPWD/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2> "$OLDPWD/gpurun_out/prof_bench.err" )
   echo "prof exit $?"
   find gpurun_out/prof -name "*stats*" | head
 fi
