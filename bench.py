@@ -268,7 +268,7 @@ def main():
         dom = max(hess, key=lambda k: hess[k]["total_ms"])
         v = hess[dom]
         achieved = v["work"] / (v["total_ms"] * 1e-3) / 1e12
-        roofline = dict(kernel=f"hessian_syrk_16bit_kernel<bf16> ({dom})", bound="mfma", achieved=round(achieved, 2),
+        roofline = dict(kernel=f"hessian_syrk_16bit_256_kernel<bf16> ({dom}; algorithmic flops 2*T*K^2 per launch)", bound="mfma", achieved=round(achieved, 2),
                         peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                         traffic=None, avg_launch_ms=round(v["avg_ms"], 4), launches=v["launches"])
 

@@ -45,6 +45,9 @@ int inc_abi_version(void);                 /* bumps on any signature change     
 const char* inc_error_string(int code);    /* static string for an INC_ERR_* code                */
 const char* inc_target_arch(void);         /* "gfx950"                                           */
 
+/* debug: != 0 routes inc_woq_gemm / inc_gptq_hessian_accum to the generic 128x128 tilings (A/B runs) */
+void inc_debug_set_small_tiles(int on);
+
 /* ---- K1/K2: bit packing ------------------------------------------------------------------- *
  * inc_pack_rows  == INCWeightOnlyLinear.pack_tensor   (weight_only/modules.py:580, :445, :546,
  *                   numba packers torch/utils/bit_packer.py:35-278):
@@ -107,8 +110,14 @@ int inc_dequant_ints(const int16_t* int_weight, const void* scales, int scale_dt
  *   bias [N] of `xdtype` or NULL.  bits in {4, 8}.  g_idx must be NULL in this ABI version
  *   (act_order checkpoints: inc_woq_dequant honours g_idx; the fused kernel returns
  *   INC_ERR_UNSUPPORTED so that a caller can never get a silently wrong product).
- *   The library picks the MFMA tile kernel (large M) or the split-K GEMV (M <= 16) itself;
- *   `workspace` (fp32, inc_woq_gemm_workspace_bytes) is only touched by the split-K path.
+ *   The library picks the kernel itself: 256x256x64 LDS-DMA tile kernel (4-bit, M >= 128, K % 64 == 0,
+ *   power-of-two group_size >= 32 or one group), split-K MFMA GEMV (M <= 16), or the generic 128x128
+ *   tile kernel for everything else.
+ *   `workspace` (inc_woq_gemm_workspace_bytes; 0 bytes when M > 16) is only touched when M <= 16:
+ *   its first 16 KiB hold the per-strip arrival counters of the in-kernel split-K reduction and MUST BE
+ *   ZERO when the workspace is first used (the last-arriving workgroup re-arms them, so a workspace that
+ *   is only ever handed to this function stays valid); the fp32 partials follow.  One workspace must not
+ *   be shared by calls that may run concurrently (different streams).
  */
 int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16_t* scales,

@@ -20,6 +20,7 @@ INC_SCHEME_ASYM, INC_SCHEME_SYM = 0, 1
 _P = c_void_p
 SIGNATURES = {
     "inc_abi_version": (c_int, []),
+    "inc_debug_set_small_tiles": (None, [c_int]),
     "inc_error_string": (c_char_p, [c_int]),
     "inc_target_arch": (c_char_p, []),
     "inc_pack_rows": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, _P]),

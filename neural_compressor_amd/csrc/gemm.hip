@@ -266,6 +266,270 @@ __global__ __launch_bounds__(256) void woq_gemm_tile_kernel(
 }
 
 // =============================================================================================
+// large-M fast path (4-bit, K % 64 == 0, group_size % 32 == 0): 256x256x64 workgroup tile
+// =============================================================================================
+// 512 threads = 8 waves as 2 (M) x 4 (N); a wave owns 128 (m) x 64 (n) = 4 x 2 MFMA 32x32x16 tiles
+// (128 fp32 accumulators).  One workgroup per CU (128 KiB LDS, two stages):
+//   x tile      256 rows x 128 B, brought in by LDS-DMA (global_load_lds_dwordx4): every DMA
+//               instruction moves 8 full 128-byte rows.  The LDS image is row-major with the 16-byte
+//               chunk index XOR-ed by ((row >> 1) & 7); the DMA destination is lane-linear, so the
+//               permutation is applied to the per-lane SOURCE address and again on the ds_read_b128
+//               side -> conflict-free fragment reads and full-line global reads.
+//   W tile      each thread fetches 4 packed words (4 packed rows of ONE column: the wave reads 256
+//               contiguous bytes per row), dequantises them once for the whole workgroup and writes
+//               the 4 x 16 B in MFMA-fragment order [n-frag][k16][lane] -> both the ds_write_b128 and
+//               the ds_read_b128 are lane-linear (conflict-free).
+// The MFMA is issued with W as the A operand and x as the B operand: a lane then owns 4 consecutive
+// output columns per accumulator quad -> 8-byte stores in the epilogue (4x fewer store instructions).
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int T_ASTAGE = TM * TK * 2;  // bytes
+constexpr int T_BSTAGE = TN * TK * 2;
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+template <bool IS_BF16>
+__device__ __forceinline__ uint32_t cvt_pair(float a, float b) {
+  f32x2 f = {a, b};
+  uint32_t r;
+  if constexpr (IS_BF16) {
+    bf16x2 h = __builtin_convertvector(f, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+    __builtin_memcpy(&r, &h, 4);
+  } else {
+    f16x2 h = __builtin_convertvector(f, f16x2);
+    __builtin_memcpy(&r, &h, 4);
+  }
+  return r;
+}
+
+// 8 nibbles of `w` -> 8 x rn16((q - z) * s), k-ordered, as 4 dwords.  fma(q, s, -z*s) is exact in
+// fp32 (q, z < 32 and s has 11 significant bits), so the single rounding is the 16-bit conversion.
+template <bool IS_BF16>
+__device__ __forceinline__ uint4 dequant8(uint32_t w, float s, float nzs) {
+  uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
+  asm volatile("" : "+v"(lo), "+v"(hi));  // keep the byte form: v_cvt_f32_ubyteN reads it directly
+  uint4 o;
+  o.x = cvt_pair<IS_BF16>(fmaf((float)(lo & 0xffu), s, nzs), fmaf((float)(hi & 0xffu), s, nzs));
+  o.y = cvt_pair<IS_BF16>(fmaf((float)((lo >> 8) & 0xffu), s, nzs), fmaf((float)((hi >> 8) & 0xffu), s, nzs));
+  o.z = cvt_pair<IS_BF16>(fmaf((float)((lo >> 16) & 0xffu), s, nzs), fmaf((float)((hi >> 16) & 0xffu), s, nzs));
+  o.w = cvt_pair<IS_BF16>(fmaf((float)(lo >> 24), s, nzs), fmaf((float)(hi >> 24), s, nzs));
+  return o;
+}
+
+// Four LDS-DMA instructions (1 KiB each) of one wave: LDS[lds_dst + i*1024 + lane*16] <- base[voff_i].
+// Issued from inline asm on purpose: hipcc orders every later ds_read behind a DMA it can see with
+// s_waitcnt vmcnt(0) (it cannot prove the two LDS stages disjoint), which would expose the whole HBM
+// latency in every K-step.  The DMA has no VGPR destination, so hiding it is register-safe; completion
+// is the explicit `s_waitcnt vmcnt(0)` + barrier at the end of the K-step (cdna_hip_programming.md 5.7).
+// M0 (LDS base of the DMA) is saved/restored; s_nop 4 covers a freshly written SGPR base, s_nop 0 the
+// M0 write -> LDS-DMA hazard.
+__device__ __forceinline__ void lds_dma_4x1k(const void* base, uint32_t lds_dst, uint32_t v0, uint32_t v1,
+                                             uint32_t v2, uint32_t v3) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_nop 4\n\t"
+      "s_mov_b32 m0, %6\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, %6, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, %6, 0x800\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, %5\n\t"
+      "s_add_u32 m0, %6, 0xc00\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %4, %5\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "s"(lds_dst)
+      : "memory", "scc");
+}
+
+template <bool IS_BF16>
+__global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
+    const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
+    const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int64_t M, int64_t N, int64_t K,
+    int64_t NW, int g_shift, int y_vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abase = smem;                 // 2 stages
+  char* const Bbase = smem + 2 * T_ASTAGE;  // 2 stages
+
+  const int tiles_n = (int)((N + TN - 1) / TN);
+  const int tiles_m = (int)((M + TM - 1) / TM);
+  const int nwg = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective XCD remap
+  }
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- x staging (LDS-DMA): instruction i of this wave fills LDS rows (wave*4+i)*8 .. +7 -------
+  uint32_t avoff[4];  // byte offset of this lane's 16-byte chunk from x + m0*K + kt*TK
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int R = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    int64_t row = m0 + R;
+    if (row > M - 1) row = M - 1;  // rows past M are computed from a valid row and never stored
+    avoff[i] = (uint32_t)(((row - m0) * K + 8 * c) * 2);
+  }
+  const uint16_t* const xtile = x + m0 * K;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;  // LDS byte address of the dynamic segment (low half of the flat address)
+  // ---- W staging: this thread's column and packed-row half ---------------------------------------
+  const int bcol = tid & 255, kwh = tid >> 8;
+  int64_t ncol = n0 + bcol;
+  if (ncol > N - 1) ncol = N - 1;
+  const uint32_t* wsrc = qweight + (int64_t)(4 * kwh) * N + ncol;
+  const int zshift = 4 * (int)(ncol & 7);
+  const int64_t zcol = ncol >> 3;
+  // LDS slot of word j: [nf = bcol>>5][kk = 2*kwh + (j>>1)][lane' = (bcol&31) + 32*(j&1)]
+  const int bdst0 = (((bcol >> 5) * 4 + 2 * kwh) * 64 + (bcol & 31)) * 16;
+
+  // this thread's share of the NEXT W tile, still packed (registers): 4 words + scale + zero word
+  uint32_t raw[4], zw;
+  uint16_t scb;
+  const int voff = (4 * kwh) * (int)N + (int)ncol;  // element offset inside a K-tile of qweight (fits 32 bits)
+  auto load_w = [&](int kt) {
+    const uint32_t* tile = qweight + (int64_t)kt * (TK / 8) * N;  // wave-uniform base
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = tile[voff + j * (int)N];
+    const int64_t g = g_shift >= 0 ? (((int64_t)kt * TK + 32 * kwh) >> g_shift) : 0;
+    scb = scales[g * N + ncol];
+    zw = qzeros[g * NW + zcol];
+  };
+  auto stash_regs = [&](int stage, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint16_t sb, uint32_t zword) {
+    const float sc = f16_bits_to_f32(sb);
+    uint32_t zz = ((zword >> zshift) & 15u) + 1u;  // modules.py:407-410 (stored zp-1; wraps above 15)
+    zz = zz > 15u ? 0u : zz;
+    const float nzs = -(float)zz * sc;
+    char* dst = Bbase + stage * T_BSTAGE + bdst0;
+    *reinterpret_cast<uint4*>(dst) = dequant8<IS_BF16>(w0, sc, nzs);                    // kk = 2*kwh,   k-octet 0
+    *reinterpret_cast<uint4*>(dst + 32 * 16) = dequant8<IS_BF16>(w1, sc, nzs);          //               k-octet 1
+    *reinterpret_cast<uint4*>(dst + 64 * 16) = dequant8<IS_BF16>(w2, sc, nzs);          // kk = 2*kwh+1, k-octet 0
+    *reinterpret_cast<uint4*>(dst + (64 + 32) * 16) = dequant8<IS_BF16>(w3, sc, nzs);   //               k-octet 1
+  };
+  auto stash_w = [&](int stage) { stash_regs(stage, raw[0], raw[1], raw[2], raw[3], scb, zw); };
+  auto dma_x = [&](int kt, int stage) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * T_ASTAGE + wave * 4096);
+    lds_dma_4x1k(xtile + (int64_t)kt * TK, dst, avoff[0], avoff[1], avoff[2], avoff[3]);
+  };
+  // makes the compiler's own wait for the packed-W registers happen HERE (before the next DMA is
+  // issued): its s_waitcnt accounting does not see the DMA and would otherwise drain it later
+  auto settle_w = [&]() {
+    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(zw));
+    uint32_t t = scb;
+    asm volatile("" : "+v"(t));
+    scb = (uint16_t)t;
+  };
+
+  f32x16 acc[2][4];  // [n-frag][m-frag]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment read offsets
+  const int a_row = wm * 128 + (lane & 31);         // + 32*mf
+  const int a_sw = ((lane & 31) >> 1) & 7;           // (row >> 1) & 7 (tile bases are multiples of 32)
+  const int a_hi = lane >> 5;                        // chunk = 2*kk + a_hi
+  const int b_off = (wn * 2 * 4 * 64 + lane) * 16;   // + (nf*4 + kk) * 1024
+
+  auto mma_step = [&](const char* As, const char* Bs, int kk) {
+    uint4 xa[4], wb[2];
+    const int chunk = ((2 * kk + a_hi) ^ a_sw) << 4;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) xa[mf] = *reinterpret_cast<const uint4*>(As + (a_row + 32 * mf) * 128 + chunk);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) wb[nf] = *reinterpret_cast<const uint4*>(Bs + (nf * 4 + kk) * 1024);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma32<IS_BF16>(wb[nf], xa[mf], acc[nf][mf]);
+  };
+
+  // Two-stage pipeline, one barrier per K-tile.  In iteration kt the LDS-DMA of x tile kt+1 and the
+  // packed loads of W tile kt+2 are issued first and land under the 32 MFMAs; the dequantisation of W
+  // tile kt+1 (registers -> other LDS stage) sits between the first and second MFMA group so that
+  // its VALU work shares the issue slots the matrix pipe leaves free.  vmcnt(0) only at the barrier.
+  const int nk = (int)(K / TK);
+  dma_x(0, 0);
+  load_w(0);
+  stash_w(0);
+  load_w(nk > 1 ? 1 : 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    const int cur = kt & 1;
+    const char* As = Abase + cur * T_ASTAGE;
+    const char* Bs = Bbase + cur * T_BSTAGE + b_off;
+    settle_w();
+    dma_x(kt + 1, cur ^ 1);
+    const uint32_t r0 = raw[0], r1 = raw[1], r2 = raw[2], r3 = raw[3], zcur = zw;
+    const uint16_t scur = scb;
+    load_w(kt + 2 < nk ? kt + 2 : nk - 1);   // in flight for the whole K-step
+    __builtin_amdgcn_sched_barrier(0);        // keep the loads up here (hipcc would sink them to their use)
+    mma_step(As, Bs, 0);
+    stash_regs(cur ^ 1, r0, r1, r2, r3, scur, zcur);
+    mma_step(As, Bs, 1);
+    mma_step(As, Bs, 2);
+    mma_step(As, Bs, 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  {
+    const int cur = (nk - 1) & 1;
+    const char* As = Abase + cur * T_ASTAGE;
+    const char* Bs = Bbase + cur * T_BSTAGE + b_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) mma_step(As, Bs, kk);
+  }
+
+  // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int64_t nb = n0 + wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (nb + e < N) bv[e] = cvt16<IS_BF16>(bias[nb + e]);
+      }
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
+        if (m >= M) continue;
+        const float v0 = acc[nf][mf][4 * rq + 0] + bv[0], v1 = acc[nf][mf][4 * rq + 1] + bv[1];
+        const float v2 = acc[nf][mf][4 * rq + 2] + bv[2], v3 = acc[nf][mf][4 * rq + 3] + bv[3];
+        uint16_t* dst = y + m * N + nb;
+        if (y_vec_ok && nb + 4 <= N) {
+          *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair<IS_BF16>(v0, v1), cvt_pair<IS_BF16>(v2, v3));
+        } else {
+          const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nb + e < N) dst[e] = IS_BF16 ? f32_to_bf16_bits(vv[e]) : f32_to_f16_bits(vv[e]);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // small-M (decode) kernel: M <= 16
 // =============================================================================================
 constexpr int SN = 64;  // columns per workgroup strip (16 lanes x 4 columns)
@@ -390,6 +654,153 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, const ui
   }
 }
 
+// =============================================================================================
+// small-M fast path (4-bit, M <= 16, K % 32 == 0, N % 4 == 0, group lookup by shift): HBM-bound
+// =============================================================================================
+// The whole packed matrix is only N*K/2 bytes (8 MiB at 4096^2), a few microseconds of HBM time, so the
+// kernel is built around memory-level parallelism: a wave owns 64 columns x 256 k and issues ALL of its
+// weight traffic (8 x 16 B per lane = 8 KiB per wave) before it touches any of it; 4 waves of a workgroup
+// take 4 consecutive k-ranges of the same 64-column strip (1024 k), grid = strips x K/1024 workgroups
+// (256 at 4096^2: one per CU).  x is the 16-row A operand of v_mfma_f32_16x16x32 (rows >= M zeroed), each
+// lane's 16-byte weight load is 4 adjacent columns = 4 B operands (output column 4*(lane&15)+c).
+// Reduction: the 4 waves add through LDS; across workgroups each writes its fp32 partial strip, then the
+// LAST workgroup to arrive on the strip's counter (agent-scope release / acquire, cdna_hip_programming.md
+// Guideline 16) sums the partials in a fixed order, adds the bias, converts and stores -> one launch,
+// deterministic.  The counters live in the caller's workspace, must be zero on entry and are returned to
+// zero by the last arriver.
+constexpr int VS = 8;   // MFMA K=32 steps per wave
+template <bool IS_BF16, bool G128>
+__global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
+    const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
+    float* __restrict__ partial, unsigned* __restrict__ counters, int M, int64_t N, int64_t K, int64_t NW,
+    int64_t G, int g_shift, int splitk) {
+  __shared__ float red[4 * 16 * 65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int strip = blockIdx.x, slice = blockIdx.y;
+  const int jn = lane & 15, oct = lane >> 4;
+  const int64_t n0 = (int64_t)strip * 64;
+  int64_t ncol = n0 + 4 * jn;
+  if (ncol > N - 4) ncol = N - 4;  // clamped lanes recompute valid columns; their results are not stored
+  const int steps_total = (int)(K / 32);
+  const int step0 = (slice * 4 + wave) * VS;
+
+  // ---- issue every load of this wave up front ---------------------------------------------------
+  uint4 w[VS], a[VS];
+  const int am = jn < M ? jn : M - 1;  // A row (clamped; rows >= M are zeroed below)
+#pragma unroll
+  for (int s = 0; s < VS; ++s) {
+    int st = step0 + s;
+    if (st > steps_total - 1) st = steps_total - 1;  // past-the-end steps re-read the last one and are zeroed via A
+    w[s] = *reinterpret_cast<const uint4*>(qweight + ((int64_t)st * 4 + oct) * N + ncol);
+    a[s] = *reinterpret_cast<const uint4*>(x + (int64_t)am * K + (int64_t)st * 32 + 8 * oct);
+  }
+  // group parameters: G128 -> the wave's 256 k span at most the two groups of its two 128-k halves
+  constexpr int NG = G128 ? 2 : VS;
+  uint2 sraw[NG];
+  uint32_t zraw[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    int st = step0 + (G128 ? 4 * i : i);
+    if (st > steps_total - 1) st = steps_total - 1;
+    const int64_t g = g_shift >= 0 ? (((int64_t)st * 32) >> g_shift) : 0;
+    sraw[i] = *reinterpret_cast<const uint2*>(scales + g * N + ncol);
+    zraw[i] = qzeros[g * NW + (ncol >> 3)];
+  }
+  const int zsh = 4 * (int)(ncol & 7);  // ncol % 4 == 0: the 4 zero nibbles sit at bits zsh .. zsh+15
+  // this thread's 4 outputs of the strip: idx = tid + 256*i -> row idx>>6, column idx&63; bias fetched now
+  uint16_t braw[4];
+  const uint16_t* const bsrc = bias ? bias : scales;  // always a valid address: the loads stay unconditional
+  bool out_ok[4];
+  int64_t out_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i, m = idx >> 6, c = idx & 63;
+    out_ok[i] = m < M && n0 + c < N;
+    out_off[i] = out_ok[i] ? (int64_t)m * N + n0 + c : 0;
+    braw[i] = bsrc[out_ok[i] ? n0 + c : 0];
+  }
+  __builtin_amdgcn_sched_barrier(0);  // everything above is in flight before the first use below
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool row_ok = jn < M;
+#pragma unroll
+  for (int s = 0; s < VS; ++s) {
+    const int gi = G128 ? (s >> 2) : s;
+    const bool live = row_ok && (step0 + s < steps_total);
+    uint4 av = a[s];
+    av.x = live ? av.x : 0u; av.y = live ? av.y : 0u; av.z = live ? av.z : 0u; av.w = live ? av.w : 0u;
+    const uint32_t sw[2] = {sraw[gi].x, sraw[gi].y};
+    const uint32_t ww[4] = {w[s].x, w[s].y, w[s].z, w[s].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float sc = f16_bits_to_f32((uint16_t)(sw[c >> 1] >> (16 * (c & 1))));
+      uint32_t zz = ((zraw[gi] >> (zsh + 4 * c)) & 15u) + 1u;
+      zz = zz > 15u ? 0u : zz;
+      const uint4 b = dequant8<IS_BF16>(ww[c], sc, -(float)zz * sc);
+      acc[c] = mfma16<IS_BF16>(av, b, acc[c]);
+    }
+  }
+  // ---- reduce the 4 waves: D col = lane&15 -> column 4*jn + c, row m = 4*oct + r ------------------
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * oct + r) * 65 + 4 * jn + c] = acc[c][r];
+  __syncthreads();
+  float sum[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i, m = idx >> 6, c = idx & 63;
+    sum[i] = red[(0 * 16 + m) * 65 + c] + red[(1 * 16 + m) * 65 + c] + red[(2 * 16 + m) * 65 + c] + red[(3 * 16 + m) * 65 + c];
+  }
+  if (splitk > 1) {
+    const int64_t slab = (int64_t)M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (out_ok[i]) partial[(int64_t)slice * slab + out_off[i]] = sum[i];
+    // publish: drain the stores of every wave, then one agent-scope release + ticket from lane 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned ticket = __hip_atomic_fetch_add(&counters[strip], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = ticket == (unsigned)(splitk - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&counters[strip], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
+      }
+      red[0] = last ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (red[0] == 0.f) return;
+    // last arriver: fixed-order sum over the slices, 4 slices x 4 outputs of loads in flight at a time
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum[i] = 0.f;
+    for (int sl0 = 0; sl0 < splitk; sl0 += 4) {
+      float pv[4][4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int sl = sl0 + d < splitk ? sl0 + d : splitk - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[d][i] = partial[(int64_t)sl * slab + out_off[i]];
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[i] += (sl0 + d < splitk) ? pv[d][i] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (out_ok[i]) {
+      const float v = sum[i] + (bias ? cvt16<IS_BF16>(braw[i]) : 0.f);
+      y[out_off[i]] = IS_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+    }
+}
+
 // choose the number of K-slices for the small-M kernel: enough workgroups to cover the chip, each
 // slice a multiple of 4 waves x one MFMA K=32 step
 inline int small_slices(int64_t N, int64_t K, int bits, int* kw_per_slice_out) {
@@ -413,10 +824,14 @@ inline int small_slices(int64_t N, int64_t K, int bits, int* kw_per_slice_out) {
 
 extern "C" {
 
+// workspace layout (M <= 16 only): [0, 16 KiB) arrival counters of the fast GEMV (uint32 per 64-column
+// strip; MUST be zero on first use, the kernel re-arms them), then fp32 split-K partials.
+constexpr int64_t WS_COUNTER_BYTES = 16384;
 int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M > 16) return 0;
-  (void)K;
-  return (int64_t)64 * M * N * 4;  // <= 64 K-slices of fp32 partials
+  int64_t slices = ceil_div64(K, 32 * VS * 4);
+  if (slices < 64) slices = 64;  // the generic split-K path uses up to 64 slices
+  return WS_COUNTER_BYTES + slices * M * N * 4;
 }
 
 int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16_t* scales,
@@ -439,7 +854,25 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   const uint16_t* bp = (const uint16_t*)bias;
   uint16_t* yp = (uint16_t*)y;
   const bool bf = xdtype == INC_BF16;
-  if (M > 16) {
+  // group lookup by shift: group_size a power of two >= 32, or a single group (group_size >= K)
+  int g_shift = -2;
+  if (group_size >= K) g_shift = -1;
+  else if (group_size >= 32 && (group_size & (group_size - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < group_size) ++g_shift; }
+  const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M >= 128 && N >= 64 &&
+                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
+  if (big_ok && !inc_force_small_tiles()) {
+    const size_t smem = (size_t)2 * T_ASTAGE + 2 * T_BSTAGE;  // 128 KiB
+    static bool big_attr_set = false;
+    if (!big_attr_set) {
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      big_attr_set = true;
+    }
+    const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
+    const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
+    if (bf) woq_gemm_w4_big_kernel<true><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+    else woq_gemm_w4_big_kernel<false><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+  } else if (M > 16) {
     const int x_vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const size_t smem = (size_t)2 * 2 * GM * GP * sizeof(uint16_t);
     static bool attr_set = false;
@@ -455,11 +888,23 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     if (bits == 4) { if (bf) INC_TILE(4, true); else INC_TILE(4, false); }
     else { if (bf) INC_TILE(8, true); else INC_TILE(8, false); }
 #undef INC_TILE
+  } else if (bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && ceil_div64(N, 64) * 4 <= WS_COUNTER_BYTES &&
+             (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !inc_force_small_tiles()) {
+    const int splitk = (int)ceil_div64(K, 32 * VS * 4);
+    if (!workspace || workspace_bytes < WS_COUNTER_BYTES + (int64_t)splitk * M * N * 4) return INC_ERR_WORKSPACE;
+    unsigned* counters = (unsigned*)workspace;
+    float* part = (float*)((char*)workspace + WS_COUNTER_BYTES);
+    dim3 grid((unsigned)ceil_div64(N, 64), (unsigned)splitk);
+    const bool g128 = g_shift == -1 || g_shift >= 7;
+#define INC_GEMV(F, GG) woq_gemv_w4_kernel<F, GG><<<grid, 256, 0, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, G, g_shift, splitk)
+    if (bf) { if (g128) INC_GEMV(true, true); else INC_GEMV(true, false); }
+    else { if (g128) INC_GEMV(false, true); else INC_GEMV(false, false); }
+#undef INC_GEMV
   } else {
     int kw_per_slice = 0;
     const int slices = small_slices(N, K, bits, &kw_per_slice);
-    if (!workspace || workspace_bytes < (int64_t)slices * M * N * 4) return INC_ERR_WORKSPACE;
-    float* part = (float*)workspace;
+    if (!workspace || workspace_bytes < WS_COUNTER_BYTES + (int64_t)slices * M * N * 4) return INC_ERR_WORKSPACE;
+    float* part = (float*)((char*)workspace + WS_COUNTER_BYTES);
     dim3 grid((unsigned)ceil_div64(N, SN), (unsigned)slices);
 #define INC_SMALL(B, F) woq_gemm_small_kernel<B, F><<<grid, 256, 0, s>>>(xp, qw, scales, qz, g_idx, part, M, N, K, KW, NW, group_size, kw_per_slice)
     if (bits == 4) { if (bf) INC_SMALL(4, true); else INC_SMALL(4, false); }

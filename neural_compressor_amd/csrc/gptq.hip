@@ -169,6 +169,144 @@ __global__ __launch_bounds__(256) void hessian_syrk_16bit_kernel(const uint16_t*
     }
 }
 
+// ---- 16-bit inputs, 256x256 tile of H per workgroup (K >= 256) --------------------------------------
+// 512 threads = 8 waves as 2 (i) x 4 (j); a wave owns 128 x 64 of H = 4 x 2 MFMA 32x32x16 tiles.
+// Per 64-token step each thread fetches ONE 8(token) x 8(feature) block (eight 16-byte loads, the wave
+// covers 8 full 128-byte row segments per load), transposes it with 32 v_perm_b32 and writes eight
+// 16-byte [feature][8 tokens] rows.  LDS rows are [feature][64 tokens + 8 pad] (144 B pitch): the
+// 8-lane ds_write_b128 groups write one contiguous 128-byte row, and the ds_read_b128 fragment reads
+// (rows lane&31, pitch 9 x 16 B) hit 16 distinct bank slots per lane group -> both conflict-free.
+// Software pipeline: the block for step s+1 is fetched during step s-1/s, transposed and written to the
+// other LDS stage between the first and second MFMA group of step s; one barrier per step.
+constexpr int H2 = 256;
+constexpr int H2_OPER = H2 * HPITCH;       // elements per operand per stage
+constexpr int H2_STAGE = 2 * H2_OPER;      // elements per stage
+
+__device__ __forceinline__ void store_block_transposed_perm(uint16_t* lds, const uint4 (&r)[8]) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&r[0]);  // w[token*4 + m]: features 2m, 2m+1 of that token
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t a = w[(2 * p) * 4 + m], b = w[(2 * p + 1) * 4 + m];  // tokens 2p, 2p+1
+      lo[p] = __builtin_amdgcn_perm(b, a, 0x05040100u);  // [a.lo16, b.lo16]: feature 2m,   tokens 2p, 2p+1
+      hi[p] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // [a.hi16, b.hi16]: feature 2m+1
+    }
+    *reinterpret_cast<uint4*>(lds + (2 * m) * HPITCH) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<uint4*>(lds + (2 * m + 1) * HPITCH) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  }
+}
+
+// branch-free fetch of one 8(token) x 8(feature) block: addresses are clamped into the tensor (features
+// past K only feed rows/columns of H that are never stored; tokens past T are zeroed when TAIL)
+template <bool TAIL>
+__device__ __forceinline__ void load_block8x8_fast(const uint16_t* __restrict__ xf, int64_t T, int64_t ldx,
+                                                   int64_t t0, uint4 (&r)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int64_t t = t0 + i;
+    const bool ok = t < T;
+    if (TAIL && !ok) t = T - 1;
+    uint4 v = *reinterpret_cast<const uint4*>(xf + t * ldx);
+    if (TAIL) {
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+    }
+    r[i] = v;
+  }
+}
+
+template <bool IS_BF16, bool TAIL>
+__global__ __launch_bounds__(512) void hessian_syrk_16bit_256_kernel(const uint16_t* __restrict__ x, int64_t T,
+                                                                     int64_t K, int64_t ldx, float* __restrict__ H,
+                                                                     float beta, float alpha, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint16_t* smem = reinterpret_cast<uint16_t*>(smem_raw);
+  int ti, tj;
+  tri_decode(blockIdx.x, nt, ti, tj);
+  const int64_t i0 = (int64_t)ti * H2, j0 = (int64_t)tj * H2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  // staging role: threads 0..255 fetch the i tile, 256..511 the j tile
+  const int oper = tid >> 8, tt = tid & 255;
+  const int t_chunk = tt & 7, f_chunk = tt >> 3;
+  int64_t fbase = (oper == 0 ? i0 : j0) + f_chunk * 8;
+  if (fbase > K - 8) fbase = K - 8;  // K % 8 == 0 on this path: the chunk is entirely outside -> clamp (results unused)
+  const uint16_t* const xf = x + fbase;
+  uint16_t* const wr_base = smem + oper * H2_OPER + (f_chunk * 8) * HPITCH + t_chunk * 8;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (int)((T + HK - 1) / HK);
+  uint4 regs[8];
+  load_block8x8_fast<TAIL>(xf, T, ldx, (int64_t)t_chunk * 8, regs);
+  store_block_transposed_perm(wr_base, regs);
+  load_block8x8_fast<true>(xf, T, ldx, (int64_t)HK + t_chunk * 8, regs);  // all-zero when there is no step 1
+  __syncthreads();
+
+  const int frag_off = (lane & 31) * HPITCH + 8 * (lane >> 5);
+  auto mma_step = [&](const uint16_t* As, const uint16_t* Bs, int kk) {
+    uint4 a[4], b[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const uint4*>(As + (m * 32) * HPITCH + frag_off + kk * 16);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const uint4*>(Bs + (n * 32) * HPITCH + frag_off + kk * 16);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = mfma16<IS_BF16>(a[m], b[n], acc[m][n]);
+  };
+
+  // steady state: no branches inside the step (the last two steps are peeled)
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) {
+    const int cur = kt & 1;
+    const uint16_t* As = smem + cur * H2_STAGE + (wm * 128) * HPITCH;
+    const uint16_t* Bs = smem + cur * H2_STAGE + H2_OPER + (wn * 64) * HPITCH;
+    mma_step(As, Bs, 0);
+    store_block_transposed_perm(wr_base + (cur ^ 1) * H2_STAGE, regs);
+    load_block8x8_fast<TAIL>(xf, T, ldx, (int64_t)(kt + 2) * HK + t_chunk * 8, regs);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetch up here: hipcc would sink it next to its use
+    mma_step(As, Bs, 1);
+    mma_step(As, Bs, 2);
+    mma_step(As, Bs, 3);
+    __syncthreads();
+  }
+  for (; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const uint16_t* As = smem + cur * H2_STAGE + (wm * 128) * HPITCH;
+    const uint16_t* Bs = smem + cur * H2_STAGE + H2_OPER + (wn * 64) * HPITCH;
+    mma_step(As, Bs, 0);
+    if (kt + 1 < nk) store_block_transposed_perm(wr_base + (cur ^ 1) * H2_STAGE, regs);
+    mma_step(As, Bs, 1);
+    mma_step(As, Bs, 2);
+    mma_step(As, Bs, 3);
+    __syncthreads();
+  }
+
+  // epilogue: D[row i][col j], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); 128-byte runs along j
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int64_t col = j0 + wn * 64 + n * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < K && col < K) {
+          float* p = H + row * K + col;
+          *p = beta * (*p) + alpha * acc[m][n][r];
+        }
+      }
+    }
+}
+
 // ---- fp32 inputs: exact fp32 MFMA 32x32x2 ------------------------------------------------------
 constexpr int FK = 32;  // tokens per step
 __global__ __launch_bounds__(256) void hessian_syrk_f32_kernel(const float* __restrict__ x, int64_t T,
@@ -465,7 +603,25 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
       (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_set = true;
     }
-    if (xdtype == INC_BF16)
+    if (K >= H2 && vec_ok && (K % 8) == 0 && !inc_force_small_tiles()) {
+      const int nt2 = (int)ceil_div64(K, H2);
+      const int ntiles2 = nt2 * (nt2 + 1) / 2;
+      const size_t smem2 = (size_t)2 * H2_STAGE * sizeof(uint16_t);  // 144 KiB
+      static bool attr2_set = false;
+      if (!attr2_set) {
+        (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+        (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+        (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+        (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+        attr2_set = true;
+      }
+      const uint16_t* xp = (const uint16_t*)x;
+      const bool tail = (T % HK) != 0;
+#define INC_H2(B, TL) hessian_syrk_16bit_256_kernel<B, TL><<<ntiles2, 512, smem2, s>>>(xp, T, K, ldx, H, beta, alpha, nt2)
+      if (xdtype == INC_BF16) { if (tail) INC_H2(true, true); else INC_H2(true, false); }
+      else { if (tail) INC_H2(false, true); else INC_H2(false, false); }
+#undef INC_H2
+    } else if (xdtype == INC_BF16)
       hessian_syrk_16bit_kernel<true><<<ntiles, 256, smem, s>>>((const uint16_t*)x, T, K, ldx, H, beta, alpha, nt, vec_ok);
     else
       hessian_syrk_16bit_kernel<false><<<ntiles, 256, smem, s>>>((const uint16_t*)x, T, K, ldx, H, beta, alpha, nt, vec_ok);

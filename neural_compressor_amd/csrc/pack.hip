@@ -331,7 +331,16 @@ inline int grid_1d(int64_t total, int block = 256) {
 
 }  // namespace
 
+#include <stdlib.h>
+int inc_small_tiles_flag(int set_to) {
+  static int v = [] { const char* e = getenv("INC_MI355X_SMALL_TILES"); return (e && e[0] == '1') ? 1 : 0; }();
+  if (set_to >= 0) v = set_to;
+  return v;
+}
+
 extern "C" {
+void inc_debug_set_small_tiles(int on) { (void)inc_small_tiles_flag(on ? 1 : 0); }
+
 
 int inc_abi_version(void) { return 1; }
 const char* inc_target_arch(void) { return "gfx950"; }

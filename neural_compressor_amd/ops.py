@@ -178,7 +178,9 @@ def _workspace(dev, nbytes):
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        # zero-filled: the first 16 KiB are the split-K arrival counters of the M <= 16 kernel, which must be zero on
+        # first use (the kernel re-arms them); one workspace per (device, stream) so concurrent streams never share them
+        buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
         _ws_cache[key] = buf
     return buf
 

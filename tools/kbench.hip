@@ -1,0 +1,374 @@
+// tools/kbench.hip -- kernel-level check + timing harness over the C-ABI (no Python, no torch: starts in
+// milliseconds on a fresh GPU box).  Build: make -C tools.  Run: tools/kbench [gemm|gemv|hessian|probe|all]
+//
+// Everything here is test infrastructure: the references are a naive fp32 kernel and the library's own
+// first-generation tilings (which the pytest suite pins against the oracle).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../include/inc_mi355x.h"
+
+#define HIPCHECK(x)                                                                      \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                           \
+    }                                                                                    \
+  } while (0)
+#define INCCHECK(x)                                                                \
+  do {                                                                             \
+    int r_ = (x);                                                                  \
+    if (r_ != INC_OK) {                                                            \
+      fprintf(stderr, "INC error %d (%s) at %s:%d\n", r_, inc_error_string(r_), __FILE__, __LINE__); \
+      exit(3);                                                                     \
+    }                                                                              \
+  } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint32_t rnd() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 7;
+  rng_state ^= rng_state << 17;
+  return (uint32_t)(rng_state >> 32);
+}
+static inline float rnd_normal() {  // sum of 4 uniforms, unit variance, zero mean
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) s += (float)(rnd() & 0xffffff) / 16777216.f - 0.5f;
+  return s * 1.7320508f;
+}
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline uint16_t f2h(float f) {
+  _Float16 h = (_Float16)f;
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  return b;
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  explicit DevBuf(size_t n_) : n(n_) { HIPCHECK(hipMalloc(&p, n * sizeof(T))); }
+  ~DevBuf() { (void)hipFree(p); }
+  void upload(const std::vector<T>& h) { HIPCHECK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice)); }
+  std::vector<T> download() const {
+    std::vector<T> h(n);
+    HIPCHECK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+  void zero() { HIPCHECK(hipMemset(p, 0, n * sizeof(T))); }
+};
+
+// y_ref[m, n] = sum_k x[m,k] * w[n,k] in fp32 (bf16 inputs), rows listed in `rows`
+__global__ void ref_gemm_rows(const uint16_t* x, const uint16_t* w, const int* rows, int nrows, int64_t N, int64_t K,
+                              float* out) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (n >= N || r >= nrows) return;
+  const uint16_t* xr = x + (int64_t)rows[r] * K;
+  const uint16_t* wr = w + n * K;
+  float acc = 0.f;
+  for (int64_t k = 0; k < K; ++k)
+    acc += __uint_as_float((uint32_t)xr[k] << 16) * __uint_as_float((uint32_t)wr[k] << 16);
+  out[(int64_t)r * N + n] = acc;
+}
+
+// H_ref[i, j] = sum_t x[t,i] x[t,j] for sampled (i, j)
+__global__ void ref_hessian_samples(const uint16_t* x, int64_t T, int64_t K, const int* ii, const int* jj, int ns,
+                                    double* out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  double acc = 0.0;
+  for (int64_t t = 0; t < T; ++t)
+    acc += (double)__uint_as_float((uint32_t)x[t * K + ii[s]] << 16) * (double)__uint_as_float((uint32_t)x[t * K + jj[s]] << 16);
+  out[s] = acc;
+}
+
+struct Timer {
+  hipEvent_t a, b;
+  Timer() { HIPCHECK(hipEventCreate(&a)); HIPCHECK(hipEventCreate(&b)); }
+  void start() { HIPCHECK(hipEventRecord(a, 0)); }
+  float stop_ms() {
+    HIPCHECK(hipEventRecord(b, 0));
+    HIPCHECK(hipEventSynchronize(b));
+    float ms;
+    HIPCHECK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+  }
+};
+
+struct Packed {
+  int64_t N, K, G;
+  int gs;
+  DevBuf<int32_t> qweight, qzeros;
+  DevBuf<uint16_t> scales;
+  Packed(int64_t N_, int64_t K_, int gs_, bool sym)
+      : N(N_), K(K_), G((K_ + gs_ - 1) / gs_), gs(gs_), qweight((size_t)(K_ / 8) * N_), qzeros((size_t)((K_ + gs_ - 1) / gs_) * ((N_ + 7) / 8)),
+        scales((size_t)((K_ + gs_ - 1) / gs_) * N_) {
+    std::vector<int32_t> qw(qweight.n), qz(qzeros.n);
+    std::vector<uint16_t> sc(scales.n);
+    for (auto& v : qw) v = (int32_t)rnd();
+    for (auto& v : qz) v = sym ? 0x77777777 : (int32_t)rnd();
+    for (auto& v : sc) v = f2h(0.004f + 0.004f * ((rnd() & 0xffff) / 65536.f));
+    qweight.upload(qw);
+    qzeros.upload(qz);
+    scales.upload(sc);
+  }
+};
+
+static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool with_bias, bool time_it, int check_rows) {
+  Packed W(N, K, gs, sym);
+  DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N), y_old((size_t)M * N), dense((size_t)N * K), bias((size_t)N);
+  {
+    std::vector<uint16_t> hx(x.n), hb(N);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    for (auto& v : hb) v = f2bf(rnd_normal());
+    x.upload(hx);
+    bias.upload(hb);
+  }
+  const int64_t wsb = inc_woq_gemm_workspace_bytes(M, N, K);
+  DevBuf<char> ws((size_t)(wsb > 0 ? wsb : 16));
+  ws.zero();
+  const void* bp = with_bias ? bias.p : nullptr;
+  inc_debug_set_small_tiles(0);
+  INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+  HIPCHECK(hipDeviceSynchronize());
+  inc_debug_set_small_tiles(1);
+  INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y_old.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+  HIPCHECK(hipDeviceSynchronize());
+  inc_debug_set_small_tiles(0);
+  // (1) full coverage: new tiling vs first-generation tiling (same arithmetic, different fp32 summation order)
+  std::vector<uint16_t> hy = y.download(), hyo = y_old.download();
+  double num = 0, den = 0;
+  int64_t big = 0;
+  for (size_t i = 0; i < hy.size(); ++i) {
+    const double a = bf2f(hy[i]), b = bf2f(hyo[i]);
+    num += (a - b) * (a - b);
+    den += b * b;
+    if (fabs(a - b) > 0.02 * (fabs(b) + 1.0)) ++big;
+  }
+  const double rel_old = sqrt(num / (den + 1e-30));
+  // (2) sampled rows vs a naive fp32 GEMM over the library's own dequantised (bf16) weight
+  INCCHECK(inc_woq_dequant(W.qweight.p, W.scales.p, W.qzeros.p, nullptr, dense.p, INC_BF16, N, K, W.G, gs, 4, nullptr));
+  std::vector<int> rows;
+  for (int r = 0; r < check_rows; ++r) rows.push_back((int)(((int64_t)r * 7919) % M));
+  rows[0] = 0;
+  rows[check_rows - 1] = (int)(M - 1);
+  DevBuf<int> drows(rows.size());
+  drows.upload(rows);
+  DevBuf<float> ref((size_t)check_rows * N);
+  ref_gemm_rows<<<dim3((unsigned)((N + 255) / 256), (unsigned)check_rows), 256>>>(x.p, dense.p, drows.p, check_rows, N, K, ref.p);
+  HIPCHECK(hipDeviceSynchronize());
+  std::vector<float> href = ref.download();
+  std::vector<uint16_t> hb = bias.download();
+  double num2 = 0, den2 = 0, maxabs = 0;
+  for (int r = 0; r < check_rows; ++r)
+    for (int64_t n = 0; n < N; ++n) {
+      const double b = href[(size_t)r * N + n] + (with_bias ? bf2f(hb[n]) : 0.f);
+      const double a = bf2f(hy[(size_t)rows[r] * N + n]);
+      num2 += (a - b) * (a - b);
+      den2 += b * b;
+      if (fabs(a - b) > maxabs) maxabs = fabs(a - b);
+    }
+  const double rel_ref = sqrt(num2 / (den2 + 1e-30));
+  const bool ok = rel_old < 3e-3 && rel_ref < 3e-3 && big == 0;
+  printf("GEMM M=%ld N=%ld K=%ld gs=%d %s%s: rel(new vs old tiling)=%.2e outliers=%ld rel(new vs fp32 ref, %d rows)=%.2e maxabs=%.3g  %s\n",
+         (long)M, (long)N, (long)K, gs, sym ? "sym" : "asym", with_bias ? "+bias" : "", rel_old, (long)big, check_rows, rel_ref, maxabs,
+         ok ? "OK" : "FAIL");
+  if (time_it) {
+    Timer t;
+    for (int mode = 0; mode < 2; ++mode) {
+      inc_debug_set_small_tiles(mode);
+      for (int i = 0; i < 3; ++i)
+        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+      const int iters = M <= 16 ? 200 : 20;
+      t.start();
+      for (int i = 0; i < iters; ++i)
+        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+      const float ms = t.stop_ms() / iters;
+      const double flops = 2.0 * M * N * K;
+      const double bytes = (double)N * K / 2 + (double)W.G * N * 2 + (double)W.G * (N / 8) * 4 + (double)M * K * 2 + (double)M * N * 2;
+      printf("  %-22s %9.4f ms  %8.1f TFLOP/s  %8.1f GB/s\n", mode ? "first-gen tiling" : "fast path", ms, flops / ms / 1e9, bytes / ms / 1e6);
+    }
+    inc_debug_set_small_tiles(0);
+  }
+  return ok ? 0 : 1;
+}
+
+static int run_gemv_repeat(int64_t N, int64_t K, int M) {
+  // the arrival counters must re-arm: 50 back-to-back calls on one workspace give bit-identical outputs
+  Packed W(N, K, 128, true);
+  DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
+  std::vector<uint16_t> hx(x.n);
+  for (auto& v : hx) v = f2bf(rnd_normal());
+  x.upload(hx);
+  const int64_t wsb = inc_woq_gemm_workspace_bytes(M, N, K);
+  DevBuf<char> ws((size_t)wsb);
+  ws.zero();
+  std::vector<uint16_t> first;
+  int bad = 0;
+  for (int it = 0; it < 50; ++it) {
+    INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, ws.p, wsb, nullptr));
+    std::vector<uint16_t> hy = y.download();
+    if (it == 0) first = hy;
+    else if (memcmp(first.data(), hy.data(), hy.size() * 2) != 0) ++bad;
+  }
+  printf("GEMV repeat M=%d N=%ld K=%ld: %d of 49 repeats differ from the first call  %s\n", M, (long)N, (long)K, bad, bad ? "FAIL" : "OK");
+  return bad ? 1 : 0;
+}
+
+static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
+  DevBuf<uint16_t> x((size_t)T * K);
+  {
+    std::vector<uint16_t> hx(x.n);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    x.upload(hx);
+  }
+  DevBuf<float> H((size_t)K * K), Hold((size_t)K * K);
+  H.zero();
+  Hold.zero();
+  inc_debug_set_small_tiles(0);
+  INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.f, 1.f, nullptr));
+  INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.25f, nullptr));  // exercises beta/alpha
+  inc_debug_set_small_tiles(1);
+  INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, Hold.p, 0.f, 1.f, nullptr));
+  INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, Hold.p, 0.5f, 0.25f, nullptr));
+  inc_debug_set_small_tiles(0);
+  HIPCHECK(hipDeviceSynchronize());
+  std::vector<float> h = H.download(), ho = Hold.download();
+  double num = 0, den = 0;
+  int64_t differ = 0;
+  for (int64_t i = 0; i < K; ++i)
+    for (int64_t j = i; j < K; ++j) {  // upper triangle only (syrk contract)
+      const double a = h[i * K + j], b = ho[i * K + j];
+      num += (a - b) * (a - b);
+      den += b * b;
+      if (a != b) ++differ;
+    }
+  const double rel = sqrt(num / (den + 1e-30));
+  // sampled entries vs fp64
+  const int ns = 256;
+  std::vector<int> ii(ns), jj(ns);
+  for (int s = 0; s < ns; ++s) {
+    int a = (int)(rnd() % K), b = (int)(rnd() % K);
+    if (a > b) { int t = a; a = b; b = t; }
+    if (s < 8) { a = b = (int)((K - 1) * s / 7); }
+    ii[s] = a; jj[s] = b;
+  }
+  DevBuf<int> dii(ns), djj(ns);
+  dii.upload(ii); djj.upload(jj);
+  DevBuf<double> dref(ns);
+  ref_hessian_samples<<<(ns + 63) / 64, 64>>>(x.p, T, K, dii.p, djj.p, ns, dref.p);
+  HIPCHECK(hipDeviceSynchronize());
+  std::vector<double> r = dref.download();
+  double maxrel = 0;
+  for (int s = 0; s < ns; ++s) {
+    const double want = 0.75 * r[s];  // 0.5*(1*S) + 0.25*S
+    const double got = h[(int64_t)ii[s] * K + jj[s]];
+    const double e = fabs(got - want) / (fabs(want) + 1e-3 * sqrt((double)T));
+    if (e > maxrel) maxrel = e;
+  }
+  const bool ok = rel < 1e-5 && maxrel < 1e-3;
+  printf("HESSIAN T=%ld K=%ld: rel(256-tile vs 128-tile)=%.2e (%ld entries differ) max rel err vs fp64 on %d samples=%.2e  %s\n", (long)T,
+         (long)K, rel, (long)differ, ns, maxrel, ok ? "OK" : "FAIL");
+  if (time_it) {
+    Timer t;
+    for (int mode = 0; mode < 2; ++mode) {
+      inc_debug_set_small_tiles(mode);
+      for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
+      const int iters = 10;
+      t.start();
+      for (int i = 0; i < iters; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
+      const float ms = t.stop_ms() / iters;
+      printf("  %-22s %9.4f ms  %8.1f TFLOP/s (2*T*K^2 convention)\n", mode ? "128x128 tiles" : "256x256 tiles", ms, 2.0 * T * K * K / ms / 1e9);
+    }
+    inc_debug_set_small_tiles(0);
+  }
+  return ok ? 0 : 1;
+}
+
+// ---- ds_read_b64_tr_b16 probe: which LDS halfwords does lane l receive? ----------------------------
+__global__ void probe_tr(uint32_t* out, int addr_mode) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (uint16_t)i;
+  __syncthreads();
+  const int lane = threadIdx.x;
+  // addr_mode 0: lane*8 bytes (every lane its own 4-halfword chunk, contiguous)
+  // addr_mode 1: row-major [rows of 64 halfwords]: lane -> row (lane&15)... 128-byte pitch: (lane&15)*128 + (lane>>4)*8
+  uint32_t addr = addr_mode == 0 ? lane * 8 : ((lane & 15) * 128 + (lane >> 4) * 8);
+  addr += (uint32_t)(uintptr_t)lds;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  out[lane * 2] = v.x;
+  out[lane * 2 + 1] = v.y;
+}
+static void run_probe() {
+  DevBuf<uint32_t> out(128);
+  for (int mode = 0; mode < 2; ++mode) {
+    probe_tr<<<1, 64>>>(out.p, mode);
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<uint32_t> h = out.download();
+    printf("PROBE ds_read_b64_tr_b16 addr_mode=%d (value = LDS halfword index; mode0 addr=lane*8B, mode1 addr=(lane&15)*128B+(lane>>4)*8B)\n", mode);
+    for (int l = 0; l < 64; ++l) {
+      printf("  lane %2d: %4u %4u %4u %4u", l, h[2 * l] & 0xffff, h[2 * l] >> 16, h[2 * l + 1] & 0xffff, h[2 * l + 1] >> 16);
+      if (l % 2 == 1) printf("\n");
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  const std::string what = argc > 1 ? argv[1] : "all";
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s, %d CUs, %s, ABI %d\n", prop.name, prop.multiProcessorCount, prop.gcnArchName, inc_abi_version());
+  int fails = 0;
+  if (what == "gemm" || what == "all") {
+    fails += run_gemm_case(256, 256, 64, 32, false, true, false, 64);     // one tile, one K-step, gs=32 asym
+    fails += run_gemm_case(300, 1000, 192, 64, false, true, false, 64);   // ragged M and N
+    fails += run_gemm_case(1024, 768, 1024, 1024, true, false, false, 64);  // single group (g_shift = -1)
+    fails += run_gemm_case(4096, 4096, 4096, 128, true, false, true, 64);
+    fails += run_gemm_case(4096, 11008, 4096, 128, true, false, true, 32);
+    fails += run_gemm_case(4096, 4096, 11008, 128, true, false, true, 32);
+    fails += run_gemm_case(8192, 4096, 4096, 128, false, true, true, 32);
+    fails += run_gemm_case(512, 4096, 4096, 128, true, false, true, 64);
+    fails += run_gemm_case(128, 4096, 4096, 128, true, false, true, 64);
+  }
+  if (what == "gemv" || what == "all") {
+    fails += run_gemm_case(1, 4096, 4096, 128, true, false, true, 1);
+    fails += run_gemm_case(16, 4096, 4096, 128, false, true, true, 16);
+    fails += run_gemm_case(4, 11008, 4096, 128, true, false, true, 4);
+    fails += run_gemm_case(8, 4096, 11008, 128, true, true, true, 8);
+    fails += run_gemm_case(3, 1000, 416, 32, false, true, false, 3);   // ragged N, K tail of the split, gs=32
+    fails += run_gemv_repeat(4096, 4096, 1);
+    fails += run_gemv_repeat(4096, 11008, 16);
+  }
+  if (what == "hessian" || what == "all") {
+    fails += run_hessian_case(200, 320, false);     // token tail + ragged feature tile
+    fails += run_hessian_case(2048, 4096, true);
+    fails += run_hessian_case(2048, 11008, true);
+    fails += run_hessian_case(16384, 4096, true);
+  }
+  if (what == "probe" || what == "all") run_probe();
+  printf("kbench: %d failing case(s)\n", fails);
+  return fails ? 1 : 0;
+}
