@@ -317,37 +317,6 @@ __device__ __forceinline__ uint4 dequant8(uint32_t w, float s, float nzs) {
   return o;
 }
 
-// Four LDS-DMA instructions (1 KiB each) of one wave: LDS[lds_dst + i*1024 + lane*16] <- base[voff_i].
-// Issued from inline asm on purpose: hipcc orders every later ds_read behind a DMA it can see with
-// s_waitcnt vmcnt(0) (it cannot prove the two LDS stages disjoint), which would expose the whole HBM
-// latency in every K-step.  The DMA has no VGPR destination, so hiding it is register-safe; completion
-// is the explicit `s_waitcnt vmcnt(0)` + barrier at the end of the K-step (cdna_hip_programming.md 5.7).
-// M0 (LDS base of the DMA) is saved/restored; s_nop 4 covers a freshly written SGPR base, s_nop 0 the
-// M0 write -> LDS-DMA hazard.
-__device__ __forceinline__ void lds_dma_4x1k(const void* base, uint32_t lds_dst, uint32_t v0, uint32_t v1,
-                                             uint32_t v2, uint32_t v3) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_nop 4\n\t"
-      "s_mov_b32 m0, %6\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %5\n\t"
-      "s_add_u32 m0, %6, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, %5\n\t"
-      "s_add_u32 m0, %6, 0x800\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %5\n\t"
-      "s_add_u32 m0, %6, 0xc00\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %4, %5\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "s"(lds_dst)
-      : "memory", "scc");
-}
-
 template <bool IS_BF16>
 __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,

@@ -20,6 +20,8 @@
 //   gptq_lazy_update    W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] with the exact fp32 MFMA.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -520,6 +522,150 @@ __global__ __launch_bounds__(64) void gptq_quant_block_kernel(
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------------------------
+// the serial column chain, second generation: FOUR lanes per weight row
+// ---------------------------------------------------------------------------------------------
+// The chain of 128 dependent steps cannot be shortened, so the kernel maximises how many chains run at
+// once and minimises the work per step: a wave owns 16 rows, the 4 lanes of a quad share one row with the
+// block's columns interleaved (lane q owns columns 4c+q).  At step i the owner lane (q = i&3) broadcasts
+// the column value to its quad with one DPP quad_perm move; all 4 lanes then compute q/err redundantly
+// (identical inputs -> identical bits, no second exchange) and each applies the rank-1 update to its own
+// still-live columns (4c+q > i; column groups entirely behind i are skipped at compile time, which halves
+// the average work).  N = 4096 rows -> 256 single-wave workgroups (one per CU) instead of 64, and a step
+// costs ~16 updates instead of 128.  The arithmetic per element is unchanged (true divisions, mul-then-sub,
+// contraction off), so results are bit-identical to the one-lane-per-row kernel and to the reference's ops.
+constexpr int Q4R = 16;  // rows per wave
+// compile-time loop: f(integral_constant<int, I>) for I in [BEGIN, END) -- every register index in the step
+// body is then a literal (a `#pragma unroll` loop this size is only partly unrolled and falls back to
+// s_set_gpr_idx register indexing)
+template <int I, int END, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < END) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, END>(f);
+  }
+}
+// value of lane `src` (0..3) of each quad, in every lane of the quad: one v_mov_b32 with a DPP quad_perm
+__device__ __forceinline__ float quad_bcast(float v, int src) {
+  const int x = __float_as_int(v);
+  int y;
+  switch (src) {  // the control word must be a literal; `src` is a constant after unrolling
+    case 0: y = __builtin_amdgcn_mov_dpp(x, 0x00, 0xf, 0xf, true); break;
+    case 1: y = __builtin_amdgcn_mov_dpp(x, 0x55, 0xf, 0xf, true); break;
+    case 2: y = __builtin_amdgcn_mov_dpp(x, 0xAA, 0xf, 0xf, true); break;
+    default: y = __builtin_amdgcn_mov_dpp(x, 0xFF, 0xf, 0xf, true); break;
+  }
+  return __int_as_float(y);
+}
+#pragma clang fp contract(off)
+// GPB = scale groups per 128-column block (1, 2 or 4: group_size >= 128 / 64 / 32 with i1 % 128 == 0), known
+// at compile time so that the 128 steps contain no branch at all; count == 128 on this path.
+template <int QDT, int GPB>
+__global__ __launch_bounds__(64) void gptq_quant_block_q4_kernel(
+    const float* __restrict__ w, const float* __restrict__ Hinv, const float* __restrict__ scale,
+    const float* __restrict__ zero, uint8_t* __restrict__ codes, void* __restrict__ q_out,
+    float* __restrict__ err, int64_t N, int64_t K, int64_t G, int64_t i1, int64_t g0, float maxq) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* hs = reinterpret_cast<float*>(smem_raw);  // [QB][QB] Hinv1 tile, later reused as the output stage
+  const int lane = threadIdx.x, r = lane >> 2, q = lane & 3;
+  const int64_t n0 = (int64_t)blockIdx.x * Q4R;
+  const int64_t row = n0 + r, rowc = row < N ? row : N - 1;
+
+  // Hinv1 tile -> LDS by LDS-DMA: 64 instructions of 1 KiB (two 512-byte rows each), all in flight at once
+  {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
+    const float* hb = Hinv + i1 * K + i1;
+    const uint32_t v0 = (uint32_t)(((lane >> 5) * K + 4 * (lane & 31)) * 4);
+    const uint32_t step = (uint32_t)(2 * K * 4);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      lds_dma_4x1k(hb, lds0 + j * 4096, v0 + (4 * j) * step, v0 + (4 * j + 1) * step, v0 + (4 * j + 2) * step, v0 + (4 * j + 3) * step);
+  }
+  // this lane's 32 columns of its row: block columns 4c + q
+  float wr[32], ev[32];
+  uint32_t cw[8];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    wr[c] = w[rowc * K + i1 + 4 * c + q];
+    ev[c] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cw[c] = 0u;
+  float sg[GPB], zg[GPB];
+#pragma unroll
+  for (int g = 0; g < GPB; ++g) {
+    sg[g] = scale[rowc * G + g0 + g];
+    zg[g] = zero[rowc * G + g0 + g];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // The row of Hinv1 needed by step i+1 is read from LDS while step i computes: two register sets used
+  // alternately (even / odd steps) so that no copies are needed.
+  float ha[33], hb2[33];  // [c] = hs[i][4c+q] for the live c, [32] = hs[i][i]
+  auto fetch_row = [&](auto ic, float (&h)[33]) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < QB) {
+#pragma unroll
+      for (int c = i >> 2; c < 32; ++c) h[c] = hs[i * QB + 4 * c + q];
+      h[32] = hs[i * QB + i];
+    }
+  };
+  auto step = [&](auto ic, float (&h)[33]) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int qo = i & 3, ci = i >> 2, g = i / (QB / GPB);
+    const float s = sg[g], z = zg[g];
+    const float x = quad_bcast(wr[ci], qo);
+    float t = rintf(x / s) + z;
+    t = fminf(fmaxf(t, 0.f), maxq);
+    const float qv = s * (t - z);
+    const float e = (x - qv) / h[32];
+    const bool own = q == qo;
+#pragma unroll
+    for (int c = ci; c < 32; ++c) {
+      const float pr = e * h[c];  // exact zero below the diagonal (Hinv is upper triangular)
+      wr[c] = wr[c] - pr;
+    }
+    wr[ci] = own ? qv : wr[ci];
+    ev[ci] = own ? e : ev[ci];
+    cw[ci >> 2] = own ? (cw[ci >> 2] | ((uint32_t)t << (8 * (ci & 3)))) : cw[ci >> 2];
+  };
+  fetch_row(std::integral_constant<int, 0>{}, ha);
+  static_for<0, QB / 2>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    fetch_row(std::integral_constant<int, 2 * p + 1>{}, hb2);
+    step(std::integral_constant<int, 2 * p>{}, ha);
+    fetch_row(std::integral_constant<int, 2 * p + 2>{}, ha);
+    step(std::integral_constant<int, 2 * p + 1>{}, hb2);
+  });
+  __syncthreads();
+  // stage the three outputs through LDS (rows of 128) for coalesced stores: Err1, Q, codes
+  float* st = hs;  // [Q4R][QB] floats
+#pragma unroll
+  for (int c = 0; c < 32; ++c) st[r * QB + 4 * c + q] = ev[c];
+  __syncthreads();
+  for (int idx = lane; idx < Q4R * QB / 4; idx += 64) {
+    const int rr = idx >> 5, c4 = (idx & 31) * 4;
+    if (n0 + rr < N) *reinterpret_cast<float4*>(err + (n0 + rr) * QB + c4) = *reinterpret_cast<const float4*>(st + rr * QB + c4);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 32; ++c) st[r * QB + 4 * c + q] = wr[c];
+  uint8_t* cst = reinterpret_cast<uint8_t*>(st + Q4R * QB);  // [Q4R][QB] bytes
+#pragma unroll
+  for (int c = 0; c < 32; ++c) cst[r * QB + 4 * c + q] = (uint8_t)((cw[c >> 2] >> (8 * (c & 3))) & 0xffu);
+  __syncthreads();
+  for (int idx = lane; idx < Q4R * QB; idx += 64) {
+    const int rr = idx >> 7, c = idx & 127;
+    if (n0 + rr < N) {
+      const int64_t o = (n0 + rr) * K + i1 + c;
+      if (q_out) store_from_f32<QDT>(q_out, o, st[rr * QB + c]);
+      if (codes) codes[o] = cst[rr * QB + c];
+    }
+  }
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------------
 // lazy update: W[:, i2:] -= Err1[N,128] @ Hinv[i1:i1+128, i2:]
 // ---------------------------------------------------------------------------------------------
 constexpr int LT = 128;
@@ -580,6 +726,131 @@ __global__ __launch_bounds__(256) void gptq_lazy_update_kernel(float* __restrict
         }
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lazy update, second generation: W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] with Err1 held in registers
+// ---------------------------------------------------------------------------------------------
+// 256 threads = 4 waves, each wave owns 32 rows of a 128-row panel and keeps its whole 32 x 128 slice of
+// Err1 as MFMA A-operands in 64 VGPRs for the lifetime of the workgroup.  The workgroup walks over the
+// 128-column tiles assigned to it (tile = chunk, chunk + nchunks, ...): the [128 k][128 col] fp32 tile of
+// Hinv arrives by LDS-DMA into one of two 64 KiB LDS buffers while the previous tile is being multiplied
+// (exact fp32 v_mfma_f32_32x32x2_f32: 256 per wave per tile), the W tile is fetched into registers at the
+// start of the tile and written back as W - acc at its end (same "sum, then subtract" order as before).
+constexpr int L2T = 128;
+template <bool UNUSED>
+__global__ __launch_bounds__(256) void gptq_lazy_update_v2_kernel(float* __restrict__ w, const float* __restrict__ Hinv,
+                                                                  const float* __restrict__ err, int64_t N, int64_t K,
+                                                                  int64_t i1, int64_t i2, int nchunks, int ncol_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = blockIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * L2T + wave * 32;  // first row of this wave
+
+  // Err1 slice -> registers: a[s] = Err1[r0 + (lane&31)][2s + (lane>>5)]
+  float a[64];
+  {
+    int64_t row = r0 + (lane & 31);
+    if (row > N - 1) row = N - 1;
+    const float* ep = err + row * QB + (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < 64; ++s) a[s] = ep[2 * s];
+  }
+  // DMA source offsets (bytes from Hinv + i1*K + c0): instruction j of this wave moves tile rows
+  // (wave*16 + j)*2 + (lane>>5), 16-byte chunk lane&31
+  const uint32_t rowoff = (uint32_t)(((wave * 32 + (lane >> 5)) * K) * 4);
+  const float* const hbase = Hinv + i1 * K;
+  auto dma_tile = [&](int ct, int buf) {
+    const int64_t c0 = i2 + (int64_t)ct * L2T;
+    int64_t col = c0 + 4 * (lane & 31);
+    if (col > K - 4) col = K - 4;  // partial last tile: clamped columns are never stored
+    const uint32_t v = rowoff + (uint32_t)(col * 4);
+    const uint32_t step = (uint32_t)(2 * K * 4);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * (L2T * L2T * 4) + wave * 16384);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      lds_dma_4x1k(hbase, dst + q4 * 4096, v + (4 * q4) * step, v + (4 * q4 + 1) * step, v + (4 * q4 + 2) * step,
+                   v + (4 * q4 + 3) * step);
+  };
+
+  int ct = chunk;
+  if (ct >= ncol_tiles) return;
+  dma_tile(ct, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (; ct < ncol_tiles; ct += nchunks, cur ^= 1) {
+    const int64_t c0 = i2 + (int64_t)ct * L2T;
+    if (ct + nchunks < ncol_tiles) dma_tile(ct + nchunks, cur ^ 1);
+    // W tile -> registers (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    float wt[4][16];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      int64_t col = c0 + nf * 32 + (lane & 31);
+      if (col > K - 1) col = K - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row > N - 1) row = N - 1;
+        wt[nf][r] = w[row * K + col];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
+    const float* hs = reinterpret_cast<const float*>(smem_raw + cur * (L2T * L2T * 4)) + (lane >> 5) * L2T + (lane & 31);
+    // B operands are read from LDS one batch (8 k-steps x 4 column fragments) AHEAD of the MFMAs that use them:
+    // with one wave per SIMD nothing else hides the LDS latency (hipcc alone reads each pair just in time)
+    float bA[32], bB[32];
+    auto load_batch = [&](int g, float (&b)[32]) {
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) b[s8 * 4 + nf] = hs[(2 * (8 * g + s8)) * L2T + nf * 32];
+    };
+    auto mma_batch = [&](int g, const float (&b)[32]) {
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 * g + s8], b[s8 * 4 + nf], acc[nf], 0, 0, 0);
+    };
+    load_batch(0, bA);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      load_batch(2 * p + 1, bB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_batch(2 * p, bA);
+      if (p < 3) load_batch(2 * p + 2, bA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_batch(2 * p + 1, bB);
+    }
+    if (r0 + 32 <= N && c0 + L2T <= K) {  // wave-uniform: interior tile, unguarded stores
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        float* wp = w + (r0 + 4 * (lane >> 5)) * K + c0 + nf * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wp[((r & 3) + 8 * (r >> 2)) * K] = wt[nf][r] - acc[nf][r];
+      }
+    } else {
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const int64_t col = c0 + nf * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < N && col < K) w[row * K + col] = wt[nf][r] - acc[nf][r];
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -669,6 +940,31 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
     (void)hipFuncSetAttribute((const void*)gptq_quant_block_kernel<INC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
+  // second-generation kernel: full 128-column block starting on a 128-column boundary, 1 / 2 / 4 groups per block
+  int gpb = 0;
+  if (group_size <= 0 || (group_size % QB) == 0) gpb = 1;
+  else if (group_size == 64) gpb = 2;
+  else if (group_size == 32) gpb = 4;
+  if (gpb && count == QB && (i1 % QB) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles()) {
+    const size_t smem4 = (size_t)QB * QB * 4;  // 64 KiB: Hinv1 tile, reused as the output stage
+    static bool attr4_set = false;
+#define INC_Q4_ATTR(DT, GP) (void)hipFuncSetAttribute((const void*)gptq_quant_block_q4_kernel<DT, GP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)
+    if (!attr4_set) {
+      INC_Q4_ATTR(INC_F32, 1); INC_Q4_ATTR(INC_F32, 2); INC_Q4_ATTR(INC_F32, 4);
+      INC_Q4_ATTR(INC_F16, 1); INC_Q4_ATTR(INC_F16, 2); INC_Q4_ATTR(INC_F16, 4);
+      INC_Q4_ATTR(INC_BF16, 1); INC_Q4_ATTR(INC_BF16, 2); INC_Q4_ATTR(INC_BF16, 4);
+      attr4_set = true;
+    }
+#undef INC_Q4_ATTR
+    const unsigned blocks4 = (unsigned)ceil_div64(N, Q4R);
+    const int64_t g0 = group_size > 0 ? i1 / group_size : 0;
+#define INC_Q4(GP) gptq_quant_block_q4_kernel<DT, GP><<<blocks4, 64, smem4, s>>>(w, Hinv, scale, zero, codes, q_out, err, N, K, G, i1, g0, maxq)
+    INC_DISPATCH_DTYPE(q_dtype, DT, {
+      if (gpb == 1) INC_Q4(1); else if (gpb == 2) INC_Q4(2); else INC_Q4(4);
+    })
+#undef INC_Q4
+    INC_LAUNCH_RETURN();
+  }
   INC_DISPATCH_DTYPE(q_dtype, DT, {
     gptq_quant_block_kernel<DT><<<blocks, 64, smem, s>>>(w, Hinv, scale, zero, codes, q_out, err, N, K, G, i1, count, group_size, maxq);
   })
@@ -680,6 +976,21 @@ int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t 
   INC_CHECK_ARG(w && Hinv && err && N > 0 && K > 0 && i1 >= 0 && count > 0 && count <= QB);
   const int64_t i2 = i1 + count;
   if (i2 >= K) return INC_OK;  // nothing to the right of the block
+  if (count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles()) {
+    const int ncol_tiles = (int)ceil_div64(K - i2, L2T);
+    const int row_tiles = (int)ceil_div64(N, L2T);
+    int nchunks = (int)ceil_div64(512, row_tiles);  // ~512 workgroups when the trailing matrix is wide enough
+    if (nchunks > ncol_tiles) nchunks = ncol_tiles;
+    const size_t smem2 = (size_t)2 * L2T * L2T * 4;  // 128 KiB
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+      attr2_set = true;
+    }
+    gptq_lazy_update_v2_kernel<true><<<dim3((unsigned)nchunks, (unsigned)row_tiles), 256, smem2, inc_s(stream)>>>(
+        w, Hinv, err, N, K, i1, i2, nchunks, ncol_tiles);
+    INC_LAUNCH_RETURN();
+  }
   const size_t smem = (size_t)LT * LAP * 4 + (size_t)QB * LT * 4;
   static bool attr_set = false;
   if (!attr_set) {

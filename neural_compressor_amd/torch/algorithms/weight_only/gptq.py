@@ -457,18 +457,50 @@ class RAWGPTQuantizer(object):
                     solvers[name].acc = solvers[owner].acc
                 else:  # pragma: no cover - different damping per layer: cannot share the factorisation
                     raise RuntimeError(f"{name} shares its input with {owner} but not its GPTQ settings; pass share_hessians=False")
-            # Step 2.4: solve (reference :690-747)
+            # Step 2.4: solve (reference :690-747).  The column loop treats every weight ROW independently, so Linears
+            # that share one Hessian (q/k/v, gate/up) and one GPTQ setting are stacked along N and solved in ONE pass:
+            # a third of the serial 128-column steps and three times the rows in flight per step, same results.
             results = {}
+            _KEYS = ("bits", "sym", "group_size", "block_size", "percdamp", "act_order", "hybrid_order", "fp8_aware",
+                     "static_groups", "mse", "dtype", "use_double_quant")
+            batches, index = [], {}
             for name, layer in layers.items():
-                cfg = solvers[name].cfg
-                scale, _, zp, Q = solvers[name].fasterquant(
-                    layer.weight.data, blocksize=cfg["block_size"], percdamp=cfg["percdamp"], groupsize=cfg["group_size"],
+                sv = solvers[name]
+                key = None
+                if isinstance(layer, nn.Linear) and self.share_hessians:
+                    key = (id(sv.acc), layer.weight.dtype, tuple(sv.cfg.get(k) for k in _KEYS))
+                if key is not None and key in index:
+                    batches[index[key]].append(name)
+                else:
+                    if key is not None:
+                        index[key] = len(batches)
+                    batches.append([name])
+            for names in batches:
+                sv = solvers[names[0]]
+                cfg = sv.cfg
+                if len(names) == 1:
+                    W = layers[names[0]].weight.data
+                else:
+                    W = torch.cat([layers[n].weight.data for n in names], dim=0)
+                scale, _, zp, Q = sv.fasterquant(
+                    W, blocksize=cfg["block_size"], percdamp=cfg["percdamp"], groupsize=cfg["group_size"],
                     act_order=cfg["act_order"], hybrid_order=cfg["hybrid_order"], fp8_aware=cfg["fp8_aware"],
                     static_groups=cfg["static_groups"],
                 )
-                layer.weight.data = Q
-                results[name] = dict(scale=scale, zero=None if cfg["sym"] else zp, perm=solvers[name].perm, codes=solvers[name].codes)
-                solvers[name].free()
+                codes, perm = sv.codes, sv.perm
+                r0 = 0
+                for n in names:
+                    rows = layers[n].weight.shape[0]
+                    sl = slice(r0, r0 + rows)
+                    r0 += rows
+                    one = len(names) == 1
+                    layers[n].weight.data = Q if one else Q[sl].contiguous()
+                    results[n] = dict(scale=scale if one else scale[sl].contiguous(),
+                                      zero=None if cfg["sym"] else (zp if one else zp[sl].contiguous()), perm=perm,
+                                      codes=codes if one else codes[sl].contiguous())
+                    solvers[n].perm = perm
+                for n in names:
+                    solvers[n].free()
             del solvers
             # Step 2.5: outputs of the quantised block become the next block's inputs (reference :749-762)
             def replace(j, out):

@@ -64,6 +64,39 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"gptq_tiny_llama_{tag}.npz"), **out)
         print(tag, "modules:", int(out["n_modules"]))
 
+    # AWQ with an explicit absorb_layer_dict (the reference's jit-trace discovery fails on this transformers version
+    # and silently falls back to self-absorption; the explicit dict pins the structure for both implementations):
+    #   "fold": norms absorb q/k/v and gate/up, o_proj / down_proj absorb themselves (MulLinear)
+    #   "self": every Linear absorbs itself (what the reference's fallback produces)
+    from neural_compressor.torch.quantization import AWQConfig
+
+    ABSORB = {
+        "fold": {"input_layernorm": ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"],
+                 "post_attention_layernorm": ["mlp.gate_proj", "mlp.up_proj"],
+                 "self_attn.o_proj": "self_attn.o_proj", "mlp.down_proj": "mlp.down_proj"},
+        "self": {n: n for n in ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+                                "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]},
+    }
+    for tag, absorb in ABSORB.items():
+        model = tiny_llama()
+        model.config.use_cache = False  # the reference re-runs blocks with the captured kwargs; a live KV cache would grow
+        cfg = AWQConfig(bits=4, group_size=32, use_sym=False, use_auto_scale=True, use_auto_clip=True, absorb_layer_dict=absorb)
+        model = prepare(model, cfg, example_inputs=ids[0])
+        run_fn(model)
+        q = convert(model)
+        out = {}
+        dump_modules(q, out)
+        for name, mod in q.named_modules():
+            if type(mod).__name__ == "MulLinear":
+                out[f"{name}.input_scale"] = mod.input_scale.float().numpy()
+            if type(mod).__name__ == "LlamaRMSNorm":
+                out[f"{name}.weight"] = mod.weight.detach().float().numpy()
+        with torch.no_grad():
+            out["logits"] = q(ids[0]).logits.float().numpy()
+            out["logits_fp"] = tiny_llama()(ids[0]).logits.float().numpy()
+        np.savez_compressed(os.path.join(HERE, f"awq_tiny_llama_{tag}.npz"), **out)
+        print("awq", tag, "modules:", int(out["n_modules"]))
+
     model = tiny_llama()
     q = quantize(model, RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
     out = {}

@@ -306,6 +306,66 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
   return ok ? 0 : 1;
 }
 
+// ---- GPTQ column loop: quad-per-row quant block + register-resident lazy update vs the first generation --------
+static int run_colloop_case(int64_t N, int64_t K, int gs, int nblocks, bool time_it) {
+  std::vector<float> hw((size_t)N * K), hh((size_t)K * K, 0.f);
+  for (auto& v : hw) v = 0.02f * rnd_normal();
+  for (int64_t i = 0; i < K; ++i) {  // upper-triangular "Cholesky factor of H^-1": positive diagonal, small off-diagonal
+    hh[i * K + i] = 0.5f + (float)(rnd() & 0xffff) / 65536.f;
+    for (int64_t j = i + 1; j < K; ++j) hh[i * K + j] = 0.02f * rnd_normal();
+  }
+  const int64_t G = (K + gs - 1) / gs;
+  std::vector<float> hs((size_t)N * G), hz((size_t)N * G, 8.f);
+  for (auto& v : hs) v = 0.01f + 0.005f * (float)(rnd() & 0xffff) / 65536.f;
+  DevBuf<float> Hinv((size_t)K * K), sc(hs.size()), ze(hz.size());
+  Hinv.upload(hh); sc.upload(hs); ze.upload(hz);
+  DevBuf<float> W[2] = {DevBuf<float>((size_t)N * K), DevBuf<float>((size_t)N * K)};
+  DevBuf<float> E[2] = {DevBuf<float>((size_t)N * 128), DevBuf<float>((size_t)N * 128)};
+  DevBuf<uint8_t> C[2] = {DevBuf<uint8_t>((size_t)N * K), DevBuf<uint8_t>((size_t)N * K)};
+  DevBuf<uint16_t> Q[2] = {DevBuf<uint16_t>((size_t)N * K), DevBuf<uint16_t>((size_t)N * K)};
+  for (int m = 0; m < 2; ++m) { W[m].upload(hw); C[m].zero(); Q[m].zero(); }
+  const int nb = (int)(nblocks < K / 128 ? nblocks : K / 128);
+  for (int m = 0; m < 2; ++m) {
+    inc_debug_set_small_tiles(m);
+    for (int b = 0; b < nb; ++b) {
+      INCCHECK(inc_gptq_quant_block(W[m].p, Hinv.p, sc.p, ze.p, C[m].p, Q[m].p, INC_BF16, E[m].p, N, K, G, (int64_t)b * 128, 128, gs, 4, nullptr));
+      INCCHECK(inc_gptq_lazy_update(W[m].p, Hinv.p, E[m].p, N, K, (int64_t)b * 128, 128, nullptr));
+    }
+  }
+  inc_debug_set_small_tiles(0);
+  HIPCHECK(hipDeviceSynchronize());
+  std::vector<float> w0 = W[0].download(), w1 = W[1].download(), e0 = E[0].download(), e1 = E[1].download();
+  std::vector<uint8_t> c0 = C[0].download(), c1 = C[1].download();
+  std::vector<uint16_t> q0 = Q[0].download(), q1 = Q[1].download();
+  int64_t dw = 0, de = 0, dc = 0, dq = 0;
+  for (size_t i = 0; i < w0.size(); ++i) { dw += memcmp(&w0[i], &w1[i], 4) != 0; dc += c0[i] != c1[i]; dq += q0[i] != q1[i]; }
+  for (size_t i = 0; i < e0.size(); ++i) de += memcmp(&e0[i], &e1[i], 4) != 0;
+  const bool ok = dw == 0 && de == 0 && dc == 0 && dq == 0;
+  printf("COLLOOP N=%ld K=%ld gs=%d blocks=%d: differing W=%ld Err=%ld codes=%ld Q=%ld (second vs first generation, bitwise)  %s\n", (long)N,
+         (long)K, gs, nb, (long)dw, (long)de, (long)dc, (long)dq, ok ? "OK" : "FAIL");
+  if (time_it) {
+    Timer t;
+    for (int m = 0; m < 2; ++m) {
+      inc_debug_set_small_tiles(m);
+      float tq = 0, tl = 0;
+      for (int b = 0; b < nb; ++b) {
+        t.start();
+        INCCHECK(inc_gptq_quant_block(W[m].p, Hinv.p, sc.p, ze.p, C[m].p, Q[m].p, INC_BF16, E[m].p, N, K, G, (int64_t)b * 128, 128, gs, 4, nullptr));
+        tq += t.stop_ms();
+        t.start();
+        INCCHECK(inc_gptq_lazy_update(W[m].p, Hinv.p, E[m].p, N, K, (int64_t)b * 128, 128, nullptr));
+        tl += t.stop_ms();
+      }
+      double fl = 0;
+      for (int b = 0; b < nb; ++b) fl += 2.0 * N * 128 * (double)(K - (b + 1) * 128);
+      printf("  %-22s quant_block %8.3f ms/block   lazy_update %8.3f ms/block (%7.1f TFLOP/s fp32)\n", m ? "first generation" : "second generation",
+             tq / nb, tl / nb, fl / (tl * 1e9));
+    }
+    inc_debug_set_small_tiles(0);
+  }
+  return ok ? 0 : 1;
+}
+
 // ---- ds_read_b64_tr_b16 probe: which LDS halfwords does lane l receive? ----------------------------
 __global__ void probe_tr(uint32_t* out, int addr_mode) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[4096];
@@ -368,7 +428,13 @@ int main(int argc, char** argv) {
     fails += run_hessian_case(2048, 11008, true);
     fails += run_hessian_case(16384, 4096, true);
   }
-  if (what == "probe" || what == "all") run_probe();
+  if (what == "colloop" || what == "all") {
+    fails += run_colloop_case(200, 512, 32, 4, false);      // ragged rows, 4 groups per block
+    fails += run_colloop_case(4096, 4096, 128, 32, true);
+    fails += run_colloop_case(11008, 4096, 128, 8, true);
+    fails += run_colloop_case(4096, 11008, 128, 8, true);
+  }
+  if (what == "probe") run_probe();
   printf("kbench: %d failing case(s)\n", fails);
   return fails ? 1 : 0;
 }
