@@ -195,6 +195,18 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
 int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t N, int64_t K,
                          int64_t i1, int count, inc_stream_t stream);
 
+/* ---- K6': diagonal block of the blocked inverse-Cholesky factor -------------------------------- *
+ * The reference builds Hinv = cholesky(cholesky_inverse(cholesky(H)), upper) (gptq.py:1228-1230) with
+ * three LAPACK factorisations.  Here U = J Lr^-1 J with J H J = Lr Lr^T (see gptq.py: inverse_cholesky_upper):
+ * a blocked Cholesky + a blocked triangular inverse whose O(K^3) parts are fp32 GEMMs; this entry point is
+ * the unblocked kernel for one diagonal block (== LAPACK potf2 + trti2 on it):
+ *   A [n,n] fp32 (row stride lda, n <= 128): lower triangle read; on return the lower triangle holds L
+ *   (A = L L^T) and the strict upper triangle is zero.  Linv [n,n] (row stride ldi) receives L^-1.
+ *   info: device int32, atomically max-ed with `tag` when a pivot is not positive (H not SPD).
+ */
+int inc_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, int32_t* info, int tag,
+                        inc_stream_t stream);
+
 /* ---- K8: AWQ statistics ---------------------------------------------------------------------- *
  * inc_awq_act_abs_sum: out[k] += sum_t |x[t,k]|  (fp32 [K], accumulate; caller divides by T)
  *   == _get_act_scale (weight_only/awq.py:151-154).

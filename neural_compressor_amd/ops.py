@@ -330,6 +330,23 @@ def gptq_lazy_update(w32, hinv, err, i1, count):
         check(lib.inc_gptq_lazy_update(_ptr(w32), _ptr(hinv), _ptr(err), N, K, i1, count, _stream()), "inc_gptq_lazy_update")
 
 
+def chol_diag_block(A_view, Linv_view, info, tag):
+    """In-place Cholesky of one <=128x128 diagonal block (a strided view into a larger fp32 matrix) + inverse of its
+    factor into `Linv_view` (also a strided view).  See include/inc_mi355x.h: inc_chol_diag_block."""
+    dev = A_view.device
+    if dev.type != "cuda" or Linv_view.device != dev:
+        raise RuntimeError("chol_diag_block needs HBM-resident views")
+    n = A_view.shape[0]
+    assert A_view.shape == (n, n) and Linv_view.shape == (n, n) and A_view.stride(1) == 1 and Linv_view.stride(1) == 1
+    assert A_view.dtype == torch.float32 and Linv_view.dtype == torch.float32
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_chol_diag_block(A_view.data_ptr(), A_view.stride(0), n, Linv_view.data_ptr(), Linv_view.stride(0),
+                                    _ptr(info), int(tag), _stream()),
+            "inc_chol_diag_block",
+        )
+
+
 # ---------------------------------------------------------------------------------------------------
 # K8 AWQ statistics
 # ---------------------------------------------------------------------------------------------------

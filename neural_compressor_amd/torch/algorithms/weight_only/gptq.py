@@ -22,6 +22,7 @@ Everything stays resident in HBM between the steps (no block.cpu() / .cpu() roun
 """
 
 import math
+import os
 import time
 from functools import partial
 
@@ -82,6 +83,70 @@ def find_layers(module, layers=SUPPORTED_LAYERS, name=""):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Hinv = cholesky(cholesky_inverse(cholesky(H)), upper=True)  (reference gptq.py:1228-1230), restructured
+# ---------------------------------------------------------------------------------------------------
+CHOL_NB = 128
+_EXACT_TRIO = os.environ.get("INC_MI355X_CHOLESKY_TRIO", "0") == "1"
+
+
+@torch.no_grad()
+def inverse_cholesky_upper(H):
+    """Upper Cholesky factor U of H^-1 (H^-1 = U^T U) for a symmetric positive definite fp32 H [K,K] in HBM.
+
+    The reference gets it from three LAPACK factorisations (potrf -> potri -> potrf, gptq.py:1228-1230); on the GPU
+    that is rocSOLVER, whose unblocked diagonal kernels were a fifth of the whole GPTQ run (profiles/r1c).  With J the
+    index reversal,   J H J = Lr Lr^T  (lower Cholesky)   =>   H = (J Lr J)(J Lr J)^T  with  J Lr J  UPPER triangular
+    =>   H^-1 = (J Lr^-1 J)^T (J Lr^-1 J),  and  J Lr^-1 J  is upper triangular with a positive diagonal, i.e. it IS U.
+    So ONE blocked Cholesky and ONE blocked triangular inverse replace the trio (half the flops, one rounding pass
+    instead of three):
+      * diagonal blocks (128x128): inc_chol_diag_block factors the block AND inverts its factor in one workgroup;
+      * panel solve  L[i>j, j] = A[i>j, j] @ inv(L_jj)^T  and trailing update  A[i>j, i>j] -= L_panel L_panel^T: fp32 GEMMs;
+      * Lr^-1 by recursive doubling: inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]], all pairs of a level independent.
+    The GEMMs are the fp32 library GEMMs torch dispatches to (plumbing, like torch.linalg was before); a non-positive
+    pivot raises like torch.linalg.cholesky does.
+    """
+    assert H.dim() == 2 and H.shape[0] == H.shape[1] and H.dtype == torch.float32
+    K = H.shape[0]
+    nb = CHOL_NB
+    Kp = -(-K // nb) * nb
+    dev = H.device
+    if Kp == K:
+        A = torch.flip(H, (0, 1)).contiguous()
+    else:  # pad with an identity block: chol(blockdiag(Hr, I)) = blockdiag(Lr, I)
+        A = torch.zeros((Kp, Kp), dtype=torch.float32, device=dev)
+        A[:K, :K] = torch.flip(H, (0, 1))
+        A.diagonal()[K:] = 1.0
+    X = torch.zeros((Kp, Kp), dtype=torch.float32, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    nblk = Kp // nb
+    for b in range(nblk):
+        j = b * nb
+        ops.chol_diag_block(A[j:j + nb, j:j + nb], X[j:j + nb, j:j + nb], info, b + 1)
+        if b + 1 < nblk:
+            panel = A[j + nb:, j:j + nb]                      # [M, nb] strided view
+            lp = torch.mm(panel, X[j:j + nb, j:j + nb].t())   # L_panel = A_panel @ inv(L_jj)^T
+            panel.copy_(lp)
+            A[j + nb:, j + nb:].addmm_(lp, lp.t(), alpha=-1.0)  # symmetric trailing update (both triangles kept valid)
+    # Lr^-1 by doubling: segments (start, size) whose diagonal blocks of X already hold the inverse
+    segs = [(b * nb, nb) for b in range(nblk)]
+    while len(segs) > 1:
+        nxt = []
+        for p in range(0, len(segs) - 1, 2):
+            (s1, n1), (s2, n2) = segs[p], segs[p + 1]
+            C = A[s2:s2 + n2, s1:s1 + n1]
+            T = torch.mm(C, X[s1:s1 + n1, s1:s1 + n1])
+            X[s2:s2 + n2, s1:s1 + n1] = -torch.mm(X[s2:s2 + n2, s2:s2 + n2], T)
+            nxt.append((s1, n1 + n2))
+        if len(segs) % 2:
+            nxt.append(segs[-1])
+        segs = nxt
+    if int(info.item()) != 0:
+        raise torch.linalg.LinAlgError(
+            f"inverse_cholesky_upper: the matrix is not positive definite (pivot <= 0 in diagonal block {int(info.item())})")
+    return torch.flip(X[:K, :K], (0, 1)).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
 # per-layer solver
 # ---------------------------------------------------------------------------------------------------
 class HessianAccumulator:
@@ -124,11 +189,14 @@ class HessianAccumulator:
         if act_order:
             perm = torch.argsort(torch.diagonal(H), descending=True)
             H = H[perm][:, perm].contiguous()
-        L = torch.linalg.cholesky(H)
-        Hi = torch.cholesky_inverse(L)
-        del L
-        Hinv = torch.linalg.cholesky(Hi, upper=True).contiguous()
-        del Hi
+        if _EXACT_TRIO:  # the reference's three factorisations through rocSOLVER (INC_MI355X_CHOLESKY_TRIO=1)
+            L = torch.linalg.cholesky(H)
+            Hi = torch.cholesky_inverse(L)
+            del L
+            Hinv = torch.linalg.cholesky(Hi, upper=True).contiguous()
+            del Hi
+        else:
+            Hinv = inverse_cholesky_upper(H)
         self.H = None
         self.finalized = (key, Hinv, dead, perm)
         return Hinv, dead, perm

@@ -306,10 +306,13 @@ class MulLinear(torch.nn.Module):
         return self.linear(torch.mul(X, self.input_scale))
 
     def _update_linear(self):
-        """Fold the multiplier into the weight and return the plain Linear."""
-        self.linear.weight.mul_(self.input_scale.view(1, -1).to(self.linear.weight.dtype))
+        """Fold the multiplier into the weight: y = (x * input_scale) W'^T with W' = W / input_scale (reference :939-943)."""
+        with torch.no_grad():
+            self.linear.weight.div_(self.input_scale.view(1, -1).to(self.linear.weight.dtype))
         return self.linear
 
     def _recover_linear(self):
-        self.linear.weight.div_(self.input_scale.view(1, -1).to(self.linear.weight.dtype))
+        """Undo `_update_linear` (reference :945-949)."""
+        with torch.no_grad():
+            self.linear.weight.mul_(self.input_scale.view(1, -1).to(self.linear.weight.dtype))
         return self.linear

@@ -3,8 +3,9 @@ from .config import (
     AWQConfig, GPTQConfig, RTNConfig, get_default_awq_config, get_default_gptq_config, get_default_rtn_config,
 )
 from .quantize import convert, prepare, quantize
+from ..algorithms.weight_only.save_load import load, save  # reference torch/quantization/save_load_entry.py
 
 __all__ = [
-    "prepare", "convert", "quantize", "RTNConfig", "GPTQConfig", "AWQConfig",
+    "prepare", "convert", "quantize", "save", "load", "RTNConfig", "GPTQConfig", "AWQConfig",
     "get_default_rtn_config", "get_default_gptq_config", "get_default_awq_config",
 ]

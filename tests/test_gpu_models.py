@@ -168,6 +168,17 @@ AWQ_ABSORB = {
 }
 
 
+def _to_half(model):
+    """fp16 copy of the float parameters of a quantised HF model (HF refuses `.half()` once `is_quantized` is set)."""
+    for mod in model.modules():
+        for p in mod.parameters(recurse=False):
+            if p.is_floating_point():
+                p.data = p.data.half()
+        if type(mod).__name__ == "MulLinear":
+            mod.input_scale = mod.input_scale.half()
+    return model
+
+
 def _run_awq(absorb, **kw):
     from neural_compressor_amd.torch.quantization import AWQConfig, convert, prepare
 
@@ -221,7 +232,7 @@ def test_awq_tiny_llama_vs_reference(tag):
     with torch.no_grad():
         # the packed modules return fp16 for fp32 inputs (the reference's accelerator semantics, modules.py:605): run
         # the rest of the model in fp16 too, otherwise HF's eager attention mixes fp32 RoPE outputs with an fp16 V
-        y = q.half()(ids[0].to("cuda")).logits.float().cpu().numpy()
+        y = _to_half(q)(ids[0].to("cuda")).logits.float().cpu().numpy()
     err_ours = np.linalg.norm(y - g["logits_fp"]) / np.linalg.norm(g["logits_fp"])
     err_ref = np.linalg.norm(g["logits"] - g["logits_fp"]) / np.linalg.norm(g["logits_fp"])
     assert err_ours <= 1.25 * err_ref + 1e-3, (err_ours, err_ref)
@@ -260,9 +271,61 @@ def test_awq_default_discovery_end_to_end():
     assert len(_woq_modules(q)) == 14
     with torch.no_grad():
         fp = tiny_llama().to("cuda")(ids[0].to("cuda")).logits.float()
-        y = q.half()(ids[0].to("cuda")).logits.float()
+        y = _to_half(q)(ids[0].to("cuda")).logits.float()
         r = quantize(tiny_llama(), RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
-        yr = r.half()(ids[0].to("cuda")).logits.float()
+        yr = _to_half(r)(ids[0].to("cuda")).logits.float()
     e_awq = float((y - fp).norm() / fp.norm())
     e_rtn = float((yr - fp).norm() / fp.norm())
     assert e_awq <= 1.1 * e_rtn, (e_awq, e_rtn)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# save / load (reference weight_only/save_load.py): both on-disk formats round-trip bit-exactly
+# ---------------------------------------------------------------------------------------------------------------------
+def _buffers(model):
+    return {n + "." + k: v.detach().cpu() for n, m in _woq_modules(model).items() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("fmt", ["default", "huggingface"])
+def test_save_load_roundtrip_rtn(tmp_path, fmt):
+    from neural_compressor_amd.torch.quantization import RTNConfig, load, quantize
+
+    q = quantize(tiny_llama(), RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
+    ids = calib_ids()[0].to("cuda")
+    with torch.no_grad():
+        y0 = _to_half(q)(ids).logits.float().cpu()
+    q.save(str(tmp_path), format=fmt)
+    if fmt == "default":
+        files = sorted(os.listdir(tmp_path))
+        assert "quantized_weight.pt" in files and "qconfig.json" in files  # the reference's file names
+        r = load(str(tmp_path), original_model=tiny_llama(), format="default", device="cuda")
+    else:
+        assert os.path.exists(tmp_path / "quantize_config.json")
+        r = load(str(tmp_path), format="huggingface", device="cuda")
+    b0, b1 = _buffers(q), _buffers(r)
+    assert b0.keys() == b1.keys() and len(_woq_modules(r)) == 14
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+    with torch.no_grad():
+        y1 = _to_half(r)(ids).logits.float().cpu()
+    # HF re-instantiation picks its default attention kernel (sdpa) instead of the zoo's eager one: fp16-level differences
+    assert float((y1 - y0).norm() / y0.norm()) <= (1e-3 if fmt == "default" else 2e-2)
+
+
+def test_save_load_default_awq_keeps_mul_linear(tmp_path):
+    """AWQ checkpoints carry `<name>.input_scale` + `<name>.linear.qweight`: the loader re-inserts MulLinear (reference :479-482)."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MulLinear
+    from neural_compressor_amd.torch.quantization import load
+
+    q, ids = _run_awq(AWQ_ABSORB["fold"])
+    q.save(str(tmp_path))
+    m = tiny_llama()
+    m.config.use_cache = False
+    r = load(str(tmp_path), original_model=m, device="cuda")
+    muls0 = {n: mod.input_scale.cpu() for n, mod in q.named_modules() if isinstance(mod, MulLinear)}
+    muls1 = {n: mod.input_scale.cpu() for n, mod in r.named_modules() if isinstance(mod, MulLinear)}
+    assert muls0.keys() == muls1.keys() and len(muls0) == 4
+    for n in muls0:
+        assert torch.equal(muls0[n], muls1[n])
+    for (n0, p0), (n1, p1) in zip(sorted(q.state_dict().items()), sorted(r.state_dict().items())):
+        assert n0 == n1 and torch.equal(p0.cpu(), p1.cpu()), n0

@@ -443,3 +443,39 @@ def test_awq_stats(hip, golden):
     out = torch.zeros(128, device=hip)
     ops.awq_act_abs_sum(x.reshape(-1, 128), out)
     assert torch.allclose((out / 60).cpu(), torch.from_numpy(golden["awq_xscale"]), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K6' blocked inverse-Cholesky factor (replaces the potrf -> potri -> potrf trio, gptq.py:1228-1230)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [96, 128, 300, 1024])
+def test_inverse_cholesky_upper_vs_reference_trio(hip, K):
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import inverse_cholesky_upper
+
+    g = torch.Generator().manual_seed(K)
+    X = torch.randn(4 * K, K, generator=g, dtype=torch.float64)
+    H64 = (2.0 / X.shape[0]) * X.T @ X
+    H64 += 0.01 * H64.diagonal().mean() * torch.eye(K, dtype=torch.float64)  # the reference's damping
+    H = H64.float()
+    # the reference's three factorisations (LAPACK, fp32 on the CPU) and their fp64 counterpart
+    ref32 = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
+    ref64 = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H64)), upper=True)
+    U = inverse_cholesky_upper(H.to(hip)).cpu()
+    assert torch.equal(U, torch.triu(U)), "U must be upper triangular"
+    assert bool((U.diagonal() > 0).all())
+    err_ours = float((U.double() - ref64).norm() / ref64.norm())
+    err_ref = float((ref32.double() - ref64).norm() / ref64.norm())
+    # one blocked factorisation + one triangular inverse in fp32 must be at least as accurate as the reference's fp32 trio
+    assert err_ours <= max(2.0 * err_ref, 1e-5), (err_ours, err_ref)
+    assert float((U - ref32).norm() / ref32.norm()) <= 1e-3  # the tolerance the survey sets for derived fp quantities
+    resid = float((U.double().T @ U.double() @ H64 - torch.eye(K, dtype=torch.float64)).norm() / K**0.5)
+    assert resid <= 1e-3, resid
+
+
+def test_inverse_cholesky_upper_rejects_non_spd(hip):
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import inverse_cholesky_upper
+
+    H = torch.eye(256)
+    H[200, 200] = -1.0
+    with pytest.raises(torch.linalg.LinAlgError):
+        inverse_cholesky_upper(H.to(hip))
