@@ -434,6 +434,37 @@ int main(int argc, char** argv) {
     fails += run_colloop_case(11008, 4096, 128, 8, true);
     fails += run_colloop_case(4096, 11008, 128, 8, true);
   }
+  if (what == "prof") {  // short, kernel-only workload for rocprofv3 --pmc passes (no reference kernels)
+    {
+      const int64_t M = 4096, N = 4096, K = 4096;
+      Packed W(N, K, 128, true);
+      DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
+      std::vector<uint16_t> hx(x.n);
+      for (auto& v : hx) v = f2bf(rnd_normal());
+      x.upload(hx);
+      for (int i = 0; i < 5; ++i)
+        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+      DevBuf<uint16_t> x1((size_t)K);
+      x1.upload(std::vector<uint16_t>(hx.begin(), hx.begin() + K));
+      const int64_t wsb = inc_woq_gemm_workspace_bytes(1, N, K);
+      DevBuf<char> ws((size_t)wsb);
+      ws.zero();
+      for (int i = 0; i < 5; ++i)
+        INCCHECK(inc_woq_gemm(x1.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, 1, N, K, W.G, 128, 4, ws.p, wsb, nullptr));
+    }
+    {
+      const int64_t T = 2048, K = 11008;
+      DevBuf<uint16_t> x((size_t)T * K);
+      std::vector<uint16_t> hx(x.n);
+      for (auto& v : hx) v = f2bf(rnd_normal());
+      x.upload(hx);
+      DevBuf<float> H((size_t)K * K);
+      H.zero();
+      for (int i = 0; i < 5; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
+    }
+    HIPCHECK(hipDeviceSynchronize());
+    printf("prof workload done\n");
+  }
   if (what == "probe") run_probe();
   printf("kbench: %d failing case(s)\n", fails);
   return fails ? 1 : 0;
