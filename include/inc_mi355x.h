@@ -45,7 +45,8 @@ int inc_abi_version(void);                 /* bumps on any signature change     
 const char* inc_error_string(int code);    /* static string for an INC_ERR_* code                */
 const char* inc_target_arch(void);         /* "gfx950"                                           */
 
-/* debug: != 0 routes inc_woq_gemm / inc_gptq_hessian_accum to the generic 128x128 tilings (A/B runs) */
+/* debug (A/B runs): 0 = newest kernels; 1 = route GEMM / Hessian / column loop to their first-generation kernels
+ * (which remain the generic fall-backs); 2 = second-generation 256x256 two-stage dequant-GEMM, newest elsewhere */
 void inc_debug_set_small_tiles(int on);
 
 /* ---- K1/K2: bit packing ------------------------------------------------------------------- *

@@ -24,7 +24,7 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 // 128x128 tilings, which stay in the library as the generic fall-back for odd shapes.  Initial value from
 // the environment (INC_MI355X_SMALL_TILES=1), changeable through inc_debug_set_small_tiles().
 int inc_small_tiles_flag(int set_to);  // defined in pack.hip; set_to < 0 -> query only
-static inline bool inc_force_small_tiles() { return inc_small_tiles_flag(-1) != 0; }
+static inline bool inc_force_small_tiles() { return inc_small_tiles_flag(-1) == 1; }
 
 // ---- 16-bit float <-> fp32 (bit-exact, round-to-nearest-even) -------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {

@@ -499,6 +499,212 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
 }
 
 // =============================================================================================
+// large-M deep-pipeline path (4-bit, K % 128 == 0): 256x256 tile, BK = 32, FOUR LDS stages
+// =============================================================================================
+// profiles/r1_pmc: in the two-stage kernel above the waves spend 39 % of their time parked at the per-step
+// s_waitcnt/barrier and the matrix pipe is busy 38 %: after every barrier all 8 waves issue their first fragment
+// reads at once and nothing feeds the MFMAs until they return.  This kernel keeps the same tile, wave layout,
+// LDS images (XOR-swizzled row-major x, fragment-ordered dequantised W) and dequantisation, but
+//   * a step is 32 k (16 MFMAs per wave) and there are four 32 KiB stages: while step t is multiplied, stage t+1 is
+//     complete, stage t+2 is being completed (x by DMA issued in step t-1, W dequantised in step t from words fetched
+//     in step t-1) and the loads of stage t+3 are issued -> every load has two steps to land;
+//   * the fragments of (step t+1, first k16) are read from LDS BEFORE the barrier that ends step t, under the MFMAs of
+//     (step t, second k16), so the first MFMAs after a barrier never wait for LDS;
+//   * all global traffic of the loop (x DMA, packed W words, scale, zero word) is issued from inline asm and retired
+//     with ONE counted `s_waitcnt vmcnt(6)` per step (= this step's six requests may stay in flight; everything older,
+//     i.e. the words to dequantise now and the DMA of stage t+2, has landed).  hipcc never drains the queue.
+constexpr int DK = 32;                      // k per step
+constexpr int D_ASTAGE = TM * DK * 2;       // 16 KiB
+constexpr int D_BSTAGE = TN * DK * 2;       // 16 KiB
+constexpr int D_STAGE = D_ASTAGE + D_BSTAGE;
+
+template <bool IS_BF16>
+__global__ __launch_bounds__(512) void woq_gemm_w4_deep_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
+    const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
+    const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int64_t M, int64_t N, int64_t K,
+    int64_t NW, int g_shift, int y_vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (int)((N + TN - 1) / TN);
+  const int tiles_m = (int)((M + TM - 1) / TM);
+  const int nwg = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective XCD remap
+  }
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  // ---- x DMA: instruction i (0,1) of this wave fills LDS rows (wave*2+i)*16 .. +15 (64 B per row) ----------------
+  uint32_t avoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int R = (wave * 2 + i) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((R >> 2) & 3);
+    int64_t row = m0 + R;
+    if (row > M - 1) row = M - 1;
+    avoff[i] = (uint32_t)(((row - m0) * K + 8 * c) * 2);
+  }
+  const uint16_t* const xtile = x + m0 * K;
+  // ---- W: this thread's column, its two packed rows of a step --------------------------------------------------------
+  const int bcol = tid & 255, kwh = tid >> 8;
+  int64_t ncol = n0 + bcol;
+  if (ncol > N - 1) ncol = N - 1;
+  const uint32_t wvoff0 = (uint32_t)(((int64_t)(2 * kwh) * N + ncol) * 4), wvoff1 = wvoff0 + (uint32_t)(N * 4);
+  const uint32_t svoff = (uint32_t)(ncol * 2), zvoff = (uint32_t)((ncol >> 3) * 4);
+  const int zshift = 4 * (int)(ncol & 7);
+  const int bdst = (((bcol >> 5) * 2 + kwh) * 64 + (bcol & 31)) * 16;  // + 32*16 for the second word (k-octet 1)
+
+  const int nk = (int)(K / DK);
+  // six global requests of one step, all from asm: 2 x DMA (no VGPR result), 2 packed words, scale, zero word
+  auto issue_loads = [&](int kt, int stage, uint32_t& w0, uint32_t& w1, uint32_t& sb, uint32_t& zw) {
+    if (kt > nk - 1) kt = nk - 1;  // past-the-end steps re-fetch the last tile into a stage nobody reads again
+    const uint16_t* abase = xtile + (int64_t)kt * DK;
+    const uint32_t* wbase = qweight + (int64_t)kt * (DK / 8) * N;
+    const int64_t g = g_shift >= 0 ? (((int64_t)kt * DK) >> g_shift) : 0;
+    const uint16_t* sbase = scales + g * N;
+    const uint32_t* zbase = qzeros + g * NW;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * D_STAGE + wave * 2048);
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %4, m0\n\t"
+        "s_nop 4\n\t"
+        "s_mov_b32 m0, %11\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %10\n\t"
+        "s_add_u32 m0, %11, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, %10\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "global_load_dword %0, %7, %12\n\t"
+        "global_load_dword %1, %8, %12\n\t"
+        "global_load_ushort %2, %9, %13\n\t"
+        "global_load_dword %3, %14, %15"
+        : "=&v"(w0), "=&v"(w1), "=&v"(sb), "=&v"(zw), "=&s"(keep)
+        : "v"(avoff[0]), "v"(avoff[1]), "v"(wvoff0), "v"(wvoff1), "v"(svoff), "s"(abase), "s"(dst), "s"(wbase), "s"(sbase),
+          "v"(zvoff), "s"(zbase)
+        : "memory", "scc");
+  };
+  // `older` requests have landed once at most `n` remain in flight; ties the result registers to the wait
+  auto wait_loads6 = [&](uint32_t& w0, uint32_t& w1, uint32_t& sb, uint32_t& zw) {
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(w0), "+v"(w1), "+v"(sb), "+v"(zw) : : "memory");
+  };
+  auto stash = [&](int stage, uint32_t w0, uint32_t w1, uint32_t sb, uint32_t zw) {
+    const float sc = f16_bits_to_f32((uint16_t)sb);
+    uint32_t zz = ((zw >> zshift) & 15u) + 1u;  // modules.py:407-410
+    zz = zz > 15u ? 0u : zz;
+    const float nzs = -(float)zz * sc;
+    char* dst = smem + stage * D_STAGE + D_ASTAGE + bdst;
+    *reinterpret_cast<uint4*>(dst) = dequant8<IS_BF16>(w0, sc, nzs);
+    *reinterpret_cast<uint4*>(dst + 32 * 16) = dequant8<IS_BF16>(w1, sc, nzs);
+  };
+
+  f32x16 acc[2][4];  // [n-frag][m-frag]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int a_row = wm * 128 + (lane & 31);
+  const int a_sw = ((lane & 31) >> 2) & 3;  // (row >> 2) & 3: tile bases are multiples of 32
+  const int a_hi = lane >> 5;
+  const int b_off = (wn * 2 * 2 * 64 + lane) * 16;  // + (nf*2 + kk) * 1024
+  auto read_frags = [&](int stage, int kk, uint4 (&xa)[4], uint4 (&wb)[2]) {
+    const char* As = smem + stage * D_STAGE;
+    const char* Bs = As + D_ASTAGE + b_off;
+    const int chunk = ((2 * kk + a_hi) ^ a_sw) << 4;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) xa[mf] = *reinterpret_cast<const uint4*>(As + (a_row + 32 * mf) * 64 + chunk);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) wb[nf] = *reinterpret_cast<const uint4*>(Bs + (nf * 2 + kk) * 1024);
+  };
+  auto mma8 = [&](const uint4 (&xa)[4], const uint4 (&wb)[2]) {
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma32<IS_BF16>(wb[nf], xa[mf], acc[nf][mf]);
+  };
+
+  // ---- prologue: stages 0 and 1 complete, stage 2 in flight (x DMA issued, packed words in registers) ----------
+  uint32_t ra0, ra1, ras, raz;  // register set A: tiles with even index
+  uint32_t rb0, rb1, rbs, rbz;  // register set B: tiles with odd index
+  issue_loads(0, 0, ra0, ra1, ras, raz);
+  issue_loads(1, 1, rb0, rb1, rbs, rbz);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(ras), "+v"(raz), "+v"(rb0), "+v"(rb1), "+v"(rbs), "+v"(rbz) : : "memory");
+  stash(0, ra0, ra1, ras, raz);
+  stash(1, rb0, rb1, rbs, rbz);
+  issue_loads(2, 2, ra0, ra1, ras, raz);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  uint4 xa0[4], wb0[2], xa1[4], wb1[2];
+  read_frags(0, 0, xa0, wb0);
+
+  // ---- main loop, unrolled by 4 so that stage numbers and register sets are literals -----------------------------
+  // step t (stage s = t & 3): issue loads of tile t+3 into stage (s+3)&3 / the register set of parity (t+3)&1 = (t+1)&1,
+  // dequantise tile t+2 (set t&1) into stage (s+2)&3.
+  for (int t0 = 0; t0 < nk; t0 += 4) {
+#define INC_DEEP_STEP(S, LW0, LW1, LWS, LWZ, DW0, DW1, DWS, DWZ)                                   \
+    {                                                                                              \
+      issue_loads(t0 + (S) + 3, ((S) + 3) & 3, LW0, LW1, LWS, LWZ);                               \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+      read_frags((S), 1, xa1, wb1);                                                                \
+      mma8(xa0, wb0);                                                                              \
+      wait_loads6(DW0, DW1, DWS, DWZ);                                                             \
+      stash(((S) + 2) & 3, DW0, DW1, DWS, DWZ);                                                    \
+      read_frags(((S) + 1) & 3, 0, xa0, wb0);                                                      \
+      mma8(xa1, wb1);                                                                              \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+      __builtin_amdgcn_s_barrier();                                                                \
+    }
+    // even steps load into set B (tile t+3 is odd) and dequantise set A (tile t+2 is even); odd steps the reverse
+    INC_DEEP_STEP(0, rb0, rb1, rbs, rbz, ra0, ra1, ras, raz)
+    INC_DEEP_STEP(1, ra0, ra1, ras, raz, rb0, rb1, rbs, rbz)
+    INC_DEEP_STEP(2, rb0, rb1, rbs, rbz, ra0, ra1, ras, raz)
+    INC_DEEP_STEP(3, ra0, ra1, ras, raz, rb0, rb1, rbs, rbz)
+#undef INC_DEEP_STEP
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads must not outlive the workgroup's LDS
+
+  // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int64_t nb = n0 + wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (nb + e < N) bv[e] = cvt16<IS_BF16>(bias[nb + e]);
+      }
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
+        if (m >= M) continue;
+        const float v0 = acc[nf][mf][4 * rq + 0] + bv[0], v1 = acc[nf][mf][4 * rq + 1] + bv[1];
+        const float v2 = acc[nf][mf][4 * rq + 2] + bv[2], v3 = acc[nf][mf][4 * rq + 3] + bv[3];
+        uint16_t* dst = y + m * N + nb;
+        if (y_vec_ok && nb + 4 <= N) {
+          *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair<IS_BF16>(v0, v1), cvt_pair<IS_BF16>(v2, v3));
+        } else {
+          const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nb + e < N) dst[e] = IS_BF16 ? f32_to_bf16_bits(vv[e]) : f32_to_f16_bits(vv[e]);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // small-M (decode) kernel: M <= 16
 // =============================================================================================
 constexpr int SN = 64;  // columns per workgroup strip (16 lanes x 4 columns)
@@ -829,7 +1035,19 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   else if (group_size >= 32 && (group_size & (group_size - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < group_size) ++g_shift; }
   const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M >= 128 && N >= 64 &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
-  if (big_ok && !inc_force_small_tiles()) {
+  if (big_ok && (K % 128) == 0 && inc_small_tiles_flag(-1) == 0) {
+    const size_t smem = (size_t)4 * D_STAGE;  // 128 KiB
+    static bool deep_attr_set = false;
+    if (!deep_attr_set) {
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_deep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_deep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      deep_attr_set = true;
+    }
+    const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
+    const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
+    if (bf) woq_gemm_w4_deep_kernel<true><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+    else woq_gemm_w4_deep_kernel<false><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+  } else if (big_ok && !inc_force_small_tiles()) {
     const size_t smem = (size_t)2 * T_ASTAGE + 2 * T_BSTAGE;  // 128 KiB
     static bool big_attr_set = false;
     if (!big_attr_set) {

@@ -45,6 +45,39 @@ __device__ __forceinline__ void tri_decode(int idx, int nt, int& ti, int& tj) {
   tj = t + rem;
 }
 
+// Tile order for the 256x256 syrk: workgroup b runs on XCD b % 8 (private 4 MiB L2 each).  Give every XCD a
+// CONTIGUOUS run of the logical tile sequence (bijective remap), and make that sequence walk the upper triangle in
+// 8x8-tile super-tiles, so the ~32 tiles resident on one XCD at a time share <= 8 + 8 feature panels of X instead of
+// touching ~40 different ones: the panels are then re-read from that XCD's L2, not from HBM / Infinity Cache
+// (profiles/r1_pmc: 0.5-1 GB fetched per launch for 45 MB of X with the plain row-major order).
+__device__ __forceinline__ void xcd_supertile_decode(int b, int n, int nt, int& ti, int& tj) {
+  const int q = n / 8, r = n % 8, xcd = b % 8, t = b / 8;
+  int rem = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + t;  // logical index
+  constexpr int S = 8;
+  const int ns = (nt + S - 1) / S;
+  for (int si = 0; si < ns; ++si) {
+    const int h = min(S, nt - si * S);
+    for (int sj = si; sj < ns; ++sj) {
+      const int w = min(S, nt - sj * S);
+      const int count = si == sj ? h * (h + 1) / 2 : h * w;
+      if (rem < count) {
+        if (si != sj) {
+          ti = si * S + rem / w;
+          tj = sj * S + rem % w;
+        } else {
+          int row = 0;
+          while (rem >= h - row) { rem -= h - row; ++row; }
+          ti = si * S + row;
+          tj = si * S + row + rem;
+        }
+        return;
+      }
+      rem -= count;
+    }
+  }
+  ti = tj = 0;  // unreachable for b < n
+}
+
 // one thread's 8(token) x 8(feature) block of X, zero-filled out of range
 __device__ __forceinline__ void load_block8x8(const uint16_t* __restrict__ x, int64_t T, int64_t K,
                                               int64_t ldx, int64_t t0, int64_t f0, bool vec,
@@ -225,7 +258,7 @@ __global__ __launch_bounds__(512) void hessian_syrk_16bit_256_kernel(const uint1
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint16_t* smem = reinterpret_cast<uint16_t*>(smem_raw);
   int ti, tj;
-  tri_decode(blockIdx.x, nt, ti, tj);
+  xcd_supertile_decode(blockIdx.x, gridDim.x, nt, ti, tj);
   const int64_t i0 = (int64_t)ti * H2, j0 = (int64_t)tj * H2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;

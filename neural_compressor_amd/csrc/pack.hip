@@ -339,7 +339,7 @@ int inc_small_tiles_flag(int set_to) {
 }
 
 extern "C" {
-void inc_debug_set_small_tiles(int on) { (void)inc_small_tiles_flag(on ? 1 : 0); }
+void inc_debug_set_small_tiles(int on) { (void)inc_small_tiles_flag(on < 0 ? 0 : on); }
 
 
 int inc_abi_version(void) { return 1; }

@@ -196,7 +196,11 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
          ok ? "OK" : "FAIL");
   if (time_it) {
     Timer t;
-    for (int mode = 0; mode < 2; ++mode) {
+    const int modes[3] = {0, 2, 1};
+    const char* labels[3] = {"fast path", "256^2 two-stage", "first-gen tiling"};
+    for (int mi = 0; mi < 3; ++mi) {
+      const int mode = modes[mi];
+      if (mode == 2 && M <= 16) continue;
       inc_debug_set_small_tiles(mode);
       for (int i = 0; i < 3; ++i)
         INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
@@ -207,7 +211,7 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
       const float ms = t.stop_ms() / iters;
       const double flops = 2.0 * M * N * K;
       const double bytes = (double)N * K / 2 + (double)W.G * N * 2 + (double)W.G * (N / 8) * 4 + (double)M * K * 2 + (double)M * N * 2;
-      printf("  %-22s %9.4f ms  %8.1f TFLOP/s  %8.1f GB/s\n", mode ? "first-gen tiling" : "fast path", ms, flops / ms / 1e9, bytes / ms / 1e6);
+      printf("  %-22s %9.4f ms  %8.1f TFLOP/s  %8.1f GB/s\n", labels[mi], ms, flops / ms / 1e9, bytes / ms / 1e6);
     }
     inc_debug_set_small_tiles(0);
   }
