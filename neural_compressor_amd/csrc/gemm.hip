@@ -303,21 +303,34 @@ __device__ __forceinline__ uint32_t cvt_pair(float a, float b) {
   return r;
 }
 
-// 8 nibbles of `w` -> 8 x rn16((q - z) * s), k-ordered, as 4 dwords.  fma(q, s, -z*s) is exact in
-// fp32 (q, z < 32 and s has 11 significant bits), so the single rounding is the 16-bit conversion.
+// 8 nibbles of `w` -> 8 x rn16((q - z) * s), k-ordered, as 4 dwords.
+// int -> float goes through the fp8 converter: an e4m3 byte with value q in 0..15 decodes to q * u (u = 2^-9 for the
+// OCP format of gfx950: codes 0..7 are subnormals m * 2^-9, codes 8..15 are (1 + m/8) * 2^-6 = (8 + m) * 2^-9), so ONE
+// v_cvt_pk_f32_fp8 turns two nibbles (bytes of `w & 0x0F0F0F0F`) into two floats -- 4 instead of 8 conversions per word.
+// `s_over_u` = s / u (exact: a power-of-two rescale); fma(q*u, s/u, -z*s) is exact in fp32 (q, z < 32 and s has 11
+// significant bits), so the single rounding is the 16-bit conversion: bit-identical to inc_woq_dequant.
+__device__ __forceinline__ float fp8_unit_inverse() {
+  return 1.0f / __builtin_amdgcn_cvt_pk_f32_fp8(0x00000001, false)[0];  // measured, not assumed: 2^9 on gfx950
+}
 template <bool IS_BF16>
-__device__ __forceinline__ uint4 dequant8(uint32_t w, float s, float nzs) {
-  uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
-  asm volatile("" : "+v"(lo), "+v"(hi));  // keep the byte form: v_cvt_f32_ubyteN reads it directly
+__device__ __forceinline__ uint4 dequant8(uint32_t w, float s_over_u, float nzs) {
+  const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;  // bytes: k0,k2,k4,k6 / k1,k3,k5,k7
+  const f32x2 sv = {s_over_u, s_over_u}, nv = {nzs, nzs};
+  const f32x2 e01 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), sv, nv);  // k0, k2
+  const f32x2 e23 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true), sv, nv);   // k4, k6
+  const f32x2 o01 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), sv, nv);  // k1, k3
+  const f32x2 o23 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true), sv, nv);   // k5, k7
   uint4 o;
-  o.x = cvt_pair<IS_BF16>(fmaf((float)(lo & 0xffu), s, nzs), fmaf((float)(hi & 0xffu), s, nzs));
-  o.y = cvt_pair<IS_BF16>(fmaf((float)((lo >> 8) & 0xffu), s, nzs), fmaf((float)((hi >> 8) & 0xffu), s, nzs));
-  o.z = cvt_pair<IS_BF16>(fmaf((float)((lo >> 16) & 0xffu), s, nzs), fmaf((float)((hi >> 16) & 0xffu), s, nzs));
-  o.w = cvt_pair<IS_BF16>(fmaf((float)(lo >> 24), s, nzs), fmaf((float)(hi >> 24), s, nzs));
+  o.x = cvt_pair<IS_BF16>(e01[0], o01[0]);
+  o.y = cvt_pair<IS_BF16>(e01[1], o01[1]);
+  o.z = cvt_pair<IS_BF16>(e23[0], o23[0]);
+  o.w = cvt_pair<IS_BF16>(e23[1], o23[1]);
   return o;
 }
 
-template <bool IS_BF16>
+// ABL != 0: timing-only ablations for tools/kbench (results are WRONG): 1 = no dequant arithmetic, 2 = x fragments read
+// once per K-step, 3 = no global traffic inside the K-loop, 4 = no MFMA
+template <bool IS_BF16, int ABL = 0>
 __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
     const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
@@ -340,6 +353,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float inv_u = fp8_unit_inverse();
   const int wm = wave >> 2, wn = wave & 3;
 
   // ---- x staging (LDS-DMA): instruction i of this wave fills LDS rows (wave*4+i)*8 .. +7 -------
@@ -377,11 +391,19 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
     zw = qzeros[g * NW + zcol];
   };
   auto stash_regs = [&](int stage, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint16_t sb, uint32_t zword) {
-    const float sc = f16_bits_to_f32(sb);
+    const float sc0 = f16_bits_to_f32(sb);
     uint32_t zz = ((zword >> zshift) & 15u) + 1u;  // modules.py:407-410 (stored zp-1; wraps above 15)
     zz = zz > 15u ? 0u : zz;
-    const float nzs = -(float)zz * sc;
+    const float nzs = -(float)zz * sc0;
+    const float sc = sc0 * inv_u;
     char* dst = Bbase + stage * T_BSTAGE + bdst0;
+    if constexpr (ABL == 1) {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(w0, w1, w2, w3);
+      *reinterpret_cast<uint4*>(dst + 32 * 16) = make_uint4(w1, w2, w3, w0);
+      *reinterpret_cast<uint4*>(dst + 64 * 16) = make_uint4(w2, w3, w0, w1);
+      *reinterpret_cast<uint4*>(dst + (64 + 32) * 16) = make_uint4(w3, w0, w1, __float_as_uint(nzs));
+      return;
+    }
     *reinterpret_cast<uint4*>(dst) = dequant8<IS_BF16>(w0, sc, nzs);                    // kk = 2*kwh,   k-octet 0
     *reinterpret_cast<uint4*>(dst + 32 * 16) = dequant8<IS_BF16>(w1, sc, nzs);          //               k-octet 1
     *reinterpret_cast<uint4*>(dst + 64 * 16) = dequant8<IS_BF16>(w2, sc, nzs);          // kk = 2*kwh+1, k-octet 0
@@ -415,17 +437,28 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
   const int a_hi = lane >> 5;                        // chunk = 2*kk + a_hi
   const int b_off = (wn * 2 * 4 * 64 + lane) * 16;   // + (nf*4 + kk) * 1024
 
+  uint4 xa_keep[4];
   auto mma_step = [&](const char* As, const char* Bs, int kk) {
     uint4 xa[4], wb[2];
     const int chunk = ((2 * kk + a_hi) ^ a_sw) << 4;
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf) xa[mf] = *reinterpret_cast<const uint4*>(As + (a_row + 32 * mf) * 128 + chunk);
+    for (int mf = 0; mf < 4; ++mf) {
+      if (ABL == 2 && kk != 0) xa[mf] = xa_keep[mf];
+      else xa[mf] = *reinterpret_cast<const uint4*>(As + (a_row + 32 * mf) * 128 + chunk);
+      if (ABL == 2 && kk == 0) xa_keep[mf] = xa[mf];
+    }
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) wb[nf] = *reinterpret_cast<const uint4*>(Bs + (nf * 4 + kk) * 1024);
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma32<IS_BF16>(wb[nf], xa[mf], acc[nf][mf]);
+      for (int mf = 0; mf < 4; ++mf) {
+        if constexpr (ABL == 4) {
+          acc[nf][mf][0] += __uint_as_float(wb[nf].x ^ xa[mf].y);  // keeps the fragment reads alive without the matrix pipe
+        } else {
+          acc[nf][mf] = mfma32<IS_BF16>(wb[nf], xa[mf], acc[nf][mf]);
+        }
+      }
   };
 
   // Two-stage pipeline, one barrier per K-tile.  In iteration kt the LDS-DMA of x tile kt+1 and the
@@ -445,16 +478,41 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
     const char* As = Abase + cur * T_ASTAGE;
     const char* Bs = Bbase + cur * T_BSTAGE + b_off;
     settle_w();
-    dma_x(kt + 1, cur ^ 1);
+    if (ABL != 3) dma_x(kt + 1, cur ^ 1);
     const uint32_t r0 = raw[0], r1 = raw[1], r2 = raw[2], r3 = raw[3], zcur = zw;
     const uint16_t scur = scb;
-    load_w(kt + 2 < nk ? kt + 2 : nk - 1);   // in flight for the whole K-step
+    if (ABL != 3) load_w(kt + 2 < nk ? kt + 2 : nk - 1);   // in flight for the whole K-step
     __builtin_amdgcn_sched_barrier(0);        // keep the loads up here (hipcc would sink them to their use)
+    if constexpr (ABL == 5 || ABL == 6) {
+      // one packed word per k16 group: ~19 VALU + 1 ds_write next to each group of 8 MFMAs instead of 76 VALU next to
+      // the first group (the matrix pipe starves while a wave issues a long VALU run: both waves of a SIMD are in the
+      // same phase, profiles/r1_pmc ablation)
+      const float sc0 = f16_bits_to_f32(scur);
+      uint32_t zz = ((zcur >> zshift) & 15u) + 1u;
+      zz = zz > 15u ? 0u : zz;
+      const float nzs = -(float)zz * sc0;
+      const float sc = sc0 * inv_u;
+      char* dst = Bbase + (cur ^ 1) * T_BSTAGE + bdst0;
+      const uint32_t rw[4] = {r0, r1, r2, r3};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        mma_step(As, Bs, kk);
+        *reinterpret_cast<uint4*>(dst + ((kk >> 1) * 64 + 32 * (kk & 1)) * 16) = dequant8<IS_BF16>(rw[kk], sc, nzs);
+        if constexpr (ABL == 6) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // 3 VALU
+          }
+        }
+      }
+    } else {
     mma_step(As, Bs, 0);
     stash_regs(cur ^ 1, r0, r1, r2, r3, scur, zcur);
     mma_step(As, Bs, 1);
     mma_step(As, Bs, 2);
     mma_step(As, Bs, 3);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -518,7 +576,7 @@ constexpr int D_ASTAGE = TM * DK * 2;       // 16 KiB
 constexpr int D_BSTAGE = TN * DK * 2;       // 16 KiB
 constexpr int D_STAGE = D_ASTAGE + D_BSTAGE;
 
-template <bool IS_BF16>
+template <bool IS_BF16, int VAR>
 __global__ __launch_bounds__(512) void woq_gemm_w4_deep_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
     const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
@@ -537,6 +595,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_deep_kernel(
   const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float inv_u = fp8_unit_inverse();
   const int wm = wave >> 2, wn = wave & 3;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
@@ -595,10 +654,11 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_deep_kernel(
     asm volatile("s_waitcnt vmcnt(6)" : "+v"(w0), "+v"(w1), "+v"(sb), "+v"(zw) : : "memory");
   };
   auto stash = [&](int stage, uint32_t w0, uint32_t w1, uint32_t sb, uint32_t zw) {
-    const float sc = f16_bits_to_f32((uint16_t)sb);
+    const float sc0 = f16_bits_to_f32((uint16_t)sb);
     uint32_t zz = ((zw >> zshift) & 15u) + 1u;  // modules.py:407-410
     zz = zz > 15u ? 0u : zz;
-    const float nzs = -(float)zz * sc;
+    const float nzs = -(float)zz * sc0;
+    const float sc = sc0 * inv_u;
     char* dst = smem + stage * D_STAGE + D_ASTAGE + bdst;
     *reinterpret_cast<uint4*>(dst) = dequant8<IS_BF16>(w0, sc, nzs);
     *reinterpret_cast<uint4*>(dst + 32 * 16) = dequant8<IS_BF16>(w1, sc, nzs);
@@ -656,6 +716,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_deep_kernel(
       __builtin_amdgcn_sched_barrier(0);                                                           \
       read_frags((S), 1, xa1, wb1);                                                                \
       mma8(xa0, wb0);                                                                              \
+      if (VAR >= 1) __builtin_amdgcn_sched_barrier(0); /* the 8 MFMAs above are issued BEFORE the wait */ \
       wait_loads6(DW0, DW1, DWS, DWZ);                                                             \
       stash(((S) + 2) & 3, DW0, DW1, DWS, DWZ);                                                    \
       read_frags(((S) + 1) & 3, 0, xa0, wb0);                                                      \
@@ -671,6 +732,207 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_deep_kernel(
 #undef INC_DEEP_STEP
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads must not outlive the workgroup's LDS
+
+  // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int64_t nb = n0 + wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (nb + e < N) bv[e] = cvt16<IS_BF16>(bias[nb + e]);
+      }
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
+        if (m >= M) continue;
+        const float v0 = acc[nf][mf][4 * rq + 0] + bv[0], v1 = acc[nf][mf][4 * rq + 1] + bv[1];
+        const float v2 = acc[nf][mf][4 * rq + 2] + bv[2], v3 = acc[nf][mf][4 * rq + 3] + bv[3];
+        uint16_t* dst = y + m * N + nb;
+        if (y_vec_ok && nb + 4 <= N) {
+          *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair<IS_BF16>(v0, v1), cvt_pair<IS_BF16>(v2, v3));
+        } else {
+          const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nb + e < N) dst[e] = IS_BF16 ? f32_to_bf16_bits(vv[e]) : f32_to_f16_bits(vv[e]);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// large-M path "3A2B" (4-bit, K % 128 == 0): 256x256x64 tile, THREE x stages + TWO W stages = all 160 KiB of LDS
+// =============================================================================================
+// Ablations (tools/kbench ablate, profiles/r1f): with two stages the DMA of x tile t+1 is issued at the start of step t
+// and must have landed at its end, so a step can never be shorter than one loaded HBM/L2 round trip (~1.4 us measured
+// against ~0.9 us of MFMA work) -- removing the global traffic alone gives +15-25 %, a deeper pipeline with shorter steps
+// does not help because its loads still have only ~one round trip to land.  Here the x DMA runs TWO steps ahead (three 32
+// KiB stages), the packed W words (8 KiB per step: registers are enough) also two steps ahead, and the dequantised W keeps
+// its two 32 KiB stages: 3*32 + 2*32 = 160 KiB, exactly one CU's LDS.  All loop traffic is issued from asm and retired
+// with counted waits: per step a wave issues 6 W requests then 4 DMAs; `vmcnt(14)` before the dequantisation leaves
+// the previous step's 4 DMAs + this step's 10 requests in flight, `vmcnt(10)` before the barrier retires those 4 DMAs.
+// The dequantisation is spread over the four k16 groups (one packed word next to each 8 MFMAs).
+template <bool IS_BF16>
+__global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
+    const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
+    const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int64_t M, int64_t N, int64_t K,
+    int64_t NW, int g_shift, int y_vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abase = smem;                 // 3 stages
+  char* const Bbase = smem + 3 * T_ASTAGE;  // 2 stages
+  const int tiles_n = (int)((N + TN - 1) / TN);
+  const int tiles_m = (int)((M + TM - 1) / TM);
+  const int nwg = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective XCD remap
+  }
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float inv_u = fp8_unit_inverse();
+  const int wm = wave >> 2, wn = wave & 3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  uint32_t avoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int R = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    int64_t row = m0 + R;
+    if (row > M - 1) row = M - 1;
+    avoff[i] = (uint32_t)(((row - m0) * K + 8 * c) * 2);
+  }
+  const uint16_t* const xtile = x + m0 * K;
+  const int bcol = tid & 255, kwh = tid >> 8;
+  int64_t ncol = n0 + bcol;
+  if (ncol > N - 1) ncol = N - 1;
+  uint32_t wvoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wvoff[j] = (uint32_t)(((int64_t)(4 * kwh + j) * N + ncol) * 4);
+  const uint32_t svoff = (uint32_t)(ncol * 2), zvoff = (uint32_t)((ncol >> 3) * 4);
+  const int zshift = 4 * (int)(ncol & 7);
+  const int bdst0 = (((bcol >> 5) * 4 + 2 * kwh) * 64 + (bcol & 31)) * 16;
+  const int kwh_s = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int nk = (int)(K / TK);
+
+  // one step's requests: 6 for W (4 packed words, scale, zero word) FIRST, then 4 x DMAs
+  auto issue_w = [&](int kt, uint32_t (&w)[4], uint32_t& sb, uint32_t& zw) {
+    if (kt > nk - 1) kt = nk - 1;
+    const uint32_t* wbase = qweight + (int64_t)kt * (TK / 8) * N;
+    const int64_t g = g_shift >= 0 ? (((int64_t)kt * TK + 32 * kwh_s) >> g_shift) : 0;  // wave-uniform (kwh is)
+    const uint16_t* sbase = scales + g * N;
+    const uint32_t* zbase = qzeros + g * NW;
+    asm volatile(
+        "s_nop 4\n\t"
+        "global_load_dword %0, %6, %12\n\t"
+        "global_load_dword %1, %7, %12\n\t"
+        "global_load_dword %2, %8, %12\n\t"
+        "global_load_dword %3, %9, %12\n\t"
+        "global_load_ushort %4, %10, %13\n\t"
+        "global_load_dword %5, %11, %14"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(sb), "=&v"(zw)
+        : "v"(wvoff[0]), "v"(wvoff[1]), "v"(wvoff[2]), "v"(wvoff[3]), "v"(svoff), "v"(zvoff), "s"(wbase), "s"(sbase), "s"(zbase)
+        : "memory");
+  };
+  auto issue_dma = [&](int kt, int astage) {
+    if (kt > nk - 1) kt = nk - 1;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + astage * T_ASTAGE + wave * 4096);
+    lds_dma_4x1k(xtile + (int64_t)kt * TK, dst, avoff[0], avoff[1], avoff[2], avoff[3]);
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int a_row = wm * 128 + (lane & 31);
+  const int a_sw = ((lane & 31) >> 1) & 7;
+  const int a_hi = lane >> 5;
+  const int b_off = (wn * 2 * 4 * 64 + lane) * 16;
+  auto mma_step = [&](const char* As, const char* Bs, int kk) {
+    uint4 xa[4], wb[2];
+    const int chunk = ((2 * kk + a_hi) ^ a_sw) << 4;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) xa[mf] = *reinterpret_cast<const uint4*>(As + (a_row + 32 * mf) * 128 + chunk);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) wb[nf] = *reinterpret_cast<const uint4*>(Bs + (nf * 4 + kk) * 1024);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma32<IS_BF16>(wb[nf], xa[mf], acc[nf][mf]);
+  };
+  auto dequant_into = [&](int bstage, int kk, uint32_t word, float sc, float nzs) {
+    char* dst = Bbase + bstage * T_BSTAGE + bdst0;
+    *reinterpret_cast<uint4*>(dst + ((kk >> 1) * 64 + 32 * (kk & 1)) * 16) = dequant8<IS_BF16>(word, sc, nzs);
+  };
+  auto group_params = [&](uint32_t sb, uint32_t zw, float& sc, float& nzs) {
+    const float sc0 = f16_bits_to_f32((uint16_t)sb);
+    uint32_t zz = ((zw >> zshift) & 15u) + 1u;  // modules.py:407-410
+    zz = zz > 15u ? 0u : zz;
+    nzs = -(float)zz * sc0;
+    sc = sc0 * inv_u;
+  };
+
+  // ---- prologue: x stage 0 and W stage 0 complete; queue = [W words of tile 1 (6), DMA of x tile 1 (4)] ---------------
+  uint32_t wa[4], wsa, wza;  // W register set A: tiles with ODD index
+  uint32_t wb_[4], wsb, wzb; // W register set B: tiles with EVEN index >= 2
+  {
+    uint32_t w0[4], s0, z0;
+    issue_w(0, w0, s0, z0);
+    issue_dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(s0), "+v"(z0) : : "memory");
+    float sc, nzs;
+    group_params(s0, z0, sc, nzs);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) dequant_into(0, kk, w0[kk], sc, nzs);
+  }
+  issue_w(1, wa, wsa, wza);
+  issue_dma(1, 1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // step t: x stage t%3, W stage t&1.  Issues W words of tile t+2 and the DMA of x tile t+2 (stage (t+2)%3), dequantises
+  // tile t+1 (words issued in step t-1) into W stage (t+1)&1.
+#define INC_3A2B_STEP(T, LW, LWS, LWZ, DW, DWS, DWZ)                                                              \
+  {                                                                                                                \
+    const int t_ = (T);                                                                                            \
+    const int as_ = t_ % 3, bs_ = t_ & 1;                                                                          \
+    issue_w(t_ + 2, LW, LWS, LWZ);                                                                                 \
+    issue_dma(t_ + 2, (t_ + 2) % 3);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    const char* As = Abase + as_ * T_ASTAGE;                                                                       \
+    const char* Bs = Bbase + bs_ * T_BSTAGE + b_off;                                                               \
+    mma_step(As, Bs, 0);                                                                                           \
+    asm volatile("s_waitcnt vmcnt(14)" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory"); \
+    float sc_, nzs_;                                                                                               \
+    group_params(DWS, DWZ, sc_, nzs_);                                                                             \
+    dequant_into(bs_ ^ 1, 0, DW[0], sc_, nzs_);                                                                    \
+    mma_step(As, Bs, 1);                                                                                           \
+    dequant_into(bs_ ^ 1, 1, DW[1], sc_, nzs_);                                                                    \
+    mma_step(As, Bs, 2);                                                                                           \
+    dequant_into(bs_ ^ 1, 2, DW[2], sc_, nzs_);                                                                    \
+    mma_step(As, Bs, 3);                                                                                           \
+    dequant_into(bs_ ^ 1, 3, DW[3], sc_, nzs_);                                                                    \
+    asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+  }
+  for (int t0 = 0; t0 < nk; t0 += 2) {
+    INC_3A2B_STEP(t0, wb_, wsb, wzb, wa, wsa, wza)        // even step: load tile t+2 (even) -> set B, dequantise tile t+1 (odd) <- set A
+    INC_3A2B_STEP(t0 + 1, wa, wsa, wza, wb_, wsb, wzb)    // odd step: the reverse
+  }
+#undef INC_3A2B_STEP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
 #pragma unroll
@@ -852,6 +1114,7 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
     int64_t G, int g_shift, int splitk) {
   __shared__ float red[4 * 16 * 65];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float inv_u = fp8_unit_inverse();
   const int strip = blockIdx.x, slice = blockIdx.y;
   const int jn = lane & 15, oct = lane >> 4;
   const int64_t n0 = (int64_t)strip * 64;
@@ -914,7 +1177,7 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
       const float sc = f16_bits_to_f32((uint16_t)(sw[c >> 1] >> (16 * (c & 1))));
       uint32_t zz = ((zraw[gi] >> (zsh + 4 * c)) & 15u) + 1u;
       zz = zz > 15u ? 0u : zz;
-      const uint4 b = dequant8<IS_BF16>(ww[c], sc, -(float)zz * sc);
+      const uint4 b = dequant8<IS_BF16>(ww[c], sc * inv_u, -(float)zz * sc);
       acc[c] = mfma16<IS_BF16>(av, b, acc[c]);
     }
   }
@@ -1036,17 +1299,34 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M >= 128 && N >= 64 &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
   if (big_ok && (K % 128) == 0 && inc_small_tiles_flag(-1) == 0) {
-    const size_t smem = (size_t)4 * D_STAGE;  // 128 KiB
-    static bool deep_attr_set = false;
-    if (!deep_attr_set) {
-      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_deep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_deep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      deep_attr_set = true;
+    const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
+    static bool a3_attr_set = false;
+    if (!a3_attr_set) {
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      a3_attr_set = true;
     }
     const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
     const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
-    if (bf) woq_gemm_w4_deep_kernel<true><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
-    else woq_gemm_w4_deep_kernel<false><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+    if (bf) woq_gemm_w4_3a2b_kernel<true><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+    else woq_gemm_w4_3a2b_kernel<false><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+  } else if (big_ok && bf && (K % 128) == 0 && inc_small_tiles_flag(-1) == 3) {  // experiment kept for A/B: 4 x 32 KiB stages, BK = 32
+    const size_t smem = (size_t)4 * D_STAGE;
+    (void)hipFuncSetAttribute((const void*)woq_gemm_w4_deep_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
+    const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
+    woq_gemm_w4_deep_kernel<true, 0><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+  } else if (big_ok && bf && inc_small_tiles_flag(-1) >= 11 && inc_small_tiles_flag(-1) <= 16) {  // timing-only ablations / experiments
+    const size_t smem = (size_t)2 * T_ASTAGE + 2 * T_BSTAGE;
+    const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
+    const int abl = inc_small_tiles_flag(-1) - 10;
+#define INC_ABL(A)                                                                                                            \
+    {                                                                                                                         \
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_big_kernel<true, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+      woq_gemm_w4_big_kernel<true, A><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, 1);          \
+    }
+    if (abl == 1) INC_ABL(1) else if (abl == 2) INC_ABL(2) else if (abl == 3) INC_ABL(3) else if (abl == 4) INC_ABL(4) else if (abl == 5) INC_ABL(5) else INC_ABL(6)
+#undef INC_ABL
   } else if (big_ok && !inc_force_small_tiles()) {
     const size_t smem = (size_t)2 * T_ASTAGE + 2 * T_BSTAGE;  // 128 KiB
     static bool big_attr_set = false;

@@ -175,7 +175,7 @@ _ws_cache = {}
 
 
 def _workspace(dev, nbytes):
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)  # one workspace per (device, stream): see header
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         # zero-filled: the first 16 KiB are the split-K arrival counters of the M <= 16 kernel, which must be zero on
@@ -185,26 +185,45 @@ def _workspace(dev, nbytes):
     return buf
 
 
+_ws_bytes_cache = {}
+
+
 def woq_gemm(x2d, qweight, scales, qzeros, bias, N, K, group_size, bits, g_idx=None):
-    """y[M,N] = x[M,K] @ dequant(qweight)^T + bias, fused (== INCWeightOnlyLinear.forward, modules.py:594-610)."""
-    dev = _dev(x2d, qweight, scales, qzeros, bias, g_idx)
-    if x2d.dtype not in (torch.bfloat16, torch.float16):
+    """y[M,N] = x[M,K] @ dequant(qweight)^T + bias, fused (== INCWeightOnlyLinear.forward, modules.py:594-610).
+
+    This is the decode-path entry (M = 1 runs in ~8 us on the GPU), so the host side is kept lean: argument checks are
+    attribute reads, the workspace size is memoised, and the device guard is only entered when the tensor's device is
+    not already current."""
+    dev = x2d.device
+    if dev.type != "cuda" or qweight.device != dev or not x2d.is_contiguous():
+        _dev(x2d, qweight, scales, qzeros, bias, g_idx)  # raises the descriptive error
+    if x2d.dtype is not torch.bfloat16 and x2d.dtype is not torch.float16:
         raise TypeError("woq_gemm computes in bf16 or fp16")
     if bias is not None and bias.dtype != x2d.dtype:
         bias = bias.to(x2d.dtype)
     M = x2d.shape[0]
     G = scales.shape[0]
     y = torch.empty((M, N), dtype=x2d.dtype, device=dev)
-    nbytes = lib.inc_woq_gemm_workspace_bytes(M, N, K)
-    ws = _workspace(dev, nbytes) if nbytes > 0 else None
-    with torch.cuda.device(dev):
-        check(
-            lib.inc_woq_gemm(
-                _ptr(x2d), dtype_code(x2d.dtype), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(g_idx), _ptr(bias),
-                _ptr(y), M, N, K, G, group_size, bits, _ptr(ws), 0 if ws is None else ws.numel(), _stream(),
-            ),
-            "inc_woq_gemm",
-        )
+    ws, nbytes = None, 0
+    if M <= 16:
+        key = (M, N, K)
+        nbytes = _ws_bytes_cache.get(key)
+        if nbytes is None:
+            nbytes = _ws_bytes_cache[key] = lib.inc_woq_gemm_workspace_bytes(M, N, K)
+        ws = _workspace(dev, nbytes)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    args = (
+        x2d.data_ptr(), INC_BF16 if x2d.dtype is torch.bfloat16 else INC_F16, qweight.data_ptr(), scales.data_ptr(),
+        qzeros.data_ptr(), _ptr(g_idx), _ptr(bias), y.data_ptr(), M, N, K, G, group_size, bits, _ptr(ws),
+        0 if ws is None else ws.numel(), stream,
+    )
+    if torch.cuda.current_device() == dev.index:
+        rc = lib.inc_woq_gemm(*args)
+    else:
+        with torch.cuda.device(dev):
+            rc = lib.inc_woq_gemm(*args)
+    if rc != 0:
+        check(rc, "inc_woq_gemm")
     return y
 
 

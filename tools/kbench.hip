@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -195,23 +196,34 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
          (long)M, (long)N, (long)K, gs, sym ? "sym" : "asym", with_bias ? "+bias" : "", rel_old, (long)big, check_rows, rel_ref, maxabs,
          ok ? "OK" : "FAIL");
   if (time_it) {
+    // interleaved rounds (the first variant timed after an idle gap runs at lower clocks: single back-to-back timings were
+    // biased by ~8 %): every round times every variant, rotating the order; the median over rounds is reported
     Timer t;
-    const int modes[3] = {0, 2, 1};
-    const char* labels[3] = {"fast path", "256^2 two-stage", "first-gen tiling"};
-    for (int mi = 0; mi < 3; ++mi) {
-      const int mode = modes[mi];
-      if (mode == 2 && M <= 16) continue;
-      inc_debug_set_small_tiles(mode);
-      for (int i = 0; i < 3; ++i)
+    const int modes[4] = {0, 3, 2, 1};
+    const char* labels[4] = {"fast path (3A2B)", "deep (4x32K, BK=32)", "256^2 two-stage", "first-gen tiling"};
+    const int nv = 4, rounds = 5, iters = M <= 16 ? 100 : 8;
+    std::vector<std::vector<float>> ms(nv);
+    for (int i = 0; i < 10; ++i)  // warm the clocks
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+    for (int r = 0; r < rounds; ++r)
+      for (int vi = 0; vi < nv; ++vi) {
+        const int mi = (vi + r) % nv, mode = modes[mi];
+        if ((mode == 2 || mode == 3) && M <= 16) continue;
+        inc_debug_set_small_tiles(mode);
         INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
-      const int iters = M <= 16 ? 200 : 20;
-      t.start();
-      for (int i = 0; i < iters; ++i)
-        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
-      const float ms = t.stop_ms() / iters;
-      const double flops = 2.0 * M * N * K;
-      const double bytes = (double)N * K / 2 + (double)W.G * N * 2 + (double)W.G * (N / 8) * 4 + (double)M * K * 2 + (double)M * N * 2;
-      printf("  %-22s %9.4f ms  %8.1f TFLOP/s  %8.1f GB/s\n", labels[mi], ms, flops / ms / 1e9, bytes / ms / 1e6);
+        t.start();
+        for (int i = 0; i < iters; ++i)
+          INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+        ms[mi].push_back(t.stop_ms() / iters);
+      }
+    const double flops = 2.0 * M * N * K;
+    const double bytes = (double)N * K / 2 + (double)W.G * N * 2 + (double)W.G * (N / 8) * 4 + (double)M * K * 2 + (double)M * N * 2;
+    for (int mi = 0; mi < nv; ++mi) {
+      if (ms[mi].empty()) continue;
+      std::sort(ms[mi].begin(), ms[mi].end());
+      const float med = ms[mi][ms[mi].size() / 2], best = ms[mi][0];
+      printf("  %-22s median %9.4f ms %8.1f TFLOP/s %8.1f GB/s   (best %9.4f ms %8.1f TFLOP/s)\n", labels[mi], med, flops / med / 1e9,
+             bytes / med / 1e6, best, flops / best / 1e9);
     }
     inc_debug_set_small_tiles(0);
   }
@@ -468,6 +480,28 @@ int main(int argc, char** argv) {
     }
     HIPCHECK(hipDeviceSynchronize());
     printf("prof workload done\n");
+  }
+  if (what == "ablate") {  // timing-only ablations of the two-stage dequant-GEMM (outputs are wrong by construction)
+    const int64_t M = 4096, N = 4096, K = 4096;
+    Packed W(N, K, 128, true);
+    DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
+    std::vector<uint16_t> hx(x.n);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    x.upload(hx);
+    const int modes[10] = {2, 2, 15, 16, 2, 15, 16, 11, 13, 14};
+    const char* labels[10] = {"two-stage (warm-up)", "two-stage (baseline)", "dequant spread (exact)", "spread + sched groups", "two-stage (again)", "dequant spread (again)", "spread + groups (again)", "- dequant arithmetic", "- global traffic", "- MFMA"};
+    Timer t;
+    for (int mi = 0; mi < 10; ++mi) {
+      inc_debug_set_small_tiles(modes[mi]);
+      for (int i = 0; i < 3; ++i)
+        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+      t.start();
+      for (int i = 0; i < 20; ++i)
+        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+      const float ms = t.stop_ms() / 20;
+      printf("ABLATE %-24s %8.4f ms  (%7.1f TFLOP/s equivalent)\n", labels[mi], ms, 2.0 * M * N * K / ms / 1e9);
+    }
+    inc_debug_set_small_tiles(0);
   }
   if (what == "probe") run_probe();
   printf("kbench: %d failing case(s)\n", fails);
