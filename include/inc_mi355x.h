@@ -114,7 +114,9 @@ int inc_dequant_ints(const int16_t* int_weight, const void* scales, int scale_dt
  *   The library picks the kernel itself: 256x256x64 LDS-DMA tile kernel (4-bit, M >= 128, K % 64 == 0,
  *   power-of-two group_size >= 32 or one group), split-K MFMA GEMV (M <= 16), or the generic 128x128
  *   tile kernel for everything else.
- *   `workspace` (inc_woq_gemm_workspace_bytes; 0 bytes when M > 16) is only touched when M <= 16:
+ *   `workspace` (inc_woq_gemm_workspace_bytes bytes; may be 0).  Medium M (fewer 256x256 tiles than CUs): fp32
+ *   split-K slabs, summed in a fixed order by a second small kernel; without a workspace the call still works,
+ *   single pass.  M <= 16:
  *   its first 16 KiB hold the per-strip arrival counters of the in-kernel split-K reduction and MUST BE
  *   ZERO when the workspace is first used (the last-arriving workgroup re-arms them, so a workspace that
  *   is only ever handed to this function stays valid); the fp32 partials follow.  One workspace must not

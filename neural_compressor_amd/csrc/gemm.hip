@@ -782,7 +782,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
     const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
     const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int64_t M, int64_t N, int64_t K,
-    int64_t NW, int g_shift, int y_vec_ok) {
+    int64_t NW, int g_shift, int y_vec_ok, float* __restrict__ partial, int steps_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Abase = smem;                 // 3 stages
   char* const Bbase = smem + 3 * T_ASTAGE;  // 2 stages
@@ -822,11 +822,15 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   const int zshift = 4 * (int)(ncol & 7);
   const int bdst0 = (((bcol >> 5) * 4 + 2 * kwh) * 64 + (bcol & 31)) * 16;
   const int kwh_s = __builtin_amdgcn_readfirstlane(tid >> 8);
-  const int nk = (int)(K / TK);
+  // split-K (medium M: fewer tiles than CUs): this workgroup multiplies K-tiles [kbase, kbase + nk) and, when `partial`
+  // is given, stores its fp32 tile into slab blockIdx.y; inc_woq_gemm's finalize kernel adds the slabs in a fixed order
+  const int nk_all = (int)(K / TK);
+  const int kbase = blockIdx.y * steps_per_split;
+  const int nk = min(steps_per_split, nk_all - kbase);
 
   // one step's requests: 6 for W (4 packed words, scale, zero word) FIRST, then 4 x DMAs
   auto issue_w = [&](int kt, uint32_t (&w)[4], uint32_t& sb, uint32_t& zw) {
-    if (kt > nk - 1) kt = nk - 1;
+    kt = kbase + (kt > nk - 1 ? nk - 1 : kt);
     const uint32_t* wbase = qweight + (int64_t)kt * (TK / 8) * N;
     const int64_t g = g_shift >= 0 ? (((int64_t)kt * TK + 32 * kwh_s) >> g_shift) : 0;  // wave-uniform (kwh is)
     const uint16_t* sbase = scales + g * N;
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
         : "memory");
   };
   auto issue_dma = [&](int kt, int astage) {
-    if (kt > nk - 1) kt = nk - 1;
+    kt = kbase + (kt > nk - 1 ? nk - 1 : kt);
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + astage * T_ASTAGE + wave * 4096);
     lds_dma_4x1k(xtile + (int64_t)kt * TK, dst, avoff[0], avoff[1], avoff[2], avoff[3]);
   };
@@ -860,17 +864,18 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   const int a_sw = ((lane & 31) >> 1) & 7;
   const int a_hi = lane >> 5;
   const int b_off = (wn * 2 * 4 * 64 + lane) * 16;
-  auto mma_step = [&](const char* As, const char* Bs, int kk) {
-    uint4 xa[4], wb[2];
+  auto read_frags = [&](const char* As, const char* Bs, int kk, uint4 (&xa)[4], uint4 (&wbv)[2]) {
     const int chunk = ((2 * kk + a_hi) ^ a_sw) << 4;
 #pragma unroll
     for (int mf = 0; mf < 4; ++mf) xa[mf] = *reinterpret_cast<const uint4*>(As + (a_row + 32 * mf) * 128 + chunk);
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf) wb[nf] = *reinterpret_cast<const uint4*>(Bs + (nf * 4 + kk) * 1024);
+    for (int nf = 0; nf < 2; ++nf) wbv[nf] = *reinterpret_cast<const uint4*>(Bs + (nf * 4 + kk) * 1024);
+  };
+  auto mma8 = [&](const uint4 (&xa)[4], const uint4 (&wbv)[2]) {
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma32<IS_BF16>(wb[nf], xa[mf], acc[nf][mf]);
+      for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma32<IS_BF16>(wbv[nf], xa[mf], acc[nf][mf]);
   };
   auto dequant_into = [&](int bstage, int kk, uint32_t word, float sc, float nzs) {
     char* dst = Bbase + bstage * T_BSTAGE + bdst0;
@@ -902,39 +907,75 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  // Fragment registers: X and Y alternate over the four k16 groups of a step.  The LAST group of step t is multiplied
+  // AFTER the barrier that ends the step, while the first fragments of step t+1 are already on their way from LDS and the
+  // next loads are being issued: the matrix pipe has work during what used to be a ~90-instruction bubble per step.
+  uint4 xX[4], wX[2], xY[4], wY[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xY[i] = make_uint4(0u, 0u, 0u, 0u);  // "previous step's last group" of step 0: adds zeros
+  wY[0] = wY[1] = make_uint4(0u, 0u, 0u, 0u);
+  read_frags(Abase, Bbase + b_off, 0, xX, wX);
+
   // step t: x stage t%3, W stage t&1.  Issues W words of tile t+2 and the DMA of x tile t+2 (stage (t+2)%3), dequantises
   // tile t+1 (words issued in step t-1) into W stage (t+1)&1.
 #define INC_3A2B_STEP(T, LW, LWS, LWZ, DW, DWS, DWZ)                                                              \
   {                                                                                                                \
     const int t_ = (T);                                                                                            \
     const int as_ = t_ % 3, bs_ = t_ & 1;                                                                          \
-    issue_w(t_ + 2, LW, LWS, LWZ);                                                                                 \
-    issue_dma(t_ + 2, (t_ + 2) % 3);                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
     const char* As = Abase + as_ * T_ASTAGE;                                                                       \
     const char* Bs = Bbase + bs_ * T_BSTAGE + b_off;                                                               \
-    mma_step(As, Bs, 0);                                                                                           \
+    issue_w(t_ + 2, LW, LWS, LWZ);                                                                                 \
+    issue_dma(t_ + 2, (t_ + 2) % 3);                                                                               \
+    mma8(xY, wY);                       /* group 3 of the previous step */                                         \
+    read_frags(As, Bs, 1, xY, wY);                                                                                 \
+    mma8(xX, wX);                       /* group 0 */                                                              \
     asm volatile("s_waitcnt vmcnt(14)" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory"); \
     float sc_, nzs_;                                                                                               \
     group_params(DWS, DWZ, sc_, nzs_);                                                                             \
     dequant_into(bs_ ^ 1, 0, DW[0], sc_, nzs_);                                                                    \
-    mma_step(As, Bs, 1);                                                                                           \
+    read_frags(As, Bs, 2, xX, wX);                                                                                 \
+    mma8(xY, wY);                       /* group 1 */                                                              \
     dequant_into(bs_ ^ 1, 1, DW[1], sc_, nzs_);                                                                    \
-    mma_step(As, Bs, 2);                                                                                           \
+    read_frags(As, Bs, 3, xY, wY);                                                                                 \
+    mma8(xX, wX);                       /* group 2 */                                                              \
     dequant_into(bs_ ^ 1, 2, DW[2], sc_, nzs_);                                                                    \
-    mma_step(As, Bs, 3);                                                                                           \
     dequant_into(bs_ ^ 1, 3, DW[3], sc_, nzs_);                                                                    \
     asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_s_barrier();                                                                                  \
+    read_frags(Abase + ((t_ + 1) % 3) * T_ASTAGE, Bbase + (bs_ ^ 1) * T_BSTAGE + b_off, 0, xX, wX);               \
   }
   for (int t0 = 0; t0 < nk; t0 += 2) {
     INC_3A2B_STEP(t0, wb_, wsb, wzb, wa, wsa, wza)        // even step: load tile t+2 (even) -> set B, dequantise tile t+1 (odd) <- set A
     INC_3A2B_STEP(t0 + 1, wa, wsa, wza, wb_, wsb, wzb)    // odd step: the reverse
   }
 #undef INC_3A2B_STEP
+  mma8(xY, wY);  // group 3 of the last step
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
+  if (partial) {  // split-K: raw fp32 tile into this split's slab (bias and conversion happen in the finalize kernel)
+    float* slab = partial + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int64_t nb = n0 + wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+          const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
+          if (m >= M) continue;
+          float* dst = slab + m * N + nb;
+          if (nb + 4 <= N && (N % 4) == 0) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[nf][mf][4 * rq + 0], acc[nf][mf][4 * rq + 1], acc[nf][mf][4 * rq + 2], acc[nf][mf][4 * rq + 3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (nb + e < N) dst[e] = acc[nf][mf][4 * rq + e];
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf) {
 #pragma unroll
@@ -963,6 +1004,24 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
         }
       }
     }
+  }
+}
+
+template <bool IS_BF16>
+__global__ void splitk_slab_reduce_kernel(const float* __restrict__ partial, const uint16_t* __restrict__ bias,
+                                          uint16_t* __restrict__ y, int64_t M, int64_t N, int splits) {
+  const int64_t total4 = M * N / 4;  // N % 4 == 0 on this path
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(partial)[i];
+    for (int z = 1; z < splits; ++z) {  // fixed order: deterministic
+      const float4 p = reinterpret_cast<const float4*>(partial + (int64_t)z * M * N)[i];
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (bias) {
+      const int64_t n = (i * 4) % N;
+      v.x += cvt16<IS_BF16>(bias[n]); v.y += cvt16<IS_BF16>(bias[n + 1]); v.z += cvt16<IS_BF16>(bias[n + 2]); v.w += cvt16<IS_BF16>(bias[n + 3]);
+    }
+    reinterpret_cast<uint2*>(y)[i] = make_uint2(cvt_pair<IS_BF16>(v.x, v.y), cvt_pair<IS_BF16>(v.z, v.w));
   }
 }
 
@@ -1262,11 +1321,32 @@ inline int small_slices(int64_t N, int64_t K, int bits, int* kw_per_slice_out) {
 
 extern "C" {
 
-// workspace layout (M <= 16 only): [0, 16 KiB) arrival counters of the fast GEMV (uint32 per 64-column
+// workspace layout : [0, 16 KiB) arrival counters of the fast GEMV (uint32 per 64-column
 // strip; MUST be zero on first use, the kernel re-arms them), then fp32 split-K partials.
 constexpr int64_t WS_COUNTER_BYTES = 16384;
+// split-K plan of the 3A2B kernel for medium M: enough workgroups to cover the chip, slabs of >= 4 K-steps
+static int big_splitk(int64_t M, int64_t N, int64_t K, int* steps_out) {
+  const int64_t tiles = ceil_div64(M, TM) * ceil_div64(N, TN);
+  const int nk = (int)(K / TK);
+  int splits = 1;
+  if (tiles < 192 && (K % 128) == 0 && (N % 4) == 0) {
+    splits = (int)(256 / tiles);
+    while (splits > 1 && (nk / splits) < 4) --splits;
+    if (splits > 8) splits = 8;
+  }
+  int steps = (int)ceil_div64(nk, splits);
+  steps += steps & 1;  // the K-loop is unrolled by two
+  splits = (int)ceil_div64(nk, steps);
+  *steps_out = steps;
+  return splits;
+}
+
 int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M > 16) return 0;
+  if (M > 16) {
+    int steps;
+    const int splits = M >= 128 && N >= 64 ? big_splitk(M, N, K, &steps) : 1;
+    return splits > 1 ? WS_COUNTER_BYTES + (int64_t)splits * M * N * 4 : 0;  // slabs start AFTER the counter block
+  }
   int64_t slices = ceil_div64(K, 32 * VS * 4);
   if (slices < 64) slices = 64;  // the generic split-K path uses up to 64 slices
   return WS_COUNTER_BYTES + slices * M * N * 4;
@@ -1308,8 +1388,23 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     }
     const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
     const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
-    if (bf) woq_gemm_w4_3a2b_kernel<true><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
-    else woq_gemm_w4_3a2b_kernel<false><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
+    int steps = (int)(K / TK);
+    int splits = big_splitk(M, N, K, &steps);
+    float* part = nullptr;
+    if (splits > 1) {
+      if (y_vec_ok && workspace && workspace_bytes >= WS_COUNTER_BYTES + (int64_t)splits * M * N * 4)
+        part = (float*)((char*)workspace + WS_COUNTER_BYTES);  // never touch the GEMV's arrival counters
+      else { splits = 1; steps = (int)(K / TK); }  // no workspace given: single pass (still correct, fewer workgroups)
+    }
+    dim3 g2(grid, (unsigned)splits);
+    if (bf) woq_gemm_w4_3a2b_kernel<true><<<g2, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps);
+    else woq_gemm_w4_3a2b_kernel<false><<<g2, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps);
+    if (part) {
+      int64_t rb = ceil_div64(M * N / 4, 256);
+      if (rb > 4096) rb = 4096;
+      if (bf) splitk_slab_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
+      else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
+    }
   } else if (big_ok && bf && (K % 128) == 0 && inc_small_tiles_flag(-1) == 3) {  // experiment kept for A/B: 4 x 32 KiB stages, BK = 32
     const size_t smem = (size_t)4 * D_STAGE;
     (void)hipFuncSetAttribute((const void*)woq_gemm_w4_deep_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

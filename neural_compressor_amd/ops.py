@@ -204,12 +204,12 @@ def woq_gemm(x2d, qweight, scales, qzeros, bias, N, K, group_size, bits, g_idx=N
     M = x2d.shape[0]
     G = scales.shape[0]
     y = torch.empty((M, N), dtype=x2d.dtype, device=dev)
-    ws, nbytes = None, 0
-    if M <= 16:
-        key = (M, N, K)
-        nbytes = _ws_bytes_cache.get(key)
-        if nbytes is None:
-            nbytes = _ws_bytes_cache[key] = lib.inc_woq_gemm_workspace_bytes(M, N, K)
+    ws = None
+    key = (M, N, K)
+    nbytes = _ws_bytes_cache.get(key)
+    if nbytes is None:
+        nbytes = _ws_bytes_cache[key] = lib.inc_woq_gemm_workspace_bytes(M, N, K)
+    if nbytes > 0:  # M <= 16: arrival counters + split-K partials; medium M: split-K slabs of the 256x256 kernel
         ws = _workspace(dev, nbytes)
     stream = torch.cuda.current_stream(dev).cuda_stream
     args = (

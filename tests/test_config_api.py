@@ -101,3 +101,32 @@ def test_expand_and_eq():
     assert RTNConfig(bits=4) == RTNConfig(bits=4) and RTNConfig(bits=4) != RTNConfig(bits=8)
     g = GPTQConfig(act_order=True, percdamp=0.1, block_size=128, use_mse_search=False)
     assert g.to_dict()["percdamp"] == 0.1 and g.act_order
+
+
+def test_2x_named_shim_translates_to_3x_configs():
+    """`PostTrainingQuantConfig(approach="weight_only", op_type_dict=..., recipes=...)` (the 2.x vocabulary BASELINE.json's
+    north_star uses) maps onto the 3.x config objects; `quantization.fit` is importable without a GPU."""
+    from neural_compressor_amd import quantization
+    from neural_compressor_amd.config import PostTrainingQuantConfig
+    from neural_compressor_amd.torch.quantization import AWQConfig, GPTQConfig, RTNConfig
+
+    c = PostTrainingQuantConfig(
+        approach="weight_only",
+        op_type_dict={".*": {"weight": {"bits": 4, "group_size": 128, "scheme": "sym", "algorithm": "GPTQ"}}},
+        op_name_dict={".*lm_head": {"weight": {"dtype": "fp32"}}},
+        recipes={"gptq_args": {"percdamp": 0.02, "block_size": 128, "act_order": True}},
+    ).to_3x()
+    assert isinstance(c, GPTQConfig) and (c.bits, c.group_size, c.use_sym, c.percdamp, c.act_order) == (4, 128, True, 0.02, True)
+    assert ".*lm_head" in c.local_config and c.local_config[".*lm_head"].dtype == "fp32"
+    r = PostTrainingQuantConfig(op_type_dict={".*": {"weight": {"bits": 8, "group_size": -1, "scheme": "asym", "algorithm": "RTN"}}},
+                                recipes={"rtn_args": {"enable_mse_search": True}}).to_3x()
+    assert isinstance(r, RTNConfig) and (r.bits, r.group_size, r.use_sym, r.use_mse_search) == (8, -1, False, True)
+    a = PostTrainingQuantConfig(op_type_dict={".*": {"weight": {"bits": 4, "group_size": 32, "scheme": "asym", "algorithm": "AWQ"}}},
+                                recipes={"awq_args": {"enable_auto_scale": False, "folding": True}}).to_3x()
+    assert isinstance(a, AWQConfig) and (a.use_auto_scale, a.use_auto_clip, a.folding) == (False, True, True)
+    import pytest
+
+    with pytest.raises(NotImplementedError):
+        PostTrainingQuantConfig(approach="static")
+    with pytest.raises(ValueError):
+        quantization.fit(None, PostTrainingQuantConfig(op_type_dict={".*": {"weight": {"algorithm": "GPTQ"}}}))

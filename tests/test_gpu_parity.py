@@ -422,6 +422,23 @@ def test_fused_gemm_baseline_shapes(hip, M, N, K):
     assert torch.equal(m(x * 2), y * 2)
 
 
+@pytest.mark.parametrize("M", [128, 512, 1024])
+def test_fused_gemm_split_k_medium_m(hip, M):
+    """Fewer 256x256 tiles than CUs -> deterministic split-K slabs; must equal the dense reference, be bit-reproducible,
+    and must not disturb the M <= 16 kernel that shares the per-stream workspace (its arrival counters live in the first 16 KiB)."""
+    m = _packed_layer(hip, 4096, 4096, 128, 4, False, seed=M, bias=True)
+    torch.manual_seed(M)
+    x = torch.randn(M, 4096, device=hip, dtype=torch.bfloat16)
+    w = m.recover(dtype=torch.bfloat16).float()
+    y = m(x)
+    ref = x.float() @ w.t() + m.bias.float()
+    assert rel_fro(y.float(), ref.to(torch.bfloat16).float()) <= 1e-3
+    assert torch.equal(m(x), y)
+    y1 = m(x[:1].contiguous())  # decode-shaped call right after, same workspace
+    assert rel_fro(y1.float(), ref[:1].to(torch.bfloat16).float()) <= 1e-3
+    assert torch.equal(m(x), y)
+
+
 def test_forward_matches_reference_accelerator_semantics(hip):
     """fp32 input -> cast to fp16 and fp16 out, as the reference does on an accelerator (modules.py:605)."""
     m = _packed_layer(hip, 128, 256, 32, 4, True, seed=5)
