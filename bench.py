@@ -72,6 +72,18 @@ class KernelClock:
         return out
 
 
+def _pmc_traffic(key):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes of THIS workload
+    (profiles/r1_pmc/bench_traffic.json, produced by scripts/gpu_pmc_bench.sh: FETCH_SIZE doubled as the MI355X guide
+    prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE); null when no PMC pass has been recorded."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc", "bench_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(key, {}).get("traffic_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def build_model(n_layers, device):
     from transformers import LlamaConfig, LlamaForCausalLM
 
@@ -268,9 +280,17 @@ def main():
         dom = max(hess, key=lambda k: hess[k]["total_ms"])
         v = hess[dom]
         achieved = v["work"] / (v["total_ms"] * 1e-3) / 1e12
-        roofline = dict(kernel=f"hessian_syrk_16bit_256_kernel<bf16> ({dom}; algorithmic flops 2*T*K^2 per launch)", bound="mfma", achieved=round(achieved, 2),
-                        peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                        traffic=None, avg_launch_ms=round(v["avg_ms"], 4), launches=v["launches"])
+        Kdom = int(dom.split("K")[-1])
+        nt = -(-Kdom // 256)
+        executed = (nt * (nt + 1) / 2) / (nt * nt)  # the kernel multiplies the upper-triangular 256x256 tiles only
+        roofline = dict(kernel=f"hessian_syrk_16bit_256_kernel<bf16> ({dom}; algorithmic flops 2*T*K^2 per launch)", bound="mfma",
+                        achieved=round(achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=_pmc_traffic(dom),
+                        avg_launch_ms=round(v["avg_ms"], 4), launches=v["launches"],
+                        tokens_per_launch=int(round(v["work"] / v["launches"] / (2.0 * Kdom * Kdom))),
+                        executed_frac=round(achieved * executed / BF16_MFMA_PEAK_TFLOPS, 4),
+                        note="algorithmic = the full X^T X product (SURVEY 8d); the syrk kernel executes the upper-triangular tiles "
+                             f"only ({executed:.3f} of it): executed_frac is the matrix-pipe view of the same time")
 
     result = dict(
         metric="llama2_7b_gptq_int4_g128_quantize_wall_clock", value=round(value, 3), unit="s", n_gpus=world,

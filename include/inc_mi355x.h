@@ -179,6 +179,14 @@ int inc_gptq_find_params(const float* w, int64_t N, int64_t K, int64_t col0, int
                          int ngroups, int bits, int sym, float* scale, float* zero, int64_t G,
                          int64_t g0, inc_stream_t stream);
 
+/* == the same with Quantizer's `mse` shrink-grid search (gptq.py:1567-1584, GPTQConfig(use_mse_search=True)):
+ *   for i < int(maxshrink*grid): p = 1 - i/grid; range scaled by p; keep the (scale, zero) minimising
+ *   sum |quantize(x) - x|^norm over the group (strict '<').  The reference's configure() uses grid=100,
+ *   maxshrink=0.8, norm=2.4 (gptq.py:1375-1387).                                                     */
+int inc_gptq_find_params_mse(const float* w, int64_t N, int64_t K, int64_t col0, int group_size,
+                             int ngroups, int bits, int sym, int grid, float maxshrink, float norm,
+                             float* scale, float* zero, int64_t G, int64_t g0, inc_stream_t stream);
+
 /* == the serial column loop of GPTQ.fasterquant for ONE block of columns [i1, i1+count)
  *   (gptq.py:1250-1299), count <= 128, rows independent:
  *     for i: q = scale*(clamp(rint(w/scale)+zero,0,maxq)-zero); err=(w-q)/Hinv[i,i];

@@ -46,6 +46,10 @@ SIGNATURES = {
         c_int,
         [_P, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, _P, _P, c_int64, c_int64, _P],
     ),
+    "inc_gptq_find_params_mse": (
+        c_int,
+        [_P, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, c_int64, c_int64, _P],
+    ),
     "inc_gptq_quant_block": (
         c_int,
         [_P, _P, _P, _P, _P, _P, c_int, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P],

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void groupwise_quant_kernel(
 __global__ __launch_bounds__(256) void gptq_find_params_kernel(
     const float* __restrict__ w, int64_t N, int64_t K, int64_t col0,
     int gs, int ngroups, int L, int bits, int sym, float* __restrict__ scale, float* __restrict__ zero,
-    int64_t G, int64_t g0) {
+    int64_t G, int64_t g0, int mse_steps, int mse_grid, float mse_norm) {
   const int lane = threadIdx.x & 63;
   const int tl = lane & (L - 1);
   const int team = lane / L;
@@ -222,8 +222,34 @@ __global__ __launch_bounds__(256) void gptq_find_params_kernel(
     if (xmin < 0.f) xmin = -xmax;
   }
   if (xmin == 0.f && xmax == 0.f) { xmin = -1.f; xmax = 1.f; }
-  const float s = (xmax - xmin) / maxq;
-  const float z = sym ? (maxq + 1.f) * 0.5f : rintf(-xmin / s);
+  float s = (xmax - xmin) / maxq;
+  float z = sym ? (maxq + 1.f) * 0.5f : rintf(-xmin / s);
+  if (mse_steps > 0) {
+    // shrink-grid search (gptq.py:1567-1584): keep the (scale, zero) with the smallest sum |q(x) - x|^norm; strict '<'
+    // like the reference, so the first (largest) range wins ties.  Same un-fused fp32 arithmetic as Quantizer.quantize.
+    const float z_sym = z;
+    float best = INFINITY;
+    for (int i = 0; i < mse_steps; ++i) {
+      const float p = (float)(1.0 - (double)i / (double)mse_grid);  // Python double, cast to the tensor dtype
+      const float xmin1 = p * xmin, xmax1 = p * xmax;
+      const float s1 = (xmax1 - xmin1) / maxq;
+      const float z1 = sym ? z_sym : rintf(-xmin1 / s1);
+      float err = 0.f;
+      for (int k = tl; k < klen; k += L) {
+        const float x = w[n * K + kbeg + k];
+        float t = rintf(x / s1) + z1;
+        t = fminf(fmaxf(t, 0.f), maxq);
+        const float q = s1 * (t - z1);
+        err += powf(fabsf(q - x), mse_norm);
+      }
+      for (int o = L >> 1; o > 0; o >>= 1) err += __shfl_xor(err, o, 64);
+      if (err < best) {
+        best = err;
+        s = s1;
+        z = z1;
+      }
+    }
+  }
   if (active && tl == 0) {
     scale[n * G + g0 + g] = s;
     zero[n * G + g0 + g] = z;
@@ -300,7 +326,22 @@ int inc_gptq_find_params(const float* w, int64_t N, int64_t K, int64_t col0, int
   while (L < group_size && L < 64) L <<= 1;
   const int64_t waves = ceil_div64(N * ngroups, 64 / L);
   gptq_find_params_kernel<<<(unsigned)ceil_div64(waves, 4), 256, 0, inc_s(stream)>>>(
-      w, N, K, col0, group_size, ngroups, L, bits, sym, scale, zero, G, g0);
+      w, N, K, col0, group_size, ngroups, L, bits, sym, scale, zero, G, g0, 0, 100, 2.4f);
+  INC_LAUNCH_RETURN();
+}
+
+int inc_gptq_find_params_mse(const float* w, int64_t N, int64_t K, int64_t col0, int group_size,
+                             int ngroups, int bits, int sym, int grid, float maxshrink, float norm,
+                             float* scale, float* zero, int64_t G, int64_t g0, inc_stream_t stream) {
+  INC_CHECK_ARG(w && scale && zero && N > 0 && K > 0 && ngroups > 0 && group_size > 0 && grid > 0);
+  INC_CHECK_ARG(col0 >= 0 && col0 < K && g0 >= 0 && g0 + ngroups <= G && bits >= 1 && bits <= 8);
+  INC_CHECK_ARG(maxshrink > 0.f && maxshrink <= 1.f && norm > 0.f);
+  int L = 1;
+  while (L < group_size && L < 64) L <<= 1;
+  const int64_t waves = ceil_div64(N * ngroups, 64 / L);
+  const int steps = (int)(maxshrink * (float)grid);  // int(self.maxshrink * self.grid)
+  gptq_find_params_kernel<<<(unsigned)ceil_div64(waves, 4), 256, 0, inc_s(stream)>>>(
+      w, N, K, col0, group_size, ngroups, L, bits, sym, scale, zero, G, g0, steps, grid, norm);
   INC_LAUNCH_RETURN();
 }
 

@@ -316,15 +316,24 @@ def gptq_prepare_weight(w, dead=None):
     return out
 
 
-def gptq_find_params(w32, col0, group_size, ngroups, bits, sym, scale, zero, g0):
+def gptq_find_params(w32, col0, group_size, ngroups, bits, sym, scale, zero, g0, mse=False, grid=100, maxshrink=0.8, norm=2.4):
+    """Quantizer.find_params(weight=True) for `ngroups` groups starting at column `col0` (gptq.py:1501-1624); `mse`
+    adds the shrink-grid search of :1567-1584."""
     dev = _dev(w32, scale, zero)
     N, K = w32.shape
     G = scale.shape[1]
     with torch.cuda.device(dev):
-        check(
-            lib.inc_gptq_find_params(_ptr(w32), N, K, col0, group_size, ngroups, bits, int(bool(sym)), _ptr(scale), _ptr(zero), G, g0, _stream()),
-            "inc_gptq_find_params",
-        )
+        if mse:
+            check(
+                lib.inc_gptq_find_params_mse(_ptr(w32), N, K, col0, group_size, ngroups, bits, int(bool(sym)), int(grid),
+                                             float(maxshrink), float(norm), _ptr(scale), _ptr(zero), G, g0, _stream()),
+                "inc_gptq_find_params_mse",
+            )
+        else:
+            check(
+                lib.inc_gptq_find_params(_ptr(w32), N, K, col0, group_size, ngroups, bits, int(bool(sym)), _ptr(scale), _ptr(zero), G, g0, _stream()),
+                "inc_gptq_find_params",
+            )
 
 
 def gptq_quant_block(w32, hinv, scale, zero, codes, q_out, err, i1, count, group_size, bits):

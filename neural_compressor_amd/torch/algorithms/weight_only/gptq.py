@@ -274,8 +274,7 @@ class GPTQ:
             raise NotImplementedError("act_order together with static_groups is not implemented yet")
         bits = int(self.cfg.get("bits", 4))
         sym = bool(self.cfg.get("sym", False))
-        if self.cfg.get("mse", False):
-            raise NotImplementedError("use_mse_search for GPTQ is not implemented yet")
+        mse = bool(self.cfg.get("mse", False))  # GPTQConfig(use_mse_search=True): shrink-grid search in find_params
         if self.cfg.get("dtype", "int") != "int" or self.cfg.get("use_double_quant", False):
             raise NotImplementedError("GPTQ on MI355X quantises to plain integer formats")
         weight_shape, weight_dtype = W.shape, W.dtype
@@ -294,11 +293,11 @@ class GPTQ:
         if groupsize == -1:
             # per-channel parameters come from W before dead columns are zeroed (gptq.py:1180-1189 order)
             w32 = ops.gptq_prepare_weight(W, None)
-            ops.gptq_find_params(w32, 0, K, 1, bits, sym, scale, zero, 0)
+            ops.gptq_find_params(w32, 0, K, 1, bits, sym, scale, zero, 0, mse=mse)
             del w32
         w32 = ops.gptq_prepare_weight(W, dead)
         if static_groups:
-            ops.gptq_find_params(w32, 0, gs, G, bits, sym, scale, zero, 0)
+            ops.gptq_find_params(w32, 0, gs, G, bits, sym, scale, zero, 0, mse=mse)
         if act_order:
             w32 = w32[:, perm].contiguous()
             self.perm = perm.clone()
@@ -318,7 +317,7 @@ class GPTQ:
                 g_first = -(-i1 // gs)
                 g_last = (ref_end - 1) // gs
                 if g_last >= g_first:
-                    ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first)
+                    ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first, mse=mse)
             ops.gptq_quant_block(w32, Hinv, scale, zero, codes, Q, err, i1, count, kernel_gs, bits)
             ops.gptq_lazy_update(w32, Hinv, err, i1, count)
             i1 += count

@@ -208,10 +208,12 @@ def search_clip(weight, bits=4, group_size=32, scheme="asym", full_range=False):
 # GPTQ
 # =====================================================================================================
 class GPTQQuantParams:
-    """Quantizer.find_params / quantize for dtype int, perchannel, weight=True, no mse (gptq.py:1501-1637)."""
+    """Quantizer.find_params / quantize for dtype int, perchannel, weight=True (gptq.py:1501-1637), incl. the `mse`
+    shrink-grid search (:1567-1584; configure() defaults norm=2.4, grid=100, maxshrink=0.8, :1375-1387)."""
 
-    def __init__(self, bits=4, sym=False):
+    def __init__(self, bits=4, sym=False, mse=False, norm=2.4, grid=100, maxshrink=0.8):
         self.bits, self.sym = bits, sym
+        self.mse, self.norm, self.grid, self.maxshrink = mse, norm, grid, maxshrink
         self.maxq = 2**bits - 1
         self.scale = torch.zeros(1)
         self.zero = torch.zeros(1)
@@ -234,6 +236,25 @@ class GPTQQuantParams:
             self.zero = torch.full_like(self.scale, (self.maxq + 1) / 2)
         else:
             self.zero = torch.round(-xmin / self.scale)
+        if self.mse:
+            best = torch.full([x.shape[0]], float("inf"))
+            for i in range(int(self.maxshrink * self.grid)):
+                p = 1 - i / self.grid
+                xmin1 = p * xmin
+                xmax1 = p * xmax
+                scale1 = (xmax1 - xmin1) / self.maxq
+                zero1 = torch.round(-xmin1 / scale1) if not self.sym else self.zero
+                q = torch.clamp(torch.round(x / scale1.unsqueeze(1)) + zero1.unsqueeze(1), 0, self.maxq)
+                q = scale1.unsqueeze(1) * (q - zero1.unsqueeze(1))
+                q -= x
+                q.abs_()
+                q.pow_(self.norm)
+                err = torch.sum(q, 1)
+                better = err < best
+                if torch.any(better):
+                    best[better] = err[better]
+                    self.scale[better] = scale1[better]
+                    self.zero[better] = zero1[better]
         self.scale = self.scale.reshape(-1, 1)
         self.zero = self.zero.reshape(-1, 1)
 
@@ -275,13 +296,13 @@ def gptq_hinv(H, percdamp=0.01):
 
 
 def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, groupsize=-1, act_order=False,
-                     static_groups=False, Hinv=None):
+                     static_groups=False, Hinv=None, mse=False):
     """GPTQ.fasterquant (gptq.py:1143-1351) for int dtype.  Returns dict(scale [N,G], zero [N,G], Q fp32 [N,K], perm).
 
     `Hinv` (optional) injects a precomputed factor so the column loop can be tested in isolation.
     """
     W = W.clone().float()
-    quantizer = GPTQQuantParams(bits, sym)
+    quantizer = GPTQQuantParams(bits, sym, mse=mse)
     columns = W.shape[1]
     if not quantizer.ready():
         quantizer.find_params(W)

@@ -1,0 +1,31 @@
+#!/bin/bash
+# PMC passes over the bench workload itself (1 step): HBM-side bytes per launch of the Hessian syrk kernel.
+# FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots); only --kernel-trace goes with --pmc.
+set -u
+mkdir -p gpurun_out/pmc_bench
+export TMPDIR=/tmp
+ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
+cd /tmp
+for pass in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$ROOT/gpurun_out/pmc_bench/$pass" -o pmc -- python "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-gemm > "$ROOT/gpurun_out/pmc_bench/$pass.log" 2>&1
+  echo "pass [$pass] exit $?"
+done
+python - <<'PY'
+import csv, collections, glob, json, os
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in glob.glob(os.path.join(root, "gpurun_out/pmc_bench/*/pmc_counter_collection.csv")):
+    for r in csv.DictReader(open(d)):
+        if "hessian_syrk_16bit_256" in r["Kernel_Name"]:
+            key = "hessian_K11008" if int(r["Grid_Size"]) > 512 * 200 else "hessian_K4096"
+            agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, c in agg.items():
+    f = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1) * 1024.0 if c.get("FETCH_SIZE") else None
+    w = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1) * 1024.0 if c.get("WRITE_SIZE") else None
+    out[k] = dict(fetch_size_bytes=f, write_size_bytes=w, launches=len(c.get("FETCH_SIZE", [])),
+                  traffic_bytes_per_launch=(2.0 * f + w) if f is not None and w is not None else None,
+                  note="traffic = 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes): gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X guide)")
+json.dump(out, open(os.path.join(root, "gpurun_out/pmc_bench/bench_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY

@@ -179,6 +179,9 @@ def main():
     run_gptq("gq_sym_g32_blk2048", 16, 256, 4, 80, dict(bits=4, sym=True), 2048, 32)
     run_gptq("gq_sym_act", 16, 128, 4, 48, dict(bits=4, sym=True), 128, 32, act_order=True)
     run_gptq("gq_sym8_g64", 8, 128, 3, 64, dict(bits=8, sym=True), 128, 64)
+    # use_mse_search: Quantizer.find_params shrink grid (gptq.py:1567-1584; reference test test_gptq.py:137)
+    run_gptq("gq_sym_g32_mse", 16, 128, 4, 48, dict(bits=4, sym=True, mse=True), 128, 32)
+    run_gptq("gq_asym_g64_mse", 12, 128, 4, 48, dict(bits=4, sym=False, mse=True), 128, 64)
 
     # ---- 6. AWQ statistics ---------------------------------------------------------------------------------------
     w = torch.randn(24, 128, generator=g)

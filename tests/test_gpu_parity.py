@@ -213,6 +213,8 @@ GQ_CASES = {
     "gq_sym_g128_2blk": dict(bits=4, sym=True, blocksize=128, groupsize=128),
     "gq_sym_g32_blk2048": dict(bits=4, sym=True, blocksize=2048, groupsize=32),
     "gq_sym8_g64": dict(bits=8, sym=True, blocksize=128, groupsize=64),
+    "gq_sym_g32_mse": dict(bits=4, sym=True, blocksize=128, groupsize=32, mse=True),
+    "gq_asym_g64_mse": dict(bits=4, sym=False, blocksize=128, groupsize=64, mse=True),
 }
 
 
@@ -267,14 +269,14 @@ def test_gptq_column_loop_with_injected_hinv(hip, golden, tag):
     Q = torch.empty(N, K, device=hip)
     err = torch.empty(N, 128, device=hip)
     if gs_cfg == -1:
-        ops.gptq_find_params(w32, 0, K, 1, bits, sym, scale, zero, 0)
+        ops.gptq_find_params(w32, 0, K, 1, bits, sym, scale, zero, 0, mse=kw.get("mse", False))
     i1 = 0
     while i1 < K:
         ref_end = min((i1 // blocksize + 1) * blocksize, K)
         count = min(128, ref_end - i1)
         if gs_cfg != -1 and i1 % blocksize == 0:
             g_first, g_last = -(-i1 // gs), (ref_end - 1) // gs
-            ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first)
+            ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first, mse=kw.get("mse", False))
         ops.gptq_quant_block(w32, hinv, scale, zero, codes, Q, err, i1, count, gs if gs_cfg != -1 else 0, bits)
         ops.gptq_lazy_update(w32, hinv, err, i1, count)
         i1 += count
@@ -282,7 +284,13 @@ def test_gptq_column_loop_with_injected_hinv(hip, golden, tag):
     ref_ints = golden[f"{tag}_ints"].astype(np.int32) + (2 ** (bits - 1) if sym else 0)
     got_codes = codes.cpu().numpy().astype(np.int32)
     match = float((got_codes == ref_ints).mean())
-    if K <= 128:
+    if K <= 128 and kw.get("mse", False):
+        # the shrink-grid argmin compares sums of powf() values: a last-bit difference between the CPU's and the GPU's
+        # pow / summation order may move a group to the neighbouring grid point (1 % of the range) -- allow a few
+        same = np.isclose(scale.cpu().numpy(), ref_scale, rtol=1e-6).mean()
+        assert same >= 0.97, f"only {same:.3f} of the mse-searched scales match"
+        assert match >= 0.97
+    elif K <= 128:
         # a single block: identical un-fused fp32 arithmetic -> bit-exact
         assert np.array_equal(scale.cpu().numpy(), ref_scale)
         assert np.array_equal(zero.cpu().numpy(), ref_zero)
@@ -297,7 +305,7 @@ def test_gptq_column_loop_with_injected_hinv(hip, golden, tag):
         assert np.array_equal(got_codes[:, :128], ref_ints[:, :128])
 
 
-@pytest.mark.parametrize("tag", ["gq_sym_g32", "gq_asym_g32", "gq_sym_pc", "gq_sym_g128_2blk", "gq_sym_act", "gq_sym8_g64"])
+@pytest.mark.parametrize("tag", ["gq_sym_g32", "gq_asym_g32", "gq_sym_pc", "gq_sym_g128_2blk", "gq_sym_act", "gq_sym8_g64", "gq_sym_g32_mse", "gq_asym_g64_mse"])
 def test_gptq_layer_end_to_end(hip, golden, tag):
     """add_batch -> fasterquant -> pack through the Python mirror classes vs the reference's golden outputs."""
     from neural_compressor_amd.torch.algorithms.weight_only.gptq import GPTQ
@@ -311,7 +319,7 @@ def test_gptq_layer_end_to_end(hip, golden, tag):
     layer = torch.nn.Linear(K, N, bias=False).to(hip)
     layer.weight.data.copy_(W)
     gq = GPTQ(layer, device=hip)
-    gq.configure(dict(bits=kw["bits"], sym=kw["sym"], dtype="int", mse=False))
+    gq.configure(dict(bits=kw["bits"], sym=kw["sym"], dtype="int", mse=kw.get("mse", False)))
     for j in range(X.shape[0]):
         gq.add_batch(X[j : j + 1].to(hip))
     scale, _, zero, Q = gq.fasterquant(
@@ -319,8 +327,8 @@ def test_gptq_layer_end_to_end(hip, golden, tag):
     )
     ref_ints = golden[f"{tag}_ints"].astype(np.int32) + (2 ** (kw["bits"] - 1) if kw["sym"] else 0)
     match = float((gq.codes.cpu().numpy().astype(np.int32) == ref_ints).mean())
-    assert match >= 0.99, f"only {match:.4f} of the codes match the reference"
-    assert rel_fro(scale.cpu(), torch.from_numpy(golden[f"{tag}_scale"])) <= 1e-3
+    assert match >= (0.97 if kw.get("mse") else 0.99), f"only {match:.4f} of the codes match the reference"
+    assert rel_fro(scale.cpu(), torch.from_numpy(golden[f"{tag}_scale"])) <= (1e-2 if kw.get("mse") else 1e-3)
     if not kw["sym"]:
         assert float((zero.cpu() != torch.from_numpy(golden[f"{tag}_zero"])).float().mean()) <= 0.01
     assert rel_fro(Q.cpu(), torch.from_numpy(golden[f"{tag}_Q"])) <= 3e-2

@@ -91,6 +91,8 @@ GQ_CASES = {
     "gq_sym_g32_blk2048": dict(bits=4, sym=True, blocksize=2048, groupsize=32),
     "gq_sym_act": dict(bits=4, sym=True, blocksize=128, groupsize=32, act_order=True),
     "gq_sym8_g64": dict(bits=8, sym=True, blocksize=128, groupsize=64),
+    "gq_sym_g32_mse": dict(bits=4, sym=True, blocksize=128, groupsize=32, mse=True),
+    "gq_asym_g64_mse": dict(bits=4, sym=False, blocksize=128, groupsize=64, mse=True),
 }
 
 
