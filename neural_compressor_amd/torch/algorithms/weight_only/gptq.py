@@ -270,8 +270,6 @@ class GPTQ:
         the integer codes (uint8 [N,K], original column order) are left in `self.codes`."""
         if hybrid_order or fp8_aware:
             raise NotImplementedError("hybrid_order / fp8_aware are Gaudi W4A8 options outside the MI355X scope")
-        if act_order and static_groups:
-            raise NotImplementedError("act_order together with static_groups is not implemented yet")
         bits = int(self.cfg.get("bits", 4))
         sym = bool(self.cfg.get("sym", False))
         mse = bool(self.cfg.get("mse", False))  # GPTQConfig(use_mse_search=True): shrink-grid search in find_params
@@ -298,15 +296,24 @@ class GPTQ:
         w32 = ops.gptq_prepare_weight(W, dead)
         if static_groups:
             ops.gptq_find_params(w32, 0, gs, G, bits, sym, scale, zero, 0, mse=mse)
+        loop_scale, loop_zero = scale, zero
         if act_order:
             w32 = w32[:, perm].contiguous()
             self.perm = perm.clone()
+            if static_groups and groupsize != -1:
+                # the column at permuted position p keeps the parameters of its ORIGINAL group perm[p] // groupsize
+                # (gptq.py:1273-1277): hand the column loop one (scale, zero) per column, i.e. group size 1
+                col_group = torch.div(perm, gs, rounding_mode="floor")
+                loop_scale = scale[:, col_group].contiguous()
+                loop_zero = zero[:, col_group].contiguous()
 
         codes = torch.empty((N, K), dtype=torch.uint8, device=W.device)
         Q = torch.empty((N, K), dtype=weight_dtype, device=W.device)
         err = torch.empty((N, QBLOCK), dtype=torch.float32, device=W.device)
         dynamic_groups = groupsize != -1 and not static_groups
         kernel_gs = gs if groupsize != -1 else 0
+        if loop_scale is not scale:
+            kernel_gs = 1
         blocksize = int(blocksize) if blocksize and blocksize > 0 else K
         i1 = 0
         while i1 < K:
@@ -318,7 +325,7 @@ class GPTQ:
                 g_last = (ref_end - 1) // gs
                 if g_last >= g_first:
                     ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first, mse=mse)
-            ops.gptq_quant_block(w32, Hinv, scale, zero, codes, Q, err, i1, count, kernel_gs, bits)
+            ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, err, i1, count, kernel_gs, bits)
             ops.gptq_lazy_update(w32, Hinv, err, i1, count)
             i1 += count
         logger.debug("fasterquant %dx%d issued in %.3fs", N, K, time.time() - tick)
@@ -328,6 +335,10 @@ class GPTQ:
             Q = Q[:, invperm].contiguous()
             codes = codes[:, invperm].contiguous()
         self.codes = codes
+        # with static groups the parameters belong to contiguous ORIGINAL-order groups: the packed module needs no g_idx.
+        # (The reference returns only the last group's scale in this mode (:1341-1345) and its export then indexes past
+        # it (utility.py:522); the [N, G] table is what that code means to produce.)
+        self.export_perm = None if (static_groups or not act_order) else self.perm
         if self.is_conv1d:
             Q = Q.t().contiguous()
         Q = Q.reshape(weight_shape)
@@ -587,7 +598,7 @@ class RAWGPTQuantizer(object):
                     act_order=cfg["act_order"], hybrid_order=cfg["hybrid_order"], fp8_aware=cfg["fp8_aware"],
                     static_groups=cfg["static_groups"],
                 )
-                codes, perm = sv.codes, sv.perm
+                codes, perm = sv.codes, sv.export_perm
                 r0 = 0
                 for n in names:
                     rows = layers[n].weight.shape[0]

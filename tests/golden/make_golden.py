@@ -140,7 +140,7 @@ def main():
     out["clip_asym4_g128"] = np.float64(search_clip(lin, bits=4, group_size=128, scheme="asym"))
 
     # ---- 5. GPTQ: add_batch + fasterquant on small layers ---------------------------------------------------
-    def run_gptq(tag, N, K, nb, seq, cfg, blocksize, groupsize, act_order=False):
+    def run_gptq(tag, N, K, nb, seq, cfg, blocksize, groupsize, act_order=False, static_groups=False):
         layer = torch.nn.Linear(K, N, bias=False)
         W = torch.randn(N, K, generator=g) * 0.05
         layer.weight.data.copy_(W)
@@ -156,7 +156,8 @@ def main():
             xs.append(x)
             gq.add_batch(x, None)
         H = gq.H.clone()
-        scale, _, zero, Q = gq.fasterquant(W.clone(), blocksize=blocksize, percdamp=0.01, groupsize=groupsize, act_order=act_order)
+        scale, _, zero, Q = gq.fasterquant(W.clone(), blocksize=blocksize, percdamp=0.01, groupsize=groupsize, act_order=act_order,
+                                           static_groups=static_groups)
         out[f"{tag}_W"] = W.numpy()
         out[f"{tag}_X"] = torch.cat(xs, 0).numpy()
         out[f"{tag}_H"] = H.numpy()
@@ -165,6 +166,8 @@ def main():
         out[f"{tag}_Q"] = Q.numpy()
         if act_order:
             out[f"{tag}_perm"] = gq.perm.numpy()
+        if static_groups:
+            return  # the reference returns only the last group's scale here (gptq.py:1341-1345): Q is the checked quantity
         ints = quant_weight_w_scale(
             (Q[:, gq.perm] if act_order else Q).clone(), scale, None, None if full["sym"] else zero, groupsize, dtype="int"
         )
@@ -182,6 +185,10 @@ def main():
     # use_mse_search: Quantizer.find_params shrink grid (gptq.py:1567-1584; reference test test_gptq.py:137)
     run_gptq("gq_sym_g32_mse", 16, 128, 4, 48, dict(bits=4, sym=True, mse=True), 128, 32)
     run_gptq("gq_asym_g64_mse", 12, 128, 4, 48, dict(bits=4, sym=False, mse=True), 128, 64)
+
+    # static_groups (no reference test; Q of fasterquant is the well-defined output)
+    run_gptq("gq_sym_static", 16, 128, 4, 48, dict(bits=4, sym=True), 128, 32, static_groups=True)
+    run_gptq("gq_asym_act_static", 16, 256, 4, 80, dict(bits=4, sym=False), 128, 32, act_order=True, static_groups=True)
 
     # ---- 6. AWQ statistics ---------------------------------------------------------------------------------------
     w = torch.randn(24, 128, generator=g)

@@ -344,6 +344,40 @@ def test_gptq_layer_end_to_end(hip, golden, tag):
     assert np.array_equal(m.scales.cpu().numpy().view(np.uint16), osc.view(np.uint16))
 
 
+@pytest.mark.parametrize("tag,kw", [
+    ("gq_sym_static", dict(bits=4, sym=True, blocksize=128, groupsize=32, static_groups=True)),
+    ("gq_asym_act_static", dict(bits=4, sym=False, blocksize=128, groupsize=32, act_order=True, static_groups=True)),
+])
+def test_gptq_static_groups(hip, golden, tag, kw):
+    """static_groups (with and without act_order): Q against the reference's fasterquant output; the [N, G] parameter
+    table (which the reference truncates to its last group) must dequantise the emitted codes to exactly Q, in the
+    ORIGINAL column order and without a g_idx."""
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import GPTQ
+
+    W = torch.from_numpy(golden[f"{tag}_W"])
+    X = torch.from_numpy(golden[f"{tag}_X"])
+    N, K = W.shape
+    gs = kw["groupsize"]
+    layer = torch.nn.Linear(K, N, bias=False).to(hip)
+    layer.weight.data.copy_(W)
+    gq = GPTQ(layer, device=hip)
+    gq.configure(dict(bits=kw["bits"], sym=kw["sym"], dtype="int", mse=False))
+    for j in range(X.shape[0]):
+        gq.add_batch(X[j : j + 1].to(hip))
+    scale, _, zero, Q = gq.fasterquant(layer.weight.data, blocksize=kw["blocksize"], percdamp=0.01, groupsize=gs,
+                                       act_order=kw.get("act_order", False), static_groups=True)
+    assert scale.shape == (N, K // gs) and gq.export_perm is None
+    # the last group's parameters are what the reference hands back: bit-exact (computed from the untouched W)
+    last = int(golden[f"{tag}_perm"][-1]) // gs if kw.get("act_order") else K // gs - 1
+    assert np.array_equal(scale[:, last : last + 1].cpu().numpy(), golden[f"{tag}_scale"])
+    assert np.array_equal(zero[:, last : last + 1].cpu().numpy(), golden[f"{tag}_zero"])
+    refQ = torch.from_numpy(golden[f"{tag}_Q"])
+    assert rel_fro(Q.cpu(), refQ) <= 3e-2
+    assert float((Q.cpu() == refQ).float().mean()) >= 0.98
+    deq = scale.repeat_interleave(gs, 1) * (gq.codes.float() - zero.repeat_interleave(gs, 1))
+    assert torch.equal(deq, Q)
+
+
 def test_gptq_full_size_layer_properties(hip):
     """BASELINE size (4096x4096, g128, sym): size-independent properties -- every dequantised weight lies on its
     group's grid, codes are in range, GPTQ's output error (X W^T) beats RTN's, pack->recover reproduces Q."""

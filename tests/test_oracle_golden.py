@@ -113,6 +113,20 @@ def test_gptq_layer(golden, tag):
     assert np.array_equal(ints.numpy(), golden[f"{tag}_ints"].astype(np.int32))
 
 
+@pytest.mark.parametrize("tag,kw", [
+    ("gq_sym_static", dict(bits=4, sym=True, blocksize=128, groupsize=32, static_groups=True)),
+    ("gq_asym_act_static", dict(bits=4, sym=False, blocksize=128, groupsize=32, act_order=True, static_groups=True)),
+])
+def test_gptq_static_groups(golden, tag, kw):
+    """static_groups: the reference returns only the last group's (scale, zero) (gptq.py:1341-1345); Q is the output."""
+    W = torch.from_numpy(golden[f"{tag}_W"])
+    r = O.gptq_fasterquant(W, torch.from_numpy(golden[f"{tag}_H"]), **kw)
+    assert np.array_equal(r["Q"].numpy(), golden[f"{tag}_Q"])
+    assert np.array_equal(r["scale"].numpy(), golden[f"{tag}_scale"])
+    if kw.get("act_order"):
+        assert np.array_equal(r["perm"].numpy(), golden[f"{tag}_perm"])
+
+
 def test_awq_stats(golden):
     w = torch.from_numpy(golden["awq_w"])
     assert np.array_equal(O.awq_weight_scale(w, 32).numpy(), golden["awq_wscale_g32"])
