@@ -373,8 +373,6 @@ class RAWGPTQuantizer(object):
         self.dtype = next(iter(self.model.parameters())).dtype
         self.weight_config = weight_config
         self.quant_lm_head = quant_lm_head
-        if quant_lm_head:
-            raise NotImplementedError("quant_lm_head=True for GPTQ is not implemented yet on MI355X")
         self.check_layer_config()
         self.device = torch.device(get_accelerator(device or "auto").current_device_name())
         self.is_ready = False
@@ -514,8 +512,54 @@ class RAWGPTQuantizer(object):
             if self.block_callback is not None:
                 self.block_callback(block_idx, block)
             logger.info("Quantized block %d / %d in %.2fs", block_idx + 1, len(blocks), time.time() - t0)
+        if self.quant_lm_head:
+            self.quantize_post_layer()
         logger.info("Quantization done")
         return self.model
+
+    @torch.no_grad()
+    def quantize_post_layer(self):
+        """Step 2.7 (reference :887-1080): GPTQ on the layer that follows the transformer stack (lm_head).
+
+        Like the reference, the layer is calibrated on the LAST BLOCK'S OUTPUTS as cached (:937-941) -- the final norm
+        that sits between them in the real model is not applied; restated as is so the packed lm_head is the same."""
+        post = self.gptq_related_blocks["transformers_post"]
+        if not post:
+            logger.warning("quant_lm_head=True but no layer follows the transformer stack")
+            return
+        full, layer = post["name"], post["layer"]
+        cfg = self.get_layer_config(full)
+        if cfg is None or not isinstance(layer, SUPPORTED_LAYERS):
+            logger.warning("%s can be quantized but excluded from quantization configs.", full)
+            return
+        logger.info("Quantizing post transformer layers")
+        layer.to(self.device)
+        solver = GPTQ(layer, device=self.device)
+        solver.configure(cfg)
+        handle = layer.register_forward_hook(lambda _, inp, out: solver.add_batch(inp[0].data))
+        for j in range(self.cache_key_arguments["batch_num"]):
+            if "hidden_states" in self.cache_key_arguments:
+                layer(self.cache_key_arguments["hidden_states"][j])
+            else:
+                layer(self.cache_positional_arguments[0][j])
+        handle.remove()
+        scale, _, zp, Q = solver.fasterquant(
+            layer.weight.data, blocksize=cfg["block_size"], percdamp=cfg["percdamp"], groupsize=cfg["group_size"],
+            act_order=cfg["act_order"], hybrid_order=cfg["hybrid_order"], fp8_aware=cfg["fp8_aware"],
+            static_groups=cfg["static_groups"],
+        )
+        if isinstance(layer, nn.Linear):
+            in_features, out_features = layer.in_features, layer.out_features
+        else:
+            in_features, out_features = layer.weight.shape[0], layer.weight.shape[1]
+        zero = None if cfg["sym"] else zp
+        new_module = MI355XWeightOnlyLinear(
+            in_features, out_features, dtype=cfg["dtype"], bits=cfg["bits"], group_size=cfg["group_size"],
+            zp=zero is not None, bias=layer.bias is not None, g_idx=solver.export_perm is not None, device=self.device,
+        )
+        new_module.pack_codes(solver.codes, scale, zero, layer.bias, g_idx=solver.export_perm)
+        solver.free()
+        set_module(self.model, full, new_module)
 
     @torch.no_grad()
     def quantize_block(self, block, block_idx, seq_map=None):

@@ -151,6 +151,7 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         adds the sym shift / subtracts 1 from zp in place)."""
         dev = self.qweight.device
         N, K = self.out_features, self.in_features
+        self._plan_key = None  # the kernels write the buffers through raw pointers: drop the cached forward plan
         if bias is not None:
             assert hasattr(self, "bias"), "bias is not set when initializing."
             self.bias = bias.detach().to(dev).type(self.float_type)
@@ -199,6 +200,7 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         `pack(codes - 2^(bits-1), scales, None, ...)` for sym and `pack(codes, scales, zp, ...)` for asym."""
         assert self.use_optimum_format, "pack_codes writes the optimum layout"
         dev = self.qweight.device
+        self._plan_key = None
         if bias is not None:
             self.bias = bias.detach().to(dev).type(self.float_type)
         if g_idx is not None:
@@ -255,22 +257,62 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         x2d = x.reshape(-1, self.in_features)
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
-        trivial_g_idx = self.g_idx is None or getattr(self, "_g_idx_trivial", None)
-        if trivial_g_idx is None:
-            ref = torch.arange(self.in_features, device=self.g_idx.device, dtype=torch.int32) // self.group_size
-            trivial_g_idx = bool(torch.equal(self.g_idx.to(torch.int32), ref))
-            self._g_idx_trivial = trivial_g_idx
-        if self.use_optimum_format and self.bits in (4, 8) and trivial_g_idx and self.group_size % self.n_pack == 0:
+        plan = self._forward_plan()
+        if plan == "fused":
             y = ops.woq_gemm(
                 x2d, self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features,
                 self.group_size, self.bits,
             )
+        elif plan == "fused_act_order":
+            # act_order: the K axis is sorted by group once (below); per call only the activations are gathered
+            y = ops.woq_gemm(
+                x2d.index_select(1, self._k_order), self._qweight_sorted, self.scales, self.qzeros, self.bias,
+                self.out_features, self.in_features, self.group_size, self.bits,
+            )
         else:
-            # act_order (per-element g_idx), 2-bit or non-optimum layouts: HIP dequant + dense library GEMM
+            # 2-bit / odd widths, non-optimum layouts, irregular g_idx: HIP dequant + dense library GEMM
             w = self.recover(dtype=x2d.dtype)
             b = None if self.bias is None else self.bias.to(x2d.dtype)
             y = torch.nn.functional.linear(x2d, w, b)
         return y.reshape(*lead, self.out_features)
+
+    def _forward_plan(self):
+        """Pick the forward route once per packed state.  A per-element `g_idx` (GPTQ act_order, HF desc_act
+        checkpoints; modules.py:341-344) that is a permutation of whole groups is handled by sorting the K axis by group:
+        x W^T = x[:, p] W[:, p]^T, and in the sorted order the groups are contiguous again, so the fused kernel runs on a
+        K-sorted copy of the packed words with only an activation gather per call."""
+        # in-place re-packing / load_state_dict bump the tensors' version counters -> the plan is rebuilt
+        key = (self.qweight.data_ptr(), self.qweight._version,
+               None if self.g_idx is None else (self.g_idx.data_ptr(), self.g_idx._version))
+        if getattr(self, "_plan_key", None) == key:
+            return self._plan
+        plan = "dense"
+        fusable = self.use_optimum_format and self.bits in (4, 8) and self.group_size % self.n_pack == 0
+        self._k_order = self._qweight_sorted = None
+        if fusable:
+            K, gs = self.in_features, self.group_size
+            if self.g_idx is None:
+                plan = "fused"
+            else:
+                g = self.g_idx.to(torch.int64)
+                contiguous = torch.arange(K, device=g.device) // gs
+                if torch.equal(g, contiguous):
+                    plan = "fused"
+                elif K % self.n_pack == 0:
+                    order = torch.argsort(g, stable=True)
+                    if torch.equal(g[order], contiguous):
+                        bits, npk = self.bits, self.n_pack
+                        shifts = (torch.arange(npk, device=g.device, dtype=torch.int32) * bits).view(1, npk, 1)
+                        mask = (1 << bits) - 1
+                        codes = ((self.qweight.unsqueeze(1) >> shifts) & mask).reshape(K, -1)  # [K, N] fields
+                        codes = codes.index_select(0, order).reshape(K // npk, npk, -1)
+                        words = (codes.to(torch.int64) << shifts.to(torch.int64)).sum(dim=1)  # disjoint fields, < 2^32
+                        words = torch.where(words >= 2**31, words - 2**32, words)
+                        self._qweight_sorted = words.to(torch.int32).contiguous()
+                        self._k_order = order
+                        plan = "fused_act_order"
+        self._plan_key, self._plan = key, plan
+        return plan
 
     def extra_repr(self):
         s = super().extra_repr()

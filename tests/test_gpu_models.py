@@ -121,6 +121,48 @@ def test_gptq_prepare_convert_equals_quantize():
         assert torch.equal(ma[n].scales, mb[n].scales), n
 
 
+def test_gptq_quant_lm_head_matches_oracle_on_last_block_outputs():
+    """GPTQConfig(quant_lm_head=True): step 2.7 of the reference (gptq.py:887-1080) calibrates lm_head on the last
+    block's cached outputs.  (Run through prepare/convert the reference itself iterates an EMPTY dataloader there
+    (:283, :935): zero Hessian, every column 'dead', lm_head packed as all-zero weights -- so the check is the oracle's
+    fasterquant on the Hessian of those outputs, not a model-level golden.)"""
+    import oracle.woq_oracle as O
+    from neural_compressor_amd.torch.quantization import GPTQConfig, quantize
+
+    ids = calib_ids()
+
+    def run_fn(model):
+        for x in ids:
+            model(x)
+
+    cfg = dict(bits=4, group_size=32, use_sym=True, block_size=128)
+    q = quantize(tiny_llama(), GPTQConfig(quant_lm_head=True, **cfg), run_fn=run_fn)
+    mods = _woq_modules(q)
+    assert len(mods) == 15 and "lm_head" in mods
+    base = quantize(tiny_llama(), GPTQConfig(**cfg), run_fn=run_fn)
+    assert "lm_head" not in _woq_modules(base)
+    seen = []
+    h = base.model.layers[-1].register_forward_hook(lambda _, i, o: seen.append((o[0] if isinstance(o, tuple) else o).float().cpu()))
+    with torch.no_grad():
+        for x in ids:
+            base(x.to("cuda"))
+    h.remove()
+    K = base.lm_head.weight.shape[1]
+    H, n = torch.zeros(K, K), 0
+    for x in seen:
+        H, n = O.gptq_add_batch(H, n, x.reshape(1, -1, K))
+    r = O.gptq_fasterquant(base.lm_head.weight.detach().float().cpu(), H, bits=4, sym=True, blocksize=128, groupsize=32)
+    ints = O.gptq_export_ints(r["Q"], r["scale"], r["zero"], True, 32, None)
+    got = mods["lm_head"].unpack()["int_weight"].cpu().to(torch.int32)
+    assert float((got == ints + 8).float().mean()) >= 0.97  # sym: the packed field is the code + 2^(bits-1)
+    assert float((got != got.flatten()[0]).float().mean()) > 0.5  # not the degenerate all-equal packing
+    fp = tiny_llama().to("cuda")
+    with torch.no_grad():
+        ref = fp(ids[0].to("cuda")).logits.float()
+        y = q(ids[0].to("cuda")).logits.float()
+    assert float((y - ref).norm() / ref.norm()) <= 0.25
+
+
 def test_gptq_beats_rtn_on_block_output():
     """Reference test_gptq.py:62-80 (GPTQ closer to the float model than RTN), on a bf16 Llama."""
     from neural_compressor_amd.torch.quantization import GPTQConfig, RTNConfig, quantize

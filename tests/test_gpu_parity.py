@@ -129,6 +129,37 @@ def test_dequant_with_g_idx(hip):
     assert np.array_equal(rec.cpu().numpy(), orec)
 
 
+@pytest.mark.parametrize("bits,M,dt", [(4, 1, torch.float16), (4, 8, torch.bfloat16), (4, 300, torch.float16), (8, 33, torch.bfloat16)])
+def test_forward_with_act_order_g_idx_runs_fused(hip, bits, M, dt):
+    """A module packed with a per-element g_idx (GPTQ act_order / HF desc_act, modules.py:341-344) takes the fused
+    kernel on a K-sorted copy of the words; result == x @ recover()^T, where recover() is pinned against the oracle
+    above, and re-packing in place invalidates the cached plan."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    g = torch.Generator().manual_seed(11 + M)
+    N, K, gs = 256, 512, 128
+    hi = 2 ** bits
+    iw = torch.randint(0, hi, (N, K), generator=g, dtype=torch.int32)
+    sc = torch.rand(N, K // gs, generator=g) * 0.02 + 0.002
+    zp = torch.randint(1, hi, (N, K // gs), generator=g, dtype=torch.int32)
+    perm = torch.randperm(K, generator=g)
+    m = MI355XWeightOnlyLinear(K, N, bits=bits, group_size=gs, zp=True, g_idx=True, device=hip)
+    m.pack(iw.to(hip), sc.to(hip), zp.to(hip), None, g_idx=perm.to(hip))
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dt).to(hip)
+    y = m(x)
+    assert m._plan == "fused_act_order"
+    w = m.recover(dtype=torch.float32)
+    ref = x.float() @ w.T
+    assert rel_fro(y.float().cpu(), ref.cpu()) <= 5e-3
+    # same codes, another permutation, packed into the same storage: the plan must follow
+    perm2 = torch.randperm(K, generator=g)
+    m.pack(iw.to(hip), sc.to(hip), zp.to(hip), None, g_idx=perm2.to(hip))
+    y2 = m(x)
+    ref2 = x.float() @ m.recover(dtype=torch.float32).T
+    assert rel_fro(y2.float().cpu(), ref2.cpu()) <= 5e-3
+    assert rel_fro(ref2.cpu(), ref.cpu()) > 0.1  # the two layouts really are different matrices
+
+
 # ---------------------------------------------------------------------------------------------------
 # K7 RTN
 # ---------------------------------------------------------------------------------------------------
