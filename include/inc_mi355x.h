@@ -232,6 +232,17 @@ int64_t inc_awq_weight_scale_workspace_bytes(int64_t N, int64_t K, int group_siz
 int inc_awq_weight_scale(const void* w, int wdtype, int64_t N, int64_t K, int group_size, float* out,
                          void* workspace, int64_t workspace_bytes, inc_stream_t stream);
 
+/* ---- K9: AutoAWQ checkpoint words -> optimum layout -------------------------------------------- *
+ * == repack_awq_to_optimum_format (weight_only/utility.py:1426-1459 = unpack_awq :1273 + awq_reverse_reorder_int_tensor
+ *    :1246 + pack_from_tensors :1355), called by repack_awq_and_load_state_dict
+ *    (transformers/quantization/utils.py:655-697) when an AutoAWQ checkpoint is loaded.  Integer field shuffle:
+ *   awq_qweight [K, N/8] int32 (field i of word (k,c) = code(k, 8c + {0,2,4,6,1,3,5,7}[i]))  ->  qweight [K/8, N] int32
+ *   awq_qzeros  [G, N/8] int32 (same field order, plain zero points)                       ->  qzeros  [G, N/8] int32
+ *                                                                                            (sequential, (z-1)&15)
+ * scales [G, N] fp16 are shared unchanged.  bits must be 4 (as in the reference); K % 8 == 0, N % 8 == 0.      */
+int inc_awq_repack(const int32_t* awq_qweight, const int32_t* awq_qzeros, int64_t K, int64_t N, int64_t G, int bits,
+                   int32_t* qweight, int32_t* qzeros, inc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ SIGNATURES = {
         c_int,
         [_P, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, _P, _P, c_int64, c_int64, _P],
     ),
+    "inc_awq_repack": (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int, _P, _P, _P]),
     "inc_gptq_find_params_mse": (
         c_int,
         [_P, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, _P, c_int64, c_int64, _P],

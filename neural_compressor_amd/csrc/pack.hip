@@ -491,3 +491,71 @@ int inc_dequant_ints(const int16_t* int_weight, const void* scales, int scale_dt
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// AutoAWQ "GEMM" checkpoint words -> optimum layout (reference weight_only/utility.py:1245-1459:
+// unpack_awq + awq_reverse_reorder_int_tensor + pack_from_tensors; caller transformers/quantization/utils.py:655-697).
+//   AWQ:     qweight [K, N/8] int32, field i of word (k, c) = code(k, 8c + AWQ_ORDER[i]),  AWQ_ORDER = 0,2,4,6,1,3,5,7
+//            qzeros  [G, N/8] int32, same field order, zero points stored as they are
+//   optimum: qweight [K/8, N] int32, field r of word (k/8, n) = code(8*(k/8) + r, n)
+//            qzeros  [G, N/8] int32, field j of word (g, c) = (zero(g, 8c + j) - 1) & 15
+// A pure 4-bit field shuffle, HBM-bound (reads and writes K*N/2 bytes once).  One thread owns an 8(k) x 8(n) tile:
+// 8 coalesced word reads (one per k), an 8x8 nibble transpose in registers, one 32-byte store.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t awq_field_of_column(int j) {
+  // column 8c + j sits in field AWQ_ORDER^-1[j] = {0,4,1,5,2,6,3,7}[j]
+  return (uint32_t)(((j & 1) << 2) | (j >> 1));
+}
+
+__global__ __launch_bounds__(256) void awq_repack_weight_kernel(const uint32_t* __restrict__ awq, uint32_t* __restrict__ out,
+                                                                int64_t K8, int64_t NW) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // AWQ word column (8 output columns)
+  const int64_t kb = blockIdx.y;                                      // block of 8 input rows
+  if (c >= NW || kb >= K8) return;
+  uint32_t w[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) w[r] = awq[(kb * 8 + r) * NW + c];
+  uint32_t o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t sh = 4u * awq_field_of_column(j);
+    uint32_t v = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v |= ((w[r] >> sh) & 15u) << (4 * r);
+    o[j] = v;
+  }
+  uint4* dst = reinterpret_cast<uint4*>(out + kb * NW * 8 + c * 8);
+  dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+__global__ __launch_bounds__(256) void awq_repack_zeros_kernel(const uint32_t* __restrict__ awq, uint32_t* __restrict__ out,
+                                                               int64_t words) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= words) return;
+  const uint32_t w = awq[i];
+  uint32_t v = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t z = (w >> (4u * awq_field_of_column(j))) & 15u;
+    v |= ((z - 1u) & 15u) << (4 * j);
+  }
+  out[i] = v;
+}
+
+int inc_awq_repack(const int32_t* awq_qweight, const int32_t* awq_qzeros, int64_t K, int64_t N, int64_t G, int bits,
+                   int32_t* qweight, int32_t* qzeros, inc_stream_t stream) {
+  INC_CHECK_ARG(awq_qweight && awq_qzeros && qweight && qzeros && K > 0 && N > 0 && G > 0);
+  if (bits != 4) return INC_ERR_UNSUPPORTED;  // the reference asserts bits == 4 too (utility.py:1252, 1301, 1378)
+  INC_CHECK_ARG((K % 8) == 0 && (N % 8) == 0);
+  const int64_t NW = N / 8, K8 = K / 8;
+  INC_CHECK_ARG(K8 <= 65535);
+  hipStream_t s = inc_s(stream);
+  awq_repack_weight_kernel<<<dim3((unsigned)ceil_div64(NW, 256), (unsigned)K8), 256, 0, s>>>(
+      reinterpret_cast<const uint32_t*>(awq_qweight), reinterpret_cast<uint32_t*>(qweight), K8, NW);
+  const int64_t zw = G * NW;
+  awq_repack_zeros_kernel<<<(unsigned)ceil_div64(zw, 256), 256, 0, s>>>(
+      reinterpret_cast<const uint32_t*>(awq_qzeros), reinterpret_cast<uint32_t*>(qzeros), zw);
+  INC_LAUNCH_RETURN();
+}

@@ -131,6 +131,23 @@ def woq_unpack(qweight, qzeros, N, K, G, bits, want_weight=True, want_zp=True):
     return iw, zp
 
 
+def awq_repack(awq_qweight, awq_qzeros, bits=4):
+    """AutoAWQ GEMM-format words -> optimum layout (== repack_awq_to_optimum_format, utility.py:1426-1459).
+    awq_qweight [K, N/8] int32, awq_qzeros [G, N/8] int32 -> (qweight [K/8, N], qzeros [G, N/8]); scales are shared."""
+    dev = _dev(awq_qweight, awq_qzeros)
+    assert awq_qweight.dtype == torch.int32 and awq_qzeros.dtype == torch.int32
+    awq_qweight, awq_qzeros = awq_qweight.contiguous(), awq_qzeros.contiguous()
+    K, NW = awq_qweight.shape
+    G = awq_qzeros.shape[0]
+    N = NW * (32 // bits)
+    qweight = torch.empty((K // (32 // bits), N), dtype=torch.int32, device=dev)
+    qzeros = torch.empty((G, NW), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_awq_repack(_ptr(awq_qweight), _ptr(awq_qzeros), K, N, G, bits, _ptr(qweight), _ptr(qzeros), _stream()),
+              "inc_awq_repack")
+    return qweight, qzeros
+
+
 def woq_dequant(qweight, scales, qzeros, g_idx, N, K, group_size, bits, out_dtype=torch.float16):
     """== INCWeightOnlyLinear.recover (modules.py:413-443) from the optimum layout -> dense [N,K]."""
     dev = _dev(qweight, scales, qzeros, g_idx)

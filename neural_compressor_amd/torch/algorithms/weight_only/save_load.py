@@ -22,6 +22,7 @@ import re
 
 import torch
 
+from .... import ops
 from ....common.utils import logger
 from ...utils.utility import set_module
 from .modules import MI355XWeightOnlyLinear, MulLinear
@@ -133,7 +134,15 @@ def _build(original_model, state, quantization_config, device):
             full = f"{target}.{k}"
             if full in state:
                 own[k] = state.pop(full)
-        missing = new.load_state_dict({k: v.to(device) for k, v in own.items()}, strict=False)
+        own = {k: v.to(device) for k, v in own.items()}
+        n_pack = 32 // new.bits
+        awq_shape = (module.in_features, module.out_features // n_pack)
+        if "qweight" in own and tuple(own["qweight"].shape) == awq_shape and awq_shape != tuple(new.qweight.shape):
+            # an AutoAWQ "GEMM" checkpoint ([K, N/8] words, interleaved fields): shuffle to the optimum layout on the
+            # device (reference repack_awq_and_load_state_dict, transformers/quantization/utils.py:655-697)
+            own["qweight"], own["qzeros"] = ops.awq_repack(own["qweight"], own["qzeros"], new.bits)
+            own["scales"] = own["scales"].to(torch.float16)
+        missing = new.load_state_dict(own, strict=False)
         if "qweight" in missing.missing_keys or "scales" in missing.missing_keys:
             raise RuntimeError(f"checkpoint is missing packed buffers of {target}")
         set_module(original_model, target, new)
@@ -178,8 +187,9 @@ def load(model_name_or_path, original_model=None, format="default", device="cuda
         assert qcfg.get("quant_method", "gptq") in ("gptq", "awq", "rtn", "intel/auto-round", "autoround"), qcfg.get("quant_method")
         if hasattr(config, "quantization_config"):
             delattr(config, "quantization_config")  # keep HF from looking for its own GPTQ kernels
+        model_class = kwargs.get("model_class") or AutoModelForCausalLM
         with torch.device("meta"):
-            model = AutoModelForCausalLM.from_config(config)
+            model = model_class.from_config(config)
         state = {}
         from safetensors.torch import load_file
 

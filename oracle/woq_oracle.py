@@ -403,6 +403,35 @@ def gptq_export_ints(Q, scale, zero, sym, group_size, perm=None):
 
 
 # =====================================================================================================
+# AutoAWQ checkpoint repack
+# =====================================================================================================
+AWQ_ORDER = [0, 2, 4, 6, 1, 3, 5, 7]  # utility.py:1257
+
+
+def awq_unpack_fields(words, bits=4):
+    """unpack_awq's integer part (utility.py:1305-1327): [R, C/8] int32 -> [R, C] with the AWQ field order undone
+    (awq_reverse_reorder_int_tensor :1246-1270: column 8c + AWQ_ORDER[i] is field i)."""
+    w = np.asarray(words).astype(np.uint32)
+    n_pack = 32 // bits
+    raw = np.stack([(w >> np.uint32(bits * i)) & np.uint32(2**bits - 1) for i in range(n_pack)], axis=-1)  # [R, C/8, 8]
+    out = np.empty_like(raw)
+    for i, col in enumerate(AWQ_ORDER):
+        out[..., col] = raw[..., i]
+    return out.reshape(w.shape[0], -1).astype(np.int32)
+
+
+def awq_repack_to_optimum(awq_qweight, awq_qzeros, bits=4):
+    """repack_awq_to_optimum_format (utility.py:1426-1459), integer restatement: the reference dequantises to fp16
+    (unpack_awq :1329-1341) and re-rounds (pack_from_tensors :1395-1399), which returns the same integers.
+    -> qweight [K/8, N] int32 (K-major fields), qzeros [G, N/8] int32 (sequential fields of zero-1)."""
+    codes = awq_unpack_fields(awq_qweight, bits)  # [K, N]
+    zeros = awq_unpack_fields(awq_qzeros, bits)   # [G, N]
+    qweight = pack_rows(np.ascontiguousarray(codes.T), bits, 32)  # [N, K/8]  (:1404-1413)
+    qzeros = pack_rows((zeros - 1) & (2**bits - 1), bits, 32)      # [G, N/8]  (:1415-1431)
+    return np.ascontiguousarray(qweight.T), qzeros
+
+
+# =====================================================================================================
 # AWQ statistics
 # =====================================================================================================
 def awq_weight_scale(weight, q_group_size=-1):

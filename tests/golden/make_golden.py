@@ -199,6 +199,18 @@ def main():
     out["awq_x"] = torch.cat(xs, 0).numpy()
     out["awq_xscale"] = ref_awq._get_act_scale(xs).numpy()
 
+    # ---- 6b. AutoAWQ checkpoint repack (utility.py:1426-1459) ---------------------------------------------------
+    from neural_compressor.torch.algorithms.weight_only.utility import repack_awq_to_optimum_format
+
+    Ka, Na, gsa = 256, 128, 128  # unpack_awq reshapes through [-1, group_size, K]: N must be a multiple of group_size
+    aq = torch.randint(-(2**31), 2**31 - 1, (Ka, Na // 8), generator=g, dtype=torch.int64).to(torch.int32)
+    az = torch.randint(-(2**31), 2**31 - 1, (Ka // gsa, Na // 8), generator=g, dtype=torch.int64).to(torch.int32)
+    asc = (torch.rand(Ka // gsa, Na, generator=g) * 0.02 + 0.004).half()
+    rq, rz, rs = repack_awq_to_optimum_format(aq.clone(), az.clone(), asc.clone(), 4, gsa)
+    out["awqpack_qweight_in"], out["awqpack_qzeros_in"], out["awqpack_scales"] = aq.numpy(), az.numpy(), asc.numpy()
+    out["awqpack_qweight"], out["awqpack_qzeros"] = rq.numpy(), rz.numpy()
+    assert torch.equal(rs, asc)
+
     np.savez_compressed(os.path.join(HERE, "woq_golden.npz"), **out)
     print(f"wrote {len(out)} arrays to tests/golden/woq_golden.npz")
 

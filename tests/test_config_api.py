@@ -1,5 +1,6 @@
 """CPU: config / registry semantics the reference's tests pin (test/torch/test_config.py bodies, test/common/test_common.py)."""
 
+import pytest
 import torch
 
 from neural_compressor_amd.common import ComposableConfig, config_registry
@@ -130,3 +131,35 @@ def test_2x_named_shim_translates_to_3x_configs():
         PostTrainingQuantConfig(approach="static")
     with pytest.raises(ValueError):
         quantization.fit(None, PostTrainingQuantConfig(op_type_dict={".*": {"weight": {"algorithm": "GPTQ"}}}))
+
+
+def test_front_end_configs_roundtrip(tmp_path):
+    """neural_compressor.transformers config classes: defaults, serialised keys, reload (quantization_config.py:242-456)."""
+    from neural_compressor_amd.transformers import AwqConfig, GPTQConfig, RtnConfig, TeqConfig
+    from neural_compressor_amd.transformers.utils import QUANT_CONFIG
+
+    r = RtnConfig()
+    assert (r.bits, r.group_size, r.sym, r.scheme, r.weight_dtype) == (4, 32, True, "sym", "int4")
+    assert r.modules_to_not_convert == ["lm_head", "transformer.output_layer", "embed_out"]
+    assert RtnConfig(quant_lm_head=True).modules_to_not_convert == []
+    g = GPTQConfig(bits=8, group_size=128, desc_act=True, damp_percent=0.01, tokenizer=object(), dataset=[1, 2])
+    assert g.weight_dtype == "int8" and g.to_diff_dict() == {"bits": 8, "weight_dtype": "int8", "group_size": 128, "desc_act": True, "damp_percent": 0.01}
+    with pytest.raises(ValueError):
+        GPTQConfig(damp_percent=1.5)
+    with pytest.raises(ValueError):
+        GPTQConfig(bits=3)
+    a = AwqConfig(zero_point=False)
+    assert a.sym is True and a.scheme == "sym" and AwqConfig().sym is False
+    assert TeqConfig().quant_method.value == "teq"
+    g.post_init()
+    assert g.compute_dtype == "fp16" and g.scale_dtype == "fp16"
+    g.remove_redundant_parameters()
+    assert not hasattr(g, "tokenizer") and not hasattr(g, "dataset") and not hasattr(g, "static_groups")
+    g.save_pretrained(str(tmp_path))
+    assert QUANT_CONFIG == "quantize_config.json" and (tmp_path / QUANT_CONFIG).exists()
+    g2 = GPTQConfig.from_pretrained(str(tmp_path))
+    assert g2.bits == 8 and g2.group_size == 128 and g2.desc_act is True and g2.quant_method.value == "gptq"
+    extra = AwqConfig.from_dict({"quant_method": "awq", "bits": 4, "group_size": 128, "zero_point": True, "version": "gemm"})
+    assert extra.version == "gemm" and extra.group_size == 128
+    unused = r.update(bits=8, not_a_field=1)
+    assert r.bits == 8 and unused == {"not_a_field": 1}

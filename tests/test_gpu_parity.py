@@ -160,6 +160,31 @@ def test_forward_with_act_order_g_idx_runs_fused(hip, bits, M, dt):
     assert rel_fro(ref2.cpu(), ref.cpu()) > 0.1  # the two layouts really are different matrices
 
 
+def test_awq_checkpoint_repack(hip, golden):
+    """K9: AutoAWQ words -> optimum layout, bit-exact against the reference's output (golden) and, at a Llama-2-7B
+    layer size, against the oracle; then the repacked module's forward equals the AWQ dequantisation."""
+    from neural_compressor_amd import ops
+
+    qw, qz = ops.awq_repack(torch.from_numpy(golden["awqpack_qweight_in"]).to(hip), torch.from_numpy(golden["awqpack_qzeros_in"]).to(hip))
+    assert np.array_equal(qw.cpu().numpy(), golden["awqpack_qweight"])
+    assert np.array_equal(qz.cpu().numpy(), golden["awqpack_qzeros"])
+    g = torch.Generator().manual_seed(3)
+    K, N, gs = 4096, 11008, 128
+    aq = torch.randint(-(2**31), 2**31 - 1, (K, N // 8), generator=g, dtype=torch.int64).to(torch.int32)
+    az = torch.randint(-(2**31), 2**31 - 1, (K // gs, N // 8), generator=g, dtype=torch.int64).to(torch.int32)
+    qw, qz = ops.awq_repack(aq.to(hip), az.to(hip))
+    oqw, oqz = O.awq_repack_to_optimum(aq.numpy(), az.numpy(), 4)
+    assert np.array_equal(qw.cpu().numpy(), oqw)
+    assert np.array_equal(qz.cpu().numpy(), oqz)
+    # semantic check on a slice: W[k, n] = (code - zero) * scale with AutoAWQ's field order
+    sc = (torch.rand(K // gs, N, generator=g) * 0.02 + 0.004).half()
+    rec = ops.woq_dequant(qw, sc.to(hip), qz, None, N, K, gs, 4, out_dtype=torch.float16)  # [N, K]
+    codes = torch.from_numpy(O.awq_unpack_fields(aq[:256].numpy())).float()                 # [256, N]
+    zeros = torch.from_numpy(O.awq_unpack_fields(az[:2].numpy())).float()                   # [2, N]
+    want = (codes - zeros.repeat_interleave(gs, 0)) * sc[:2].float().repeat_interleave(gs, 0)
+    assert rel_fro(rec[:, :256].T.float().cpu(), want) <= 1e-3
+
+
 # ---------------------------------------------------------------------------------------------------
 # K7 RTN
 # ---------------------------------------------------------------------------------------------------

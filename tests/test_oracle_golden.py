@@ -127,6 +127,13 @@ def test_gptq_static_groups(golden, tag, kw):
         assert np.array_equal(r["perm"].numpy(), golden[f"{tag}_perm"])
 
 
+def test_awq_checkpoint_repack(golden):
+    """Integer restatement of repack_awq_to_optimum_format == the reference's dequantise-and-re-round route."""
+    qw, qz = O.awq_repack_to_optimum(golden["awqpack_qweight_in"], golden["awqpack_qzeros_in"], 4)
+    assert np.array_equal(qw, golden["awqpack_qweight"])
+    assert np.array_equal(qz, golden["awqpack_qzeros"])
+
+
 def test_awq_stats(golden):
     w = torch.from_numpy(golden["awq_w"])
     assert np.array_equal(O.awq_weight_scale(w, 32).numpy(), golden["awq_wscale_g32"])
