@@ -76,7 +76,8 @@ def test_gptq_front_end_equals_prepare_convert(float_dir):
     ids = calib_ids(n=8, seq=32)
     cfg = GPTQConfig(bits=4, group_size=32, sym=True, damp_percent=0.01, desc_act=True, dataset=ids, seq_len=32,
                      n_samples=8, batch_size=1)
-    q = AutoModelForCausalLM.from_pretrained(float_dir, quantization_config=cfg)
+    # the zoo model runs eager attention; ask HF for the same kernel so both calibrations see identical activations
+    q = AutoModelForCausalLM.from_pretrained(float_dir, quantization_config=cfg, attn_implementation="eager")
     m = prepare(tiny_llama(dtype=torch.float16), TorchGPTQConfig(bits=4, group_size=32, use_sym=True, percdamp=0.01, act_order=True, block_size=128))
     for x in ids:
         m(x)
