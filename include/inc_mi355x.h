@@ -46,7 +46,9 @@ const char* inc_error_string(int code);    /* static string for an INC_ERR_* cod
 const char* inc_target_arch(void);         /* "gfx950"                                           */
 
 /* debug (A/B runs): 0 = newest kernels; 1 = route GEMM / Hessian / column loop to their first-generation kernels
- * (which remain the generic fall-backs); 2 = second-generation 256x256 two-stage dequant-GEMM, newest elsewhere */
+ * (which remain the generic fall-backs); 2 = second-generation 256x256 two-stage dequant-GEMM, newest elsewhere;
+ * 4 / 6 = the other instruction schedules of the 3A2B dequant-GEMM (compiler-ordered / ping-pong), 20-26 and 31-37 =
+ * timing-only ablations of its step (wrong results by construction) -- tools/kbench gemm | ablate                  */
 void inc_debug_set_small_tiles(int on);
 
 /* ---- K1/K2: bit packing ------------------------------------------------------------------- *

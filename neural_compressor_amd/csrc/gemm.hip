@@ -557,215 +557,6 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
 }
 
 // =============================================================================================
-// large-M deep-pipeline path (4-bit, K % 128 == 0): 256x256 tile, BK = 32, FOUR LDS stages
-// =============================================================================================
-// profiles/r1_pmc: in the two-stage kernel above the waves spend 39 % of their time parked at the per-step
-// s_waitcnt/barrier and the matrix pipe is busy 38 %: after every barrier all 8 waves issue their first fragment
-// reads at once and nothing feeds the MFMAs until they return.  This kernel keeps the same tile, wave layout,
-// LDS images (XOR-swizzled row-major x, fragment-ordered dequantised W) and dequantisation, but
-//   * a step is 32 k (16 MFMAs per wave) and there are four 32 KiB stages: while step t is multiplied, stage t+1 is
-//     complete, stage t+2 is being completed (x by DMA issued in step t-1, W dequantised in step t from words fetched
-//     in step t-1) and the loads of stage t+3 are issued -> every load has two steps to land;
-//   * the fragments of (step t+1, first k16) are read from LDS BEFORE the barrier that ends step t, under the MFMAs of
-//     (step t, second k16), so the first MFMAs after a barrier never wait for LDS;
-//   * all global traffic of the loop (x DMA, packed W words, scale, zero word) is issued from inline asm and retired
-//     with ONE counted `s_waitcnt vmcnt(6)` per step (= this step's six requests may stay in flight; everything older,
-//     i.e. the words to dequantise now and the DMA of stage t+2, has landed).  hipcc never drains the queue.
-constexpr int DK = 32;                      // k per step
-constexpr int D_ASTAGE = TM * DK * 2;       // 16 KiB
-constexpr int D_BSTAGE = TN * DK * 2;       // 16 KiB
-constexpr int D_STAGE = D_ASTAGE + D_BSTAGE;
-
-template <bool IS_BF16, int VAR>
-__global__ __launch_bounds__(512) void woq_gemm_w4_deep_kernel(
-    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
-    const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
-    const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int64_t M, int64_t N, int64_t K,
-    int64_t NW, int g_shift, int y_vec_ok) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = (int)((N + TN - 1) / TN);
-  const int tiles_m = (int)((M + TM - 1) / TM);
-  const int nwg = tiles_m * tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective XCD remap
-  }
-  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-  const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float inv_u = fp8_unit_inverse();
-  const int wm = wave >> 2, wn = wave & 3;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-
-  // ---- x DMA: instruction i (0,1) of this wave fills LDS rows (wave*2+i)*16 .. +15 (64 B per row) ----------------
-  uint32_t avoff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int R = (wave * 2 + i) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((R >> 2) & 3);
-    int64_t row = m0 + R;
-    if (row > M - 1) row = M - 1;
-    avoff[i] = (uint32_t)(((row - m0) * K + 8 * c) * 2);
-  }
-  const uint16_t* const xtile = x + m0 * K;
-  // ---- W: this thread's column, its two packed rows of a step --------------------------------------------------------
-  const int bcol = tid & 255, kwh = tid >> 8;
-  int64_t ncol = n0 + bcol;
-  if (ncol > N - 1) ncol = N - 1;
-  const uint32_t wvoff0 = (uint32_t)(((int64_t)(2 * kwh) * N + ncol) * 4), wvoff1 = wvoff0 + (uint32_t)(N * 4);
-  const uint32_t svoff = (uint32_t)(ncol * 2), zvoff = (uint32_t)((ncol >> 3) * 4);
-  const int zshift = 4 * (int)(ncol & 7);
-  const int bdst = (((bcol >> 5) * 2 + kwh) * 64 + (bcol & 31)) * 16;  // + 32*16 for the second word (k-octet 1)
-
-  const int nk = (int)(K / DK);
-  // six global requests of one step, all from asm: 2 x DMA (no VGPR result), 2 packed words, scale, zero word
-  auto issue_loads = [&](int kt, int stage, uint32_t& w0, uint32_t& w1, uint32_t& sb, uint32_t& zw) {
-    if (kt > nk - 1) kt = nk - 1;  // past-the-end steps re-fetch the last tile into a stage nobody reads again
-    const uint16_t* abase = xtile + (int64_t)kt * DK;
-    const uint32_t* wbase = qweight + (int64_t)kt * (DK / 8) * N;
-    const int64_t g = g_shift >= 0 ? (((int64_t)kt * DK) >> g_shift) : 0;
-    const uint16_t* sbase = scales + g * N;
-    const uint32_t* zbase = qzeros + g * NW;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * D_STAGE + wave * 2048);
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %4, m0\n\t"
-        "s_nop 4\n\t"
-        "s_mov_b32 m0, %11\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %5, %10\n\t"
-        "s_add_u32 m0, %11, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %6, %10\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "global_load_dword %0, %7, %12\n\t"
-        "global_load_dword %1, %8, %12\n\t"
-        "global_load_ushort %2, %9, %13\n\t"
-        "global_load_dword %3, %14, %15"
-        : "=&v"(w0), "=&v"(w1), "=&v"(sb), "=&v"(zw), "=&s"(keep)
-        : "v"(avoff[0]), "v"(avoff[1]), "v"(wvoff0), "v"(wvoff1), "v"(svoff), "s"(abase), "s"(dst), "s"(wbase), "s"(sbase),
-          "v"(zvoff), "s"(zbase)
-        : "memory", "scc");
-  };
-  // `older` requests have landed once at most `n` remain in flight; ties the result registers to the wait
-  auto wait_loads6 = [&](uint32_t& w0, uint32_t& w1, uint32_t& sb, uint32_t& zw) {
-    asm volatile("s_waitcnt vmcnt(6)" : "+v"(w0), "+v"(w1), "+v"(sb), "+v"(zw) : : "memory");
-  };
-  auto stash = [&](int stage, uint32_t w0, uint32_t w1, uint32_t sb, uint32_t zw) {
-    const float sc0 = f16_bits_to_f32((uint16_t)sb);
-    uint32_t zz = ((zw >> zshift) & 15u) + 1u;  // modules.py:407-410
-    zz = zz > 15u ? 0u : zz;
-    const float nzs = -(float)zz * sc0;
-    const float sc = sc0 * inv_u;
-    char* dst = smem + stage * D_STAGE + D_ASTAGE + bdst;
-    *reinterpret_cast<uint4*>(dst) = dequant8<IS_BF16>(w0, sc, nzs);
-    *reinterpret_cast<uint4*>(dst + 32 * 16) = dequant8<IS_BF16>(w1, sc, nzs);
-  };
-
-  f32x16 acc[2][4];  // [n-frag][m-frag]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int a_row = wm * 128 + (lane & 31);
-  const int a_sw = ((lane & 31) >> 2) & 3;  // (row >> 2) & 3: tile bases are multiples of 32
-  const int a_hi = lane >> 5;
-  const int b_off = (wn * 2 * 2 * 64 + lane) * 16;  // + (nf*2 + kk) * 1024
-  auto read_frags = [&](int stage, int kk, uint4 (&xa)[4], uint4 (&wb)[2]) {
-    const char* As = smem + stage * D_STAGE;
-    const char* Bs = As + D_ASTAGE + b_off;
-    const int chunk = ((2 * kk + a_hi) ^ a_sw) << 4;
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) xa[mf] = *reinterpret_cast<const uint4*>(As + (a_row + 32 * mf) * 64 + chunk);
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf) wb[nf] = *reinterpret_cast<const uint4*>(Bs + (nf * 2 + kk) * 1024);
-  };
-  auto mma8 = [&](const uint4 (&xa)[4], const uint4 (&wb)[2]) {
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-      for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma32<IS_BF16>(wb[nf], xa[mf], acc[nf][mf]);
-  };
-
-  // ---- prologue: stages 0 and 1 complete, stage 2 in flight (x DMA issued, packed words in registers) ----------
-  uint32_t ra0, ra1, ras, raz;  // register set A: tiles with even index
-  uint32_t rb0, rb1, rbs, rbz;  // register set B: tiles with odd index
-  issue_loads(0, 0, ra0, ra1, ras, raz);
-  issue_loads(1, 1, rb0, rb1, rbs, rbz);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra1), "+v"(ras), "+v"(raz), "+v"(rb0), "+v"(rb1), "+v"(rbs), "+v"(rbz) : : "memory");
-  stash(0, ra0, ra1, ras, raz);
-  stash(1, rb0, rb1, rbs, rbz);
-  issue_loads(2, 2, ra0, ra1, ras, raz);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  uint4 xa0[4], wb0[2], xa1[4], wb1[2];
-  read_frags(0, 0, xa0, wb0);
-
-  // ---- main loop, unrolled by 4 so that stage numbers and register sets are literals -----------------------------
-  // step t (stage s = t & 3): issue loads of tile t+3 into stage (s+3)&3 / the register set of parity (t+3)&1 = (t+1)&1,
-  // dequantise tile t+2 (set t&1) into stage (s+2)&3.
-  for (int t0 = 0; t0 < nk; t0 += 4) {
-#define INC_DEEP_STEP(S, LW0, LW1, LWS, LWZ, DW0, DW1, DWS, DWZ)                                   \
-    {                                                                                              \
-      issue_loads(t0 + (S) + 3, ((S) + 3) & 3, LW0, LW1, LWS, LWZ);                               \
-      __builtin_amdgcn_sched_barrier(0);                                                           \
-      read_frags((S), 1, xa1, wb1);                                                                \
-      mma8(xa0, wb0);                                                                              \
-      if (VAR >= 1) __builtin_amdgcn_sched_barrier(0); /* the 8 MFMAs above are issued BEFORE the wait */ \
-      wait_loads6(DW0, DW1, DWS, DWZ);                                                             \
-      stash(((S) + 2) & 3, DW0, DW1, DWS, DWZ);                                                    \
-      read_frags(((S) + 1) & 3, 0, xa0, wb0);                                                      \
-      mma8(xa1, wb1);                                                                              \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
-      __builtin_amdgcn_s_barrier();                                                                \
-    }
-    // even steps load into set B (tile t+3 is odd) and dequantise set A (tile t+2 is even); odd steps the reverse
-    INC_DEEP_STEP(0, rb0, rb1, rbs, rbz, ra0, ra1, ras, raz)
-    INC_DEEP_STEP(1, ra0, ra1, ras, raz, rb0, rb1, rbs, rbz)
-    INC_DEEP_STEP(2, rb0, rb1, rbs, rbz, ra0, ra1, ras, raz)
-    INC_DEEP_STEP(3, ra0, ra1, ras, raz, rb0, rb1, rbs, rbz)
-#undef INC_DEEP_STEP
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads must not outlive the workgroup's LDS
-
-  // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
-#pragma unroll
-  for (int nf = 0; nf < 2; ++nf) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const int64_t nb = n0 + wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (nb + e < N) bv[e] = cvt16<IS_BF16>(bias[nb + e]);
-      }
-#pragma unroll
-      for (int mf = 0; mf < 4; ++mf) {
-        const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
-        if (m >= M) continue;
-        const float v0 = acc[nf][mf][4 * rq + 0] + bv[0], v1 = acc[nf][mf][4 * rq + 1] + bv[1];
-        const float v2 = acc[nf][mf][4 * rq + 2] + bv[2], v3 = acc[nf][mf][4 * rq + 3] + bv[3];
-        uint16_t* dst = y + m * N + nb;
-        if (y_vec_ok && nb + 4 <= N) {
-          *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair<IS_BF16>(v0, v1), cvt_pair<IS_BF16>(v2, v3));
-        } else {
-          const float vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (nb + e < N) dst[e] = IS_BF16 ? f32_to_bf16_bits(vv[e]) : f32_to_f16_bits(vv[e]);
-        }
-      }
-    }
-  }
-}
-
-// =============================================================================================
 // large-M path "3A2B" (4-bit, K % 128 == 0): 256x256x64 tile, THREE x stages + TWO W stages = all 160 KiB of LDS
 // =============================================================================================
 // Ablations (tools/kbench ablate, profiles/r1f): with two stages the DMA of x tile t+1 is issued at the start of step t
@@ -777,7 +568,17 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_deep_kernel(
 // with counted waits: per step a wave issues 6 W requests then 4 DMAs; `vmcnt(14)` before the dequantisation leaves
 // the previous step's 4 DMAs + this step's 10 requests in flight, `vmcnt(10)` before the barrier retires those 4 DMAs.
 // The dequantisation is spread over the four k16 groups (one packed word next to each 8 MFMAs).
-template <bool IS_BF16>
+// SCHED selects the step's instruction schedule (same data flow, same results):
+//   0  as written, the compiler orders the step (it sinks every fragment read to just before the MFMAs that use it and
+//      so re-exposes the LDS latency four times per step -- see profiles/r1i)
+//   1  sched_barrier fences pin the software pipeline: reads of k16 group g+1 are issued BEFORE the MFMAs of group g
+//   3  "ping-pong": compute and load segments separated by barriers, partner waves half a step apart (see below)
+//   10-16, 31-37  timing-only ablations (tools/kbench ablate)
+// All of 0/1/3 give bit-identical outputs and, measured (profiles/r1i_kbench_*.log), the same speed within 10 %: the step is
+// not bound by instruction placement -- a variant that spread the 10 VMEM requests between the carried group's MFMAs
+// changed nothing either -- but by the sum of its parts.
+#define INC_3A2B_DEFAULT_SCHED 1
+template <bool IS_BF16, int SCHED>
 __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
     const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
@@ -800,6 +601,15 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float inv_u = fp8_unit_inverse();
   const int wm = wave >> 2, wn = wave & 3;
+  // timing-only ablations (tools/kbench ablate; results are wrong by construction): which part of a step costs what
+  // 30 + mask: the ping-pong schedule (3) minus {1: loads, 2: dequantisation + W writes, 4: fragment reads}
+  constexpr bool PP = SCHED == 3 || SCHED >= 30;
+  constexpr int PPM = SCHED >= 30 ? SCHED - 30 : 0;
+  constexpr bool NO_DEQ = SCHED == 10 || SCHED == 15 || SCHED == 16 || (PPM & 2);  // no int4 -> bf16 arithmetic
+  constexpr bool NO_WR = SCHED == 11 || SCHED == 15 || SCHED == 16 || (PPM & 2);   // no ds_write of the dequantised W
+  constexpr bool NO_RD = SCHED == 12 || SCHED == 15 || SCHED == 16 || (PPM & 4);   // no fragment reads
+  constexpr bool NO_LD = SCHED == 13 || SCHED == 15 || SCHED == 16 || (PPM & 1);   // no global loads / LDS-DMA
+  constexpr bool NO_BAR = SCHED == 14 || SCHED == 16;                 // no per-step barrier
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
   uint32_t avoff[4];
@@ -830,6 +640,10 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
 
   // one step's requests: 6 for W (4 packed words, scale, zero word) FIRST, then 4 x DMAs
   auto issue_w = [&](int kt, uint32_t (&w)[4], uint32_t& sb, uint32_t& zw) {
+    if (NO_LD) {
+      asm volatile("" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(sb), "=v"(zw));
+      return;
+    }
     kt = kbase + (kt > nk - 1 ? nk - 1 : kt);
     const uint32_t* wbase = qweight + (int64_t)kt * (TK / 8) * N;
     const int64_t g = g_shift >= 0 ? (((int64_t)kt * TK + 32 * kwh_s) >> g_shift) : 0;  // wave-uniform (kwh is)
@@ -848,6 +662,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
         : "memory");
   };
   auto issue_dma = [&](int kt, int astage) {
+    if (NO_LD) return;
     kt = kbase + (kt > nk - 1 ? nk - 1 : kt);
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + astage * T_ASTAGE + wave * 4096);
     lds_dma_4x1k(xtile + (int64_t)kt * TK, dst, avoff[0], avoff[1], avoff[2], avoff[3]);
@@ -877,9 +692,15 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma32<IS_BF16>(wbv[nf], xa[mf], acc[nf][mf]);
   };
+  auto mma1 = [&](int i, const uint4 (&xa)[4], const uint4 (&wbv)[2]) {
+    acc[i >> 2][i & 3] = mfma32<IS_BF16>(wbv[i >> 2], xa[i & 3], acc[i >> 2][i & 3]);
+  };
+#define INC_SB() __builtin_amdgcn_sched_barrier(0)
   auto dequant_into = [&](int bstage, int kk, uint32_t word, float sc, float nzs) {
     char* dst = Bbase + bstage * T_BSTAGE + bdst0;
-    *reinterpret_cast<uint4*>(dst + ((kk >> 1) * 64 + 32 * (kk & 1)) * 16) = dequant8<IS_BF16>(word, sc, nzs);
+    const uint4 v = NO_DEQ ? make_uint4(word, word, word, word) : dequant8<IS_BF16>(word, sc, nzs);
+    if (NO_WR) asm volatile("" : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    else *reinterpret_cast<uint4*>(dst + ((kk >> 1) * 64 + 32 * (kk & 1)) * 16) = v;
   };
   auto group_params = [&](uint32_t sb, uint32_t zw, float& sc, float& nzs) {
     const float sc0 = f16_bits_to_f32((uint16_t)sb);
@@ -902,7 +723,8 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) dequant_into(0, kk, w0[kk], sc, nzs);
   }
-  issue_w(1, wa, wsa, wza);
+  if (PP && wm) issue_w(1, wb_, wsb, wzb);  // the second half enters the loop one load segment later: sets swapped
+  else issue_w(1, wa, wsa, wza);
   issue_dma(1, 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -918,6 +740,56 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
 
   // step t: x stage t%3, W stage t&1.  Issues W words of tile t+2 and the DMA of x tile t+2 (stage (t+2)%3), dequantises
   // tile t+1 (words issued in step t-1) into W stage (t+1)&1.
+  // SCHED 3 ("ping-pong"): a step is split into a compute segment (32 MFMAs + their 24 fragment reads) and a load segment
+  // (10 VMEM requests, dequantisation, 4 LDS writes) with a barrier after each.  The waves of the second half (wm = 1:
+  // wave w+4 shares a SIMD with wave w) run one extra load segment before the loop, so from then on one wave of every SIMD
+  // computes while its partner loads -- the two instruction streams never compete for the matrix pipe and the VMEM/VALU
+  // issue of one hides behind the MFMAs of the other.  Half-step h: wm 0 computes tile h/2 at even h, wm 1 at odd h.  To
+  // keep every tile complete one half-step before its first reader, wm 1 works one tile further ahead in its load segment
+  // (loads tile t+3, dequantises tile t+2); stage numbers become wave-uniform run-time values, the loop body is one code.
+#define INC_3A2B_COMPUTE(As, Bs)                                                                                   \
+  {                                                                                                                \
+    if (!NO_RD) read_frags(As, Bs, 0, xX, wX);                                                                                 \
+    if (!NO_RD) read_frags(As, Bs, 1, xY, wY);                                                                                 \
+    INC_SB();                                                                                                      \
+    mma8(xX, wX);                                                                                                  \
+    INC_SB();                                                                                                      \
+    if (!NO_RD) read_frags(As, Bs, 2, xX, wX);                                                                                 \
+    INC_SB();                                                                                                      \
+    mma8(xY, wY);                                                                                                  \
+    INC_SB();                                                                                                      \
+    if (!NO_RD) read_frags(As, Bs, 3, xY, wY);                                                                                 \
+    INC_SB();                                                                                                      \
+    mma8(xX, wX);                                                                                                  \
+    INC_SB();                                                                                                      \
+    mma8(xY, wY);                                                                                                  \
+    INC_SB();                                                                                                      \
+  }
+#define INC_3A2B_LOADSEG(T, LW, LWS, LWZ, DW, DWS, DWZ)                                                           \
+  {                                                                                                                \
+    issue_w((T) + 2, LW, LWS, LWZ);                                                                                \
+    issue_dma((T) + 2, ((T) + 2) % 3);                                                                             \
+    asm volatile("s_waitcnt vmcnt(14)" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory"); \
+    float sc_, nzs_;                                                                                               \
+    group_params(DWS, DWZ, sc_, nzs_);                                                                             \
+    dequant_into(((T) & 1) ^ 1, 0, DW[0], sc_, nzs_);                                                              \
+    dequant_into(((T) & 1) ^ 1, 1, DW[1], sc_, nzs_);                                                              \
+    dequant_into(((T) & 1) ^ 1, 2, DW[2], sc_, nzs_);                                                              \
+    dequant_into(((T) & 1) ^ 1, 3, DW[3], sc_, nzs_);                                                              \
+    INC_SB();                                                                                                      \
+  }
+#define INC_3A2B_STEP3(T, LW, LWS, LWZ, DW, DWS, DWZ)                                                              \
+  {                                                                                                                \
+    const int t_ = (T);                                                                                            \
+    const char* As = Abase + (t_ % 3) * T_ASTAGE;                                                                  \
+    const char* Bs = Bbase + (t_ & 1) * T_BSTAGE + b_off;                                                          \
+    INC_3A2B_COMPUTE(As, Bs)                                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    INC_SB(); /* keep the load segment's address arithmetic on its own side of the barrier */                     \
+    INC_3A2B_LOADSEG(t_ + wm, LW, LWS, LWZ, DW, DWS, DWZ)                                                          \
+    asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+  }
 #define INC_3A2B_STEP(T, LW, LWS, LWZ, DW, DWS, DWZ)                                                              \
   {                                                                                                                \
     const int t_ = (T);                                                                                            \
@@ -926,30 +798,58 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     const char* Bs = Bbase + bs_ * T_BSTAGE + b_off;                                                               \
     issue_w(t_ + 2, LW, LWS, LWZ);                                                                                 \
     issue_dma(t_ + 2, (t_ + 2) % 3);                                                                               \
+    if (SCHED != 0) INC_SB();                                                                                      \
     mma8(xY, wY);                       /* group 3 of the previous step */                                         \
-    read_frags(As, Bs, 1, xY, wY);                                                                                 \
-    mma8(xX, wX);                       /* group 0 */                                                              \
+    if (SCHED != 0) INC_SB();                                                                                      \
+    if (!NO_RD) read_frags(As, Bs, 1, xY, wY);                                                                               \
+    if (SCHED != 0) INC_SB();                                                                                           \
     asm volatile("s_waitcnt vmcnt(14)" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory"); \
     float sc_, nzs_;                                                                                               \
     group_params(DWS, DWZ, sc_, nzs_);                                                                             \
-    dequant_into(bs_ ^ 1, 0, DW[0], sc_, nzs_);                                                                    \
-    read_frags(As, Bs, 2, xX, wX);                                                                                 \
+    if (SCHED != 0) dequant_into(bs_ ^ 1, 0, DW[0], sc_, nzs_);                                                         \
+    mma8(xX, wX);                       /* group 0 */                                                              \
+    if (SCHED == 0) dequant_into(bs_ ^ 1, 0, DW[0], sc_, nzs_);                                                        \
+    if (SCHED != 0) INC_SB();                                                                                           \
+    if (!NO_RD) read_frags(As, Bs, 2, xX, wX);                                                                                 \
+    if (SCHED != 0) INC_SB();                                                                                           \
+    if (SCHED != 0) dequant_into(bs_ ^ 1, 1, DW[1], sc_, nzs_);                                                         \
     mma8(xY, wY);                       /* group 1 */                                                              \
-    dequant_into(bs_ ^ 1, 1, DW[1], sc_, nzs_);                                                                    \
-    read_frags(As, Bs, 3, xY, wY);                                                                                 \
+    if (SCHED == 0) dequant_into(bs_ ^ 1, 1, DW[1], sc_, nzs_);                                                        \
+    if (SCHED != 0) INC_SB();                                                                                           \
+    if (!NO_RD) read_frags(As, Bs, 3, xY, wY);                                                                                 \
+    if (SCHED != 0) INC_SB();                                                                                           \
+    if (SCHED != 0) { dequant_into(bs_ ^ 1, 2, DW[2], sc_, nzs_); dequant_into(bs_ ^ 1, 3, DW[3], sc_, nzs_); }         \
     mma8(xX, wX);                       /* group 2 */                                                              \
-    dequant_into(bs_ ^ 1, 2, DW[2], sc_, nzs_);                                                                    \
-    dequant_into(bs_ ^ 1, 3, DW[3], sc_, nzs_);                                                                    \
+    if (SCHED == 0) { dequant_into(bs_ ^ 1, 2, DW[2], sc_, nzs_); dequant_into(bs_ ^ 1, 3, DW[3], sc_, nzs_); }        \
+    if (SCHED != 0) INC_SB();                                                                                           \
     asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                      \
-    __builtin_amdgcn_s_barrier();                                                                                  \
-    read_frags(Abase + ((t_ + 1) % 3) * T_ASTAGE, Bbase + (bs_ ^ 1) * T_BSTAGE + b_off, 0, xX, wX);               \
+    if (!NO_BAR) __builtin_amdgcn_s_barrier();                                                                                  \
+    if (!NO_RD) read_frags(Abase + ((t_ + 1) % 3) * T_ASTAGE, Bbase + (bs_ ^ 1) * T_BSTAGE + b_off, 0, xX, wX);               \
+    if (SCHED != 0) INC_SB();                                                                                           \
   }
-  for (int t0 = 0; t0 < nk; t0 += 2) {
-    INC_3A2B_STEP(t0, wb_, wsb, wzb, wa, wsa, wza)        // even step: load tile t+2 (even) -> set B, dequantise tile t+1 (odd) <- set A
-    INC_3A2B_STEP(t0 + 1, wa, wsa, wza, wb_, wsb, wzb)    // odd step: the reverse
+  if (PP) {
+    if (wm) {  // load segment "-1": tile 2 -> x stage 2 / set A, tile 1 (set B) -> W stage 1
+      INC_3A2B_LOADSEG(0, wa, wsa, wza, wb_, wsb, wzb)
+      asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    for (int t0 = 0; t0 < nk; t0 += 2) {
+      INC_3A2B_STEP3(t0, wb_, wsb, wzb, wa, wsa, wza)
+      INC_3A2B_STEP3(t0 + 1, wa, wsa, wza, wb_, wsb, wzb)
+    }
+    if (!wm) __builtin_amdgcn_s_barrier();  // the first half has executed one barrier fewer
+  } else {
+    for (int t0 = 0; t0 < nk; t0 += 2) {
+      INC_3A2B_STEP(t0, wb_, wsb, wzb, wa, wsa, wza)        // even step: load tile t+2 (even) -> set B, dequantise tile t+1 (odd) <- set A
+      INC_3A2B_STEP(t0 + 1, wa, wsa, wza, wb_, wsb, wzb)    // odd step: the reverse
+    }
+    mma8(xY, wY);  // group 3 of the last step
   }
 #undef INC_3A2B_STEP
-  mma8(xY, wY);  // group 3 of the last step
+#undef INC_3A2B_STEP3
+#undef INC_3A2B_COMPUTE
+#undef INC_3A2B_LOADSEG
+#undef INC_SB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
@@ -1378,12 +1278,17 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   else if (group_size >= 32 && (group_size & (group_size - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < group_size) ++g_shift; }
   const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M >= 128 && N >= 64 &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
-  if (big_ok && (K % 128) == 0 && inc_small_tiles_flag(-1) == 0) {
+  const int dbg = inc_small_tiles_flag(-1);
+  if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 26) || (dbg >= 31 && dbg <= 37))) {
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
     static bool a3_attr_set = false;
     if (!a3_attr_set) {
-      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+#define INC_A3_ATTR(B, S) (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<B, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+      INC_A3_ATTR(true, 0); INC_A3_ATTR(true, 1); INC_A3_ATTR(false, INC_3A2B_DEFAULT_SCHED);
+      INC_A3_ATTR(true, 10); INC_A3_ATTR(true, 11); INC_A3_ATTR(true, 12); INC_A3_ATTR(true, 13); INC_A3_ATTR(true, 14);
+      INC_A3_ATTR(true, 15); INC_A3_ATTR(true, 16); INC_A3_ATTR(true, 3);
+      INC_A3_ATTR(true, 31); INC_A3_ATTR(true, 32); INC_A3_ATTR(true, 34); INC_A3_ATTR(true, 37);
+#undef INC_A3_ATTR
       a3_attr_set = true;
     }
     const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
@@ -1397,31 +1302,31 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
       else { splits = 1; steps = (int)(K / TK); }  // no workspace given: single pass (still correct, fewer workgroups)
     }
     dim3 g2(grid, (unsigned)splits);
-    if (bf) woq_gemm_w4_3a2b_kernel<true><<<g2, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps);
-    else woq_gemm_w4_3a2b_kernel<false><<<g2, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps);
+#define INC_A3(B, S) woq_gemm_w4_3a2b_kernel<B, S><<<g2, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps)
+    // debug flag 4 / 6 time the other schedules of the bf16 kernel (tools/kbench A/B)
+    const int sched = dbg == 4 ? 0 : INC_3A2B_DEFAULT_SCHED;
+    if (!bf) INC_A3(false, INC_3A2B_DEFAULT_SCHED);
+    else if (dbg == 6) INC_A3(true, 3);
+    else if (dbg == 31) INC_A3(true, 31);
+    else if (dbg == 32) INC_A3(true, 32);
+    else if (dbg == 34) INC_A3(true, 34);
+    else if (dbg == 37) INC_A3(true, 37);
+    else if (dbg == 20) INC_A3(true, 10);  // 20..26: timing-only ablations of schedule 1 (wrong results by construction)
+    else if (dbg == 21) INC_A3(true, 11);
+    else if (dbg == 22) INC_A3(true, 12);
+    else if (dbg == 23) INC_A3(true, 13);
+    else if (dbg == 24) INC_A3(true, 14);
+    else if (dbg == 25) INC_A3(true, 15);
+    else if (dbg == 26) INC_A3(true, 16);
+    else if (sched == 0) INC_A3(true, 0);
+    else INC_A3(true, 1);
+#undef INC_A3
     if (part) {
       int64_t rb = ceil_div64(M * N / 4, 256);
       if (rb > 4096) rb = 4096;
       if (bf) splitk_slab_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
       else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
     }
-  } else if (big_ok && bf && (K % 128) == 0 && inc_small_tiles_flag(-1) == 3) {  // experiment kept for A/B: 4 x 32 KiB stages, BK = 32
-    const size_t smem = (size_t)4 * D_STAGE;
-    (void)hipFuncSetAttribute((const void*)woq_gemm_w4_deep_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
-    const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
-    woq_gemm_w4_deep_kernel<true, 0><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
-  } else if (big_ok && bf && inc_small_tiles_flag(-1) >= 11 && inc_small_tiles_flag(-1) <= 16) {  // timing-only ablations / experiments
-    const size_t smem = (size_t)2 * T_ASTAGE + 2 * T_BSTAGE;
-    const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
-    const int abl = inc_small_tiles_flag(-1) - 10;
-#define INC_ABL(A)                                                                                                            \
-    {                                                                                                                         \
-      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_big_kernel<true, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-      woq_gemm_w4_big_kernel<true, A><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, 1);          \
-    }
-    if (abl == 1) INC_ABL(1) else if (abl == 2) INC_ABL(2) else if (abl == 3) INC_ABL(3) else if (abl == 4) INC_ABL(4) else if (abl == 5) INC_ABL(5) else INC_ABL(6)
-#undef INC_ABL
   } else if (big_ok && !inc_force_small_tiles()) {
     const size_t smem = (size_t)2 * T_ASTAGE + 2 * T_BSTAGE;  // 128 KiB
     static bool big_attr_set = false;

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <cstring>
 #include <vector>
 
 #include "../include/inc_mi355x.h"
@@ -157,8 +158,24 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
   INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y_old.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
   HIPCHECK(hipDeviceSynchronize());
   inc_debug_set_small_tiles(0);
-  // (1) full coverage: new tiling vs first-generation tiling (same arithmetic, different fp32 summation order)
+  // (0) the alternative schedules of the 3A2B kernel keep the accumulation order: bit-identical outputs required
   std::vector<uint16_t> hy = y.download(), hyo = y_old.download();
+  int sched_mismatch = 0;
+  if (M > 16) {
+    const int alts[2] = {4, 6};
+    for (int a = 0; a < 2; ++a) {
+      inc_debug_set_small_tiles(alts[a]);
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y_old.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+      HIPCHECK(hipDeviceSynchronize());
+      std::vector<uint16_t> ha = y_old.download();
+      if (memcmp(ha.data(), hy.data(), hy.size() * 2) != 0) {
+        ++sched_mismatch;
+        printf("  schedule flag %d: output differs from the default schedule\n", alts[a]);
+      }
+    }
+    inc_debug_set_small_tiles(0);
+  }
+  // (1) full coverage: new tiling vs first-generation tiling (same arithmetic, different fp32 summation order)
   double num = 0, den = 0;
   int64_t big = 0;
   for (size_t i = 0; i < hy.size(); ++i) {
@@ -191,7 +208,7 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
       if (fabs(a - b) > maxabs) maxabs = fabs(a - b);
     }
   const double rel_ref = sqrt(num2 / (den2 + 1e-30));
-  const bool ok = rel_old < 3e-3 && rel_ref < 3e-3 && big == 0;
+  const bool ok = rel_old < 3e-3 && rel_ref < 3e-3 && big == 0 && sched_mismatch == 0;
   printf("GEMM M=%ld N=%ld K=%ld gs=%d %s%s: rel(new vs old tiling)=%.2e outliers=%ld rel(new vs fp32 ref, %d rows)=%.2e maxabs=%.3g  %s\n",
          (long)M, (long)N, (long)K, gs, sym ? "sym" : "asym", with_bias ? "+bias" : "", rel_old, (long)big, check_rows, rel_ref, maxabs,
          ok ? "OK" : "FAIL");
@@ -199,16 +216,16 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
     // interleaved rounds (the first variant timed after an idle gap runs at lower clocks: single back-to-back timings were
     // biased by ~8 %): every round times every variant, rotating the order; the median over rounds is reported
     Timer t;
-    const int modes[4] = {0, 3, 2, 1};
-    const char* labels[4] = {"fast path (3A2B)", "deep (4x32K, BK=32)", "256^2 two-stage", "first-gen tiling"};
-    const int nv = 4, rounds = 5, iters = M <= 16 ? 100 : 8;
+    const int modes[3] = {0, 4, 6};
+    const char* labels[3] = {"3A2B pinned pipeline", "3A2B compiler sched", "3A2B ping-pong"};
+    const int nv = 3, rounds = 5, iters = M <= 16 ? 100 : 8;
     std::vector<std::vector<float>> ms(nv);
     for (int i = 0; i < 10; ++i)  // warm the clocks
       INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
     for (int r = 0; r < rounds; ++r)
       for (int vi = 0; vi < nv; ++vi) {
         const int mi = (vi + r) % nv, mode = modes[mi];
-        if ((mode == 2 || mode == 3) && M <= 16) continue;
+        if (mode != 0 && M <= 16) continue;
         inc_debug_set_small_tiles(mode);
         INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
         t.start();
@@ -481,25 +498,36 @@ int main(int argc, char** argv) {
     HIPCHECK(hipDeviceSynchronize());
     printf("prof workload done\n");
   }
-  if (what == "ablate") {  // timing-only ablations of the two-stage dequant-GEMM (outputs are wrong by construction)
+  if (what == "ablate") {  // timing-only ablations of the 3A2B dequant-GEMM step (outputs are wrong by construction)
     const int64_t M = 4096, N = 4096, K = 4096;
     Packed W(N, K, 128, true);
     DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
     std::vector<uint16_t> hx(x.n);
     for (auto& v : hx) v = f2bf(rnd_normal());
     x.upload(hx);
-    const int modes[10] = {2, 2, 15, 16, 2, 15, 16, 11, 13, 14};
-    const char* labels[10] = {"two-stage (warm-up)", "two-stage (baseline)", "dequant spread (exact)", "spread + sched groups", "two-stage (again)", "dequant spread (again)", "spread + groups (again)", "- dequant arithmetic", "- global traffic", "- MFMA"};
+    const int nv = 13, rounds = 5, iters = 8;
+    const int modes[nv] = {0, 20, 21, 22, 23, 24, 25, 26, 6, 31, 32, 34, 37};
+    const char* labels[nv] = {"full step", "- dequant arithmetic", "- ds_write of W", "- fragment reads", "- global loads + DMA", "- barrier",
+                              "MFMA + barrier only", "MFMA only", "ping-pong full", "ping-pong - loads", "ping-pong - dequant/write",
+                              "ping-pong - frag reads", "ping-pong MFMA+barriers"};
+    std::vector<std::vector<float>> ms(nv);
     Timer t;
-    for (int mi = 0; mi < 10; ++mi) {
-      inc_debug_set_small_tiles(modes[mi]);
-      for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 10; ++i)
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+    for (int r = 0; r < rounds; ++r)
+      for (int vi = 0; vi < nv; ++vi) {
+        const int mi = (vi + r) % nv;
+        inc_debug_set_small_tiles(modes[mi]);
         INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
-      t.start();
-      for (int i = 0; i < 20; ++i)
-        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
-      const float ms = t.stop_ms() / 20;
-      printf("ABLATE %-24s %8.4f ms  (%7.1f TFLOP/s equivalent)\n", labels[mi], ms, 2.0 * M * N * K / ms / 1e9);
+        t.start();
+        for (int i = 0; i < iters; ++i)
+          INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+        ms[mi].push_back(t.stop_ms() / iters);
+      }
+    for (int mi = 0; mi < nv; ++mi) {
+      std::sort(ms[mi].begin(), ms[mi].end());
+      const float med = ms[mi][ms[mi].size() / 2];
+      printf("ABLATE %-24s median %8.4f ms  (%7.1f TFLOP/s equivalent)  best %8.4f\n", labels[mi], med, 2.0 * M * N * K / med / 1e9, ms[mi][0]);
     }
     inc_debug_set_small_tiles(0);
   }
