@@ -78,7 +78,12 @@ def test_gptq_front_end_equals_prepare_convert(float_dir):
                      n_samples=8, batch_size=1)
     # the zoo model runs eager attention; ask HF for the same kernel so both calibrations see identical activations
     q = AutoModelForCausalLM.from_pretrained(float_dir, quantization_config=cfg, attn_implementation="eager")
-    m = prepare(tiny_llama(dtype=torch.float16), TorchGPTQConfig(bits=4, group_size=32, use_sym=True, percdamp=0.01, act_order=True, block_size=128))
+    import transformers
+
+    # same float model object on both routes (HF keeps the rotary inv_freq in fp32 when it instantiates under fp16; the
+    # zoo's `.to(fp16)` would round it -- last-bit activation differences that flip a handful of GPTQ codes)
+    fm = transformers.AutoModelForCausalLM.from_pretrained(float_dir, dtype=torch.float16, attn_implementation="eager").eval()
+    m = prepare(fm, TorchGPTQConfig(bits=4, group_size=32, use_sym=True, percdamp=0.01, act_order=True, block_size=128))
     for x in ids:
         m(x)
     m = convert(m)
