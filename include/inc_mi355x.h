@@ -245,6 +245,37 @@ int inc_awq_weight_scale(const void* w, int wdtype, int64_t N, int64_t K, int gr
 int inc_awq_repack(const int32_t* awq_qweight, const int32_t* awq_qzeros, int64_t K, int64_t N, int64_t G, int bits,
                    int32_t* qweight, int32_t* qzeros, inc_stream_t stream);
 
+/* ---- K10-K14: SmoothQuant W8A8 (BASELINE config #4) ------------------------------------------------ *
+ * Reference: neural_compressor/torch/algorithms/smooth_quant/utility.py.  The reference executes W8A8 through
+ * intel_extension_for_pytorch (smooth_quant.py:105-125; not vendored): the in-tree fake-quant functions are the spec.
+ *
+ * inc_sq_channel_minmax: mn[k] = min(mn[k], min_t x[t,k]), mx[k] = max(mx[k], max_t x[t,k])          (fp32 [K] each,
+ *   initialise to +FLT_MAX / -FLT_MAX) == Calibration._save_input_pc_hook (:858-883), x [T,K] with row stride ld.
+ * inc_sq_weight_col_absmax: out[k] = max(out[k], max_n |w[n,k]|) (zero `out` first; call once per Linear that shares
+ *   the input) == the `torch.max(torch.abs(torch.cat(weights)), dim=0)` of cal_scale (:617-618).
+ * inc_sq_cal_scale: s[k] = clip(amax_x[k]^alpha / clip(amax_w[k], lb)^(1-alpha), 1e-5), s = 1 where amax_x^alpha == 0
+ *   == cal_scale (:605-626).
+ * inc_sq_quant_weight: per-output-channel symmetric int8 of W * smooth (smooth may be NULL):
+ *   scale[n] = clip(max_k |w'| / 127.5, eps), q = clamp(rint(w' / scale), -128, 127) == quant_dequant_w_v1 (:669-690);
+ *   qw [N, Kp] int8 (Kp >= K, columns K..Kp-1 are zero), rowsum[n] = sum_k q[n,k] (int32).
+ * inc_sq_quant_act: out[m,k] = clamp(rint(x[m,k] * in_scale[k] / sx + zp), 0, 255) - 128 as int8 [M, Kp]
+ *   == SQLinearWrapper.forward's mul (:2602) + quant_dequant_x_v1 (:726-755) with the static (sx, zp) of
+ *   SQLinearWrapper._calculate_qparams (:2607-2631); in_scale may be NULL (folded smoothing).  Kp % 16 == 0.
+ * inc_w8a8_gemm: y[m,n] = alpha[n] * (sum_k xq[m,k] * wq[n,k] + corr[n]) + bias[n]   (v_mfma_i32_32x32x32_i8)
+ *   alpha[n] = sx * w_scale[n], corr[n] = (128 - zp) * rowsum[n] (may be NULL), bias in ydtype or NULL,
+ *   y bf16 / fp16 [M,N]; K % 128 == 0 (pad with zero weight codes), xq / wq 16-byte aligned.                        */
+int inc_sq_channel_minmax(const void* x, int xdtype, int64_t T, int64_t K, int64_t ld, float* mn, float* mx,
+                          inc_stream_t stream);
+int inc_sq_weight_col_absmax(const void* w, int wdtype, int64_t N, int64_t K, float* out, inc_stream_t stream);
+int inc_sq_cal_scale(const float* amax_x, const float* amax_w, int64_t K, float alpha, float weight_max_lb, float* scale,
+                     inc_stream_t stream);
+int inc_sq_quant_weight(const void* w, int wdtype, int64_t N, int64_t K, int64_t Kp, const float* smooth, int8_t* qw,
+                        float* w_scale, int32_t* rowsum, inc_stream_t stream);
+int inc_sq_quant_act(const void* x, int xdtype, int64_t M, int64_t K, int64_t Kp, const float* in_scale, float sx, float zp,
+                     int8_t* out, inc_stream_t stream);
+int inc_w8a8_gemm(const int8_t* xq, const int8_t* wq, const float* alpha, const int32_t* corr, const void* bias, void* y,
+                  int ydtype, int64_t M, int64_t N, int64_t K, inc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@ from enum import Enum
 
 # algorithm names (reference common/utils/constants.py:28-33)
 RTN, GPTQ, AWQ = "rtn", "gptq", "awq"
+SMOOTH_QUANT = "smooth_quant"  # constants.py:31
 DEFAULT_WHITE_LIST = "*"  # constants.py:22
 EMPTY_WHITE_LIST = None  # constants.py:23
 

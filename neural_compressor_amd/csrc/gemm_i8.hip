@@ -1,0 +1,210 @@
+// gemm_i8.hip -- K14: W8A8 GEMM for SmoothQuant (BASELINE config #4), v_mfma_i32_32x32x32_i8, MFMA-bound.
+//
+//   y[m, n] = alpha[n] * ( sum_k xq[m,k] * wq[n,k]  +  corr[n] ) + bias[n]
+//
+// xq [M, K] int8 (the uint8 activation codes minus 128, inc_sq_quant_act), wq [N, K] int8 per-output-channel codes
+// (inc_sq_quant_weight), alpha[n] = s_x * s_w[n], corr[n] = (128 - zp_x) * rowsum(wq)[n]: together the exact integer form
+// of  F.linear(quant_dequant_x_v1(X * input_scale), quant_dequant_w_v1(W))  -- the fake-quant pair the reference keeps
+// in tree (smooth_quant/utility.py:652-755); the reference itself executes W8A8 through intel_extension_for_pytorch
+// (smooth_quant/smooth_quant.py:105-125), which is not part of /root/reference, so this formula is the specification.
+//
+// Tile 256 (M) x 256 (N) x 128 (K bytes) per workgroup, 512 threads = 8 waves as 2 (M) x 4 (N), a wave owns 128 x 64 = 4 x 2
+// MFMA tiles (128 int32 accumulators).  Both operands are K-contiguous int8, so both tiles are 256 rows x 128 B and use the
+// SAME path as the x tile of the 4-bit kernel (gemm.hip): LDS-DMA, 8 full 128-byte rows per instruction, 16-byte chunk
+// index XOR-ed with (row >> 1) & 7 on the source address and again on the ds_read_b128 side (no bank conflicts).  Two 64 KiB
+// stages: the DMA of tile t+1 is issued at the top of step t.  W is the A operand and x the B operand, as in gemm.hip, so a
+// lane owns 4 consecutive output columns and the epilogue stores 8 bytes.
+// Algorithmic work per launch: 2*M*N*K int8 op; bytes M*K + N*K + 2*M*N (+ 8*N).
+#include "common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+
+constexpr int IM = 256, IN = 256, IK = 128;
+constexpr int I_TILE = 256 * IK;        // 32 KiB: one operand tile
+constexpr int I_STAGE = 2 * I_TILE;     // x tile + w tile
+
+template <bool IS_BF16>
+__device__ __forceinline__ uint32_t cvt_pair16(float a, float b) {
+  f32x2_ f = {a, b};
+  uint32_t r;
+  if constexpr (IS_BF16) {
+    bf16x2_ h = __builtin_convertvector(f, bf16x2_);
+    __builtin_memcpy(&r, &h, 4);
+  } else {
+    f16x2_ h = __builtin_convertvector(f, f16x2_);
+    __builtin_memcpy(&r, &h, 4);
+  }
+  return r;
+}
+
+__device__ __forceinline__ i32x16 mfma_i8(const uint4& a, const uint4& b, i32x16 c) {
+  i32x4 av, bv;
+  __builtin_memcpy(&av, &a, 16);
+  __builtin_memcpy(&bv, &b, 16);
+  return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
+}
+
+template <bool IS_BF16>
+__global__ __launch_bounds__(512) void w8a8_gemm_kernel(const int8_t* __restrict__ xq, const int8_t* __restrict__ wq,
+                                                        const float* __restrict__ alpha, const int32_t* __restrict__ corr,
+                                                        const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
+                                                        int64_t M, int64_t N, int64_t K, int y_vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (int)((N + IN - 1) / IN);
+  const int tiles_m = (int)((M + IM - 1) / IM);
+  const int nwg = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective XCD remap (block b runs on XCD b % 8)
+  }
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * IM, n0 = (int64_t)tn * IN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  // DMA source offsets: instruction i of this wave brings rows (wave*4+i)*8 .. +7; a lane brings chunk (lane&7)^sw of row lane>>3
+  uint32_t xoff[4], woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int R = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    int64_t xr = m0 + R, wr = n0 + R;
+    if (xr > M - 1) xr = M - 1;
+    if (wr > N - 1) wr = N - 1;
+    xoff[i] = (uint32_t)((xr - m0) * K + 16 * c);
+    woff[i] = (uint32_t)((wr - n0) * K + 16 * c);
+  }
+  const int8_t* const xtile = xq + m0 * K;
+  const int8_t* const wtile = wq + n0 * K;
+  const int nk = (int)(K / IK);
+  auto issue = [&](int kt, int stage) {
+    kt = kt > nk - 1 ? nk - 1 : kt;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * I_STAGE + wave * 4096);
+    lds_dma_4x1k(xtile + (int64_t)kt * IK, dst, xoff[0], xoff[1], xoff[2], xoff[3]);
+    lds_dma_4x1k(wtile + (int64_t)kt * IK, dst + I_TILE, woff[0], woff[1], woff[2], woff[3]);
+  };
+
+  i32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+  const int sw = ((lane & 31) >> 1) & 7, hi = lane >> 5;
+  const int x_row = wm * 128 + (lane & 31);
+  const int w_row = wn * 64 + (lane & 31);
+  auto read_frags = [&](const char* S, int kk, uint4 (&xa)[4], uint4 (&wa)[2]) {
+    const int chunk = ((2 * kk + hi) ^ sw) << 4;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) xa[mf] = *reinterpret_cast<const uint4*>(S + (x_row + 32 * mf) * 128 + chunk);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) wa[nf] = *reinterpret_cast<const uint4*>(S + I_TILE + (w_row + 32 * nf) * 128 + chunk);
+  };
+  auto mma8 = [&](const uint4 (&xa)[4], const uint4 (&wa)[2]) {
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma_i8(wa[nf], xa[mf], acc[nf][mf]);
+  };
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  uint4 xX[4], wX[2], xY[4], wY[2];
+#define INC_SB() __builtin_amdgcn_sched_barrier(0)
+  for (int t = 0; t < nk; ++t) {
+    const char* S = smem + (t & 1) * I_STAGE;
+    issue(t + 1, (t + 1) & 1);  // the other stage was last read in step t-1, which every wave left through the barrier
+    INC_SB();
+    read_frags(S, 0, xX, wX);
+    read_frags(S, 1, xY, wY);
+    INC_SB();
+    mma8(xX, wX);
+    INC_SB();
+    read_frags(S, 2, xX, wX);
+    INC_SB();
+    mma8(xY, wY);
+    INC_SB();
+    read_frags(S, 3, xY, wY);
+    INC_SB();
+    mma8(xX, wX);
+    INC_SB();
+    mma8(xY, wY);
+    INC_SB();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed (this wave's share; the barrier covers the rest)
+    __builtin_amdgcn_s_barrier();
+  }
+#undef INC_SB
+
+  // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int64_t nb = n0 + wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
+      float al[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+      int cr[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (nb + e < N) {
+          al[e] = alpha[nb + e];
+          if (corr) cr[e] = corr[nb + e];
+          if (bias) bv[e] = IS_BF16 ? bf16_bits_to_f32(bias[nb + e]) : f16_bits_to_f32(bias[nb + e]);
+        }
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
+        if (m >= M) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = al[e] * (float)(acc[nf][mf][4 * rq + e] + cr[e]) + bv[e];
+        uint16_t* dst = y + m * N + nb;
+        if (y_vec_ok && nb + 4 <= N) {
+          *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair16<IS_BF16>(v[0], v[1]), cvt_pair16<IS_BF16>(v[2], v[3]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nb + e < N) dst[e] = IS_BF16 ? f32_to_bf16_bits(v[e]) : f32_to_f16_bits(v[e]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int inc_w8a8_gemm(const int8_t* xq, const int8_t* wq, const float* alpha, const int32_t* corr, const void* bias,
+                             void* y, int ydtype, int64_t M, int64_t N, int64_t K, inc_stream_t stream) {
+  INC_CHECK_ARG(xq && wq && alpha && y && M > 0 && N > 0 && K > 0);
+  if (ydtype != INC_BF16 && ydtype != INC_F16) return INC_ERR_UNSUPPORTED;
+  if ((K % IK) != 0) return INC_ERR_UNSUPPORTED;  // the module pads K to a multiple of 128 with zero weight codes
+  INC_CHECK_ARG(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(wq)) & 15) == 0);
+  INC_CHECK_ARG((int64_t)IM * K < ((int64_t)1 << 32));
+  const size_t smem = (size_t)2 * I_STAGE;  // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)w8a8_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)w8a8_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)(ceil_div64(M, IM) * ceil_div64(N, IN));
+  const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
+  hipStream_t s = inc_s(stream);
+  if (ydtype == INC_BF16)
+    w8a8_gemm_kernel<true><<<grid, 512, smem, s>>>(xq, wq, alpha, corr, (const uint16_t*)bias, (uint16_t*)y, M, N, K, y_vec_ok);
+  else
+    w8a8_gemm_kernel<false><<<grid, 512, smem, s>>>(xq, wq, alpha, corr, (const uint16_t*)bias, (uint16_t*)y, M, N, K, y_vec_ok);
+  INC_LAUNCH_RETURN();
+}

@@ -417,3 +417,96 @@ def awq_weight_scale(w, group_size):
             "inc_awq_weight_scale",
         )
     return (out / N).to(w.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K10-K14 SmoothQuant W8A8 (reference neural_compressor/torch/algorithms/smooth_quant/utility.py)
+# ---------------------------------------------------------------------------------------------------
+FLT_MAX = 3.4028234663852886e38
+
+
+def sq_new_minmax(K, device):
+    """(min, max) running buffers for sq_channel_minmax."""
+    return (torch.full((K,), FLT_MAX, dtype=torch.float32, device=device),
+            torch.full((K,), -FLT_MAX, dtype=torch.float32, device=device))
+
+
+def sq_channel_minmax(x2d, mn, mx):
+    """== Calibration._save_input_pc_hook (utility.py:858-883): running per-channel min / max of x [T, K]."""
+    dev = _dev(x2d, mn, mx)
+    if x2d.stride(-1) != 1:
+        x2d = x2d.contiguous()
+    T, K = x2d.shape
+    with torch.cuda.device(dev):
+        check(lib.inc_sq_channel_minmax(_ptr(x2d), dtype_code(x2d.dtype), T, K, x2d.stride(0), _ptr(mn), _ptr(mx), _stream()),
+              "inc_sq_channel_minmax")
+    return mn, mx
+
+
+def sq_weight_col_absmax(w, out=None):
+    """max_n |w[n,k]| accumulated into `out` (fp32 [K], zero-initialised): the weight side of cal_scale (:617-618)."""
+    w = w.contiguous()
+    dev = _dev(w, out)
+    N, K = w.shape
+    if out is None:
+        out = torch.zeros(K, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_sq_weight_col_absmax(_ptr(w), dtype_code(w.dtype), N, K, _ptr(out), _stream()), "inc_sq_weight_col_absmax")
+    return out
+
+
+def sq_cal_scale(amax_x, amax_w, alpha, weight_max_lb=1e-5):
+    """== cal_scale (utility.py:605-626) from the two abs-max vectors."""
+    amax_x = amax_x.to(torch.float32).contiguous()
+    amax_w = amax_w.to(torch.float32).contiguous()
+    dev = _dev(amax_x, amax_w)
+    K = amax_x.numel()
+    scale = torch.empty(K, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_sq_cal_scale(_ptr(amax_x), _ptr(amax_w), K, float(alpha), float(weight_max_lb), _ptr(scale), _stream()),
+              "inc_sq_cal_scale")
+    return scale
+
+
+def sq_quant_weight(w, smooth=None, Kp=None):
+    """== quant_dequant_w_v1 (utility.py:652-695, Linear, sym int8) of w * smooth -> (qw int8 [N,Kp], scale [N], rowsum [N])."""
+    w = w.contiguous()
+    smooth = None if smooth is None else smooth.to(torch.float32).contiguous()
+    dev = _dev(w, smooth)
+    N, K = w.shape
+    Kp = K if Kp is None else int(Kp)
+    qw = torch.empty((N, Kp), dtype=torch.int8, device=dev)
+    w_scale = torch.empty(N, dtype=torch.float32, device=dev)
+    rowsum = torch.empty(N, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_sq_quant_weight(_ptr(w), dtype_code(w.dtype), N, K, Kp, _ptr(smooth), _ptr(qw), _ptr(w_scale), _ptr(rowsum),
+                                      _stream()), "inc_sq_quant_weight")
+    return qw, w_scale, rowsum
+
+
+def sq_quant_act(x2d, in_scale, sx, zp, Kp=None):
+    """clamp(rint(x * in_scale / sx + zp), 0, 255) - 128 as int8 [M, Kp] (SQLinearWrapper.forward + quant_dequant_x_v1)."""
+    x2d = x2d.contiguous()
+    dev = _dev(x2d, in_scale)
+    M, K = x2d.shape
+    Kp = K if Kp is None else int(Kp)
+    out = torch.empty((M, Kp), dtype=torch.int8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_sq_quant_act(_ptr(x2d), dtype_code(x2d.dtype), M, K, Kp, _ptr(in_scale), float(sx), float(zp), _ptr(out),
+                                   _stream()), "inc_sq_quant_act")
+    return out
+
+
+def w8a8_gemm(xq, wq, alpha, corr, bias, out_dtype):
+    """y = alpha[n] * (xq @ wq^T + corr[n]) + bias[n], int32 accumulate on the matrix cores (K14)."""
+    dev = _dev(xq, wq, alpha, corr, bias)
+    M, K = xq.shape
+    N = wq.shape[0]
+    assert wq.shape[1] == K and xq.dtype == torch.int8 and wq.dtype == torch.int8
+    if bias is not None and bias.dtype != out_dtype:
+        bias = bias.to(out_dtype)
+    y = torch.empty((M, N), dtype=out_dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.inc_w8a8_gemm(_ptr(xq), _ptr(wq), _ptr(alpha), _ptr(corr), _ptr(bias), _ptr(y), dtype_code(out_dtype), M, N, K,
+                                _stream()), "inc_w8a8_gemm")
+    return y

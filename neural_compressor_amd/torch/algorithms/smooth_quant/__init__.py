@@ -1,0 +1,4 @@
+from .smooth_quant import SmoothQuantQuantizer
+from .utility import Calibration, SQLinearWrapper, TorchSmoothQuant, W8A8Linear, cal_scale
+
+__all__ = ["SmoothQuantQuantizer", "TorchSmoothQuant", "Calibration", "SQLinearWrapper", "W8A8Linear", "cal_scale"]

@@ -9,7 +9,7 @@ from types import MethodType
 
 import torch
 
-from ...common.utils import AWQ, GPTQ, RTN, Mode, logger
+from ...common.utils import AWQ, GPTQ, RTN, SMOOTH_QUANT, Mode, logger
 from ..utils.utility import get_quantizer, postprocess_model, register_algo
 
 
@@ -150,5 +150,29 @@ def awq_quantize_entry(model, configs_mapping, mode=Mode.QUANTIZE, *args, **kwar
     )
     model.qconfig = configs_mapping
     model.save = MethodType(_save, model)
+    postprocess_model(model, mode, quantizer)
+    return model
+
+
+@register_algo(SMOOTH_QUANT)
+@torch.no_grad()
+def smooth_quant_entry(model, configs_mapping, mode=Mode.QUANTIZE, *args, **kwargs):
+    """Reference algorithm_entry.py:285-345 (there: IPEX prepare/convert); here the plain dict per Linear goes to
+    SmoothQuantQuantizer and the result carries W8A8Linear modules."""
+    from ..algorithms.smooth_quant import SmoothQuantQuantizer
+
+    quant_config = {}
+    for (op_name, op_type), cfg in configs_mapping.items():
+        if cfg.name != SMOOTH_QUANT:
+            continue
+        quant_config[op_name] = {
+            "w_dtype": cfg.w_dtype, "alpha": cfg.alpha, "folding": cfg.folding, "scale_sharing": cfg.scale_sharing,
+            "absorb_to_layer": getattr(cfg, "absorb_to_layer", None),
+        }
+    run_fn = kwargs.get("run_fn", None)
+    example_inputs = kwargs.get("example_inputs", None)
+    quantizer = get_quantizer(model, quantizer_cls=SmoothQuantQuantizer, quant_config=quant_config)
+    model = quantizer.execute(model, mode=mode, run_fn=run_fn, example_inputs=example_inputs)
+    model.qconfig = configs_mapping
     postprocess_model(model, mode, quantizer)
     return model

@@ -12,14 +12,14 @@ from typing import List, Optional
 import torch
 
 from ...common.base_config import BaseConfig, register_config
-from ...common.utils import AWQ, DEFAULT_WHITE_LIST, GPTQ, RTN
-from ..utils.utility import LM_HEAD_NAMES, PRIORITY_AWQ, PRIORITY_GPTQ, PRIORITY_RTN, WOQ_WHITE_LIST
+from ...common.utils import AWQ, DEFAULT_WHITE_LIST, GPTQ, RTN, SMOOTH_QUANT
+from ..utils.utility import LM_HEAD_NAMES, PRIORITY_AWQ, PRIORITY_GPTQ, PRIORITY_RTN, PRIORITY_SMOOTH_QUANT, WOQ_WHITE_LIST
 
 FRAMEWORK_NAME = "torch"
 
 __all__ = [
     "RTNConfig", "GPTQConfig", "AWQConfig", "get_default_rtn_config", "get_default_gptq_config",
-    "get_default_awq_config", "FRAMEWORK_NAME",
+    "get_default_awq_config", "SmoothQuantConfig", "get_default_sq_config", "FRAMEWORK_NAME",
 ]
 
 
@@ -209,3 +209,70 @@ class AWQConfig(TorchBaseConfig):
 
 def get_default_awq_config() -> AWQConfig:
     return AWQConfig()
+
+
+@register_config(framework_name=FRAMEWORK_NAME, algo_name=SMOOTH_QUANT, priority=PRIORITY_SMOOTH_QUANT)
+class SmoothQuantConfig(TorchBaseConfig):
+    """SmoothQuant W8A8 (reference config.py:1485-1612): same fields and defaults.  On MI355X the supported cell is
+    the default one -- int8 per-channel symmetric weights, uint8 per-tensor asymmetric min/max activations -- and
+    `alpha` must be a number (the layer-wise "auto" tuner is not built)."""
+
+    name = SMOOTH_QUANT
+    supported_configs: List = []
+
+    def __init__(
+        self,
+        w_dtype: str = "int8",
+        w_sym: bool = True,
+        w_granularity: str = "per_channel",
+        w_algo: str = "minmax",
+        act_dtype: str = "uint8",
+        act_sym: bool = False,
+        act_granularity: str = "per_tensor",
+        act_algo: str = "minmax",
+        excluded_precisions: list = [],
+        alpha: float = 0.5,
+        folding: bool = False,
+        scale_sharing: bool = False,
+        init_alpha: float = 0.5,
+        alpha_min: float = 0.0,
+        alpha_max: float = 1.0,
+        alpha_step: float = 0.1,
+        shared_criterion: str = "max",
+        do_blockwise: bool = False,
+        auto_alpha_args: dict = None,
+        white_list: Optional[List] = DEFAULT_WHITE_LIST,
+        **kwargs,
+    ):
+        super().__init__(white_list=white_list)
+        _assign(self, locals(), [
+            "w_dtype", "w_sym", "w_granularity", "w_algo", "act_dtype", "act_sym", "act_granularity", "act_algo",
+            "excluded_precisions", "alpha", "folding", "scale_sharing", "init_alpha", "alpha_min", "alpha_max",
+            "alpha_step", "shared_criterion", "do_blockwise",
+        ])
+        self.auto_alpha_args = {
+            "init_alpha": init_alpha, "alpha_min": alpha_min, "alpha_max": alpha_max, "alpha_step": alpha_step,
+            "shared_criterion": shared_criterion, "do_blockwise": do_blockwise,
+        }
+        self.absorb_to_layer = kwargs.get("absorb_to_layer", None)
+        if w_dtype != "fp32":
+            unsupported = []
+            if w_dtype != "int8" or not w_sym or w_granularity != "per_channel" or w_algo != "minmax":
+                unsupported.append("weights must be int8 / symmetric / per_channel / minmax")
+            if act_dtype != "uint8" or act_sym or act_granularity != "per_tensor" or act_algo != "minmax":
+                unsupported.append("activations must be uint8 / asymmetric / per_tensor / minmax")
+            if unsupported:
+                raise NotImplementedError("SmoothQuant on MI355X: " + "; ".join(unsupported))
+        self._post_init()
+
+    @staticmethod
+    def get_model_info(model: torch.nn.Module, example_inputs=None):
+        return [(name, type(m).__name__) for name, m in model.named_modules() if isinstance(m, torch.nn.Linear)]
+
+    @classmethod
+    def register_supported_configs(cls):
+        cls.supported_configs = []
+
+
+def get_default_sq_config() -> SmoothQuantConfig:
+    return SmoothQuantConfig()

@@ -22,6 +22,7 @@ except Exception:  # pragma: no cover
 
 LM_HEAD_NAMES = [".*lm_head", ".*output_layer", ".*embed_out"]  # reference torch/utils/constants.py:69
 PRIORITY_GPTQ, PRIORITY_RTN, PRIORITY_AWQ = 90, 80, 70  # reference torch/utils/constants.py:45-48
+PRIORITY_SMOOTH_QUANT = 60
 
 algos_mapping = {}
 
@@ -42,6 +43,16 @@ def fetch_module(model, op_name):
         if not hasattr(mod, part):
             logger.warning("The %s is not present in the model.", op_name)
             return None
+        mod = getattr(mod, part)
+    return mod
+
+
+def get_module(model, op_name):
+    """Fetch a sub-module by dotted name (reference smooth_quant/utility.py:349-369)."""
+    mod = model
+    for part in op_name.split("."):
+        if part == "":
+            continue
         mod = getattr(mod, part)
     return mod
 

@@ -465,3 +465,75 @@ def woq_linear(x, qweight, scales_f16, qzeros, bias, N, K, bits, group_size, com
     w = torch.from_numpy(d * s).to(compute_dtype).float()
     y = torch.nn.functional.linear(x.to(compute_dtype).float(), w, None if bias is None else bias.float())
     return y
+
+
+# =====================================================================================================
+# SmoothQuant W8A8 (BASELINE config #4): neural_compressor/torch/algorithms/smooth_quant/utility.py
+# =====================================================================================================
+def sq_cal_scale(input_max_abs, weights, alpha, weight_max_lb=1e-5):
+    """cal_scale (:605-626): `weights` = list of [N_i, K] tensors that share the input."""
+    weights = torch.cat(weights, dim=0)
+    weight_max = torch.max(torch.abs(weights), dim=0)[0]
+    weight_max = torch.clip(weight_max, weight_max_lb)
+    input_power = torch.pow(input_max_abs, alpha)
+    weight_power = torch.pow(weight_max, 1 - alpha)
+    weight_scale = torch.clip(input_power / weight_power, min=1e-5)
+    weight_scale[input_power == 0] = 1.0
+    return weight_scale
+
+
+def sq_quant_w(w, num_bits=8):
+    """quant_dequant_w_v1 (:652-695), Linear, scheme "sym" -> (codes int32 [N,K], scale fp32 [N], dequantised [N,K])."""
+    eps = torch.finfo(torch.float32).eps
+    q_min, q_max = -(2.0 ** (num_bits - 1)), 2.0 ** (num_bits - 1) - 1.0
+    x_max = torch.max(torch.abs(w), dim=1).values
+    scale = x_max / (float(q_max - q_min) / 2)
+    scale = torch.clip(scale, min=eps).unsqueeze(dim=-1)
+    q = torch.round(w / scale)
+    q.clamp_(q_min, q_max)
+    return q.to(torch.int32), scale.squeeze(-1), q * scale
+
+
+def sq_act_qparams(input_scale, input_min, input_max):
+    """SQLinearWrapper._calculate_qparams (:2607-2631) for torch.quint8 -> (scale, zero_point) python floats."""
+    min_val = torch.min(input_min * input_scale)
+    max_val = torch.max(input_max * input_scale)
+    min_val_neg = torch.min(min_val, torch.zeros_like(min_val))
+    max_val_pos = torch.max(max_val, torch.zeros_like(max_val))
+    scale = (max_val_pos - min_val_neg) / 255.0
+    scale = torch.max(scale, torch.tensor(torch.finfo(torch.float32).eps))
+    zero_point = 0 - torch.round(min_val_neg / scale).to(torch.int)
+    zero_point = torch.clamp(zero_point, 0, 255)
+    return float(scale), int(zero_point)
+
+
+def sq_quant_x(x, scale, zero_point):
+    """The integer half of quant_dequant_x_v1 (:726-755) with given static parameters -> uint8 codes as int32."""
+    q = torch.round(x / scale + float(zero_point))
+    q.clamp_(0, 255)
+    return q.to(torch.int32)
+
+
+def sq_quant_dequant_x(x, min_x, max_x, num_bits=8):
+    """quant_dequant_x_v1 (:726-755) as written (parameters from the tensor-wide min / max)."""
+    eps = torch.finfo(torch.float32).eps
+    max_x, min_x = torch.max(max_x), torch.min(min_x)
+    scale = (max_x - min_x) / (2**num_bits - 1)
+    scale = torch.clip(scale, min=eps)
+    bias = torch.round((0 - min_x) / scale)
+    q_x = torch.round(x / scale + bias)
+    q_x.clamp_(0, 2.0**num_bits - 1.0)
+    return scale * (q_x - bias)
+
+
+def sq_w8a8_linear(x, w_smoothed, input_scale, act_scale, act_zp, bias=None):
+    """What the W8A8 module computes, in integers then one fp32 scaling:
+    y = s_x * s_w[n] * sum_k (qx - zp) * qw + b   with qx = quant(x * input_scale), qw = quant_w(w_smoothed)."""
+    xs = x if input_scale is None else x * input_scale
+    qx = sq_quant_x(xs.float(), act_scale, act_zp)
+    qw, sw, _ = sq_quant_w(w_smoothed.float())
+    acc = (qx.to(torch.int64) - act_zp) @ qw.to(torch.int64).T
+    y = acc.to(torch.float64) * (act_scale * sw.to(torch.float64)).unsqueeze(0)
+    if bias is not None:
+        y = y + bias.to(torch.float64)
+    return y.to(torch.float32)

@@ -39,6 +39,14 @@ def _install_stubs():
 
     pt.PrettyTable = PrettyTable
     sys.modules["prettytable"] = pt
+    # smooth_quant/utility.py imports intel_extension_for_pytorch at module level (:22); only its pure-torch functions
+    # (cal_scale, quant_dequant_w_v1, quant_dequant_x_v1, SQLinearWrapper) are called here, so an empty module suffices
+    import importlib.machinery
+
+    ipex = types.ModuleType("intel_extension_for_pytorch")
+    ipex.__version__ = "2.1.100+stub"
+    ipex.__spec__ = importlib.machinery.ModuleSpec("intel_extension_for_pytorch", loader=None)
+    sys.modules["intel_extension_for_pytorch"] = ipex
 
 
 def main():
@@ -210,6 +218,34 @@ def main():
     out["awqpack_qweight_in"], out["awqpack_qzeros_in"], out["awqpack_scales"] = aq.numpy(), az.numpy(), asc.numpy()
     out["awqpack_qweight"], out["awqpack_qzeros"] = rq.numpy(), rz.numpy()
     assert torch.equal(rs, asc)
+
+    # ---- 6c. SmoothQuant (BASELINE config #4): the in-tree pure-torch functions --------------------------------
+    from neural_compressor.torch.algorithms.smooth_quant import utility as sq
+
+    Ks, N1, N2 = 96, 24, 40
+    amax_x = torch.rand(Ks, generator=g) * 6.0
+    amax_x[5] = 0.0  # a dead channel: scale must come out as 1
+    w1 = torch.randn(N1, Ks, generator=g) * 0.1
+    w2 = torch.randn(N2, Ks, generator=g) * 0.1
+    w2[:, 7] = 0.0  # a column below weight_max_lb
+    out["sq_amax_x"], out["sq_w1"], out["sq_w2"] = amax_x.numpy(), w1.numpy(), w2.numpy()
+    for a in (0.5, 0.8):
+        out[f"sq_scale_a{int(a * 10)}"] = sq.cal_scale(amax_x.clone(), [w1.clone(), w2.clone()], a).numpy()
+    lin = torch.nn.Linear(Ks, N1, bias=False)
+    lin.weight.data.copy_(w1)
+    out["sq_qdq_w_sym"] = sq.quant_dequant_w_v1(lin, num_bits=8, scheme="sym").detach().numpy()
+    xs = torch.randn(20, Ks, generator=g) * 2.0 + 0.3
+    out["sq_x"] = xs.numpy()
+    mnx, mxx = xs.min(dim=0)[0], xs.max(dim=0)[0]
+    out["sq_qdq_x"] = sq.quant_dequant_x_v1(xs.clone(), mnx, mxx, num_bits=8).numpy()
+    in_scale = 1.0 / sq.cal_scale(torch.max(mnx.abs(), mxx.abs()), [w1.clone()], 0.5)
+    wrap = sq.SQLinearWrapper(lin, in_scale.clone(), [mnx.clone(), mxx.clone()], alpha=0.5)
+    out["sq_wrap_in_scale"] = in_scale.numpy()
+    out["sq_wrap_scale"] = wrap.scale.numpy()
+    out["sq_wrap_zp"] = wrap.zero_point.numpy()
+    out["sq_wrap_weight"] = wrap.sq_linear.weight.detach().numpy()  # W / input_scale (:2646-2653)
+    with torch.no_grad():
+        out["sq_wrap_out"] = wrap(xs).numpy()
 
     np.savez_compressed(os.path.join(HERE, "woq_golden.npz"), **out)
     print(f"wrote {len(out)} arrays to tests/golden/woq_golden.npz")

@@ -1,0 +1,178 @@
+"""GPU: SmoothQuant W8A8 (BASELINE config #4) -- kernels K10-K14 against the oracle / the reference's golden outputs, the
+W8A8 module against the integer restatement, and the model-level flow (prepare -> calibrate -> convert)."""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.woq_oracle as O
+from tests.model_zoo import calib_ids, tiny_llama
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_fro(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+def test_channel_minmax_is_exact_and_running(hip, dt):
+    from neural_compressor_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    T, K = 1500, 1000  # ragged in both directions
+    x1 = (torch.randn(T, K, generator=g) * 3).to(dt)
+    x2 = (torch.randn(77, K, generator=g) * 5 - 1).to(dt)
+    mn, mx = ops.sq_new_minmax(K, hip)
+    ops.sq_channel_minmax(x1.to(hip), mn, mx)
+    ops.sq_channel_minmax(x2.to(hip), mn, mx)
+    ref = torch.cat([x1, x2]).float()
+    assert torch.equal(mn.cpu(), ref.min(dim=0)[0])
+    assert torch.equal(mx.cpu(), ref.max(dim=0)[0])
+    # all-negative and all-positive channels exercise both branches of the ordered-int atomics
+    x3 = torch.cat([-torch.rand(300, 8, generator=g) - 1, torch.rand(300, 8, generator=g) + 1], dim=1).to(dt)
+    mn, mx = ops.sq_new_minmax(16, hip)
+    ops.sq_channel_minmax(x3.to(hip), mn, mx)
+    assert torch.equal(mn.cpu(), x3.float().min(dim=0)[0]) and torch.equal(mx.cpu(), x3.float().max(dim=0)[0])
+
+
+def test_cal_scale_vs_reference_golden(hip, golden):
+    from neural_compressor_amd.torch.algorithms.smooth_quant import cal_scale
+
+    amax_x = torch.from_numpy(golden["sq_amax_x"]).to(hip)
+    ws = [torch.from_numpy(golden["sq_w1"]).to(hip), torch.from_numpy(golden["sq_w2"]).to(hip)]
+    for a in (0.5, 0.8):
+        s = cal_scale(amax_x, ws, a).cpu().numpy()
+        ref = golden[f"sq_scale_a{int(a * 10)}"]
+        assert np.allclose(s, ref, rtol=2e-6, atol=0), np.abs(s / ref - 1).max()  # powf: last-bit differences vs the CPU's pow
+        assert s[5] == 1.0
+
+
+def test_quant_weight_bit_exact(hip, golden):
+    from neural_compressor_amd import ops
+
+    w = torch.from_numpy(golden["sq_w1"])
+    qw, sw, rs = ops.sq_quant_weight(w.to(hip), None, 128)
+    q, s, qdq = O.sq_quant_w(w)
+    assert torch.equal(qw[:, : w.shape[1]].cpu().to(torch.int32), q) and int(qw[:, w.shape[1]:].abs().max()) == 0
+    assert torch.equal(sw.cpu(), s) and torch.equal(rs.cpu(), q.sum(dim=1).to(torch.int32))
+    assert np.array_equal((qw[:, : w.shape[1]].float() * sw.view(-1, 1)).cpu().numpy(), golden["sq_qdq_w_sym"])
+    # with a smoothing vector, at a Llama-2-13B layer size (5120 -> 13824): codes, scales and row sums
+    g = torch.Generator().manual_seed(1)
+    W = (torch.randn(1024, 5120, generator=g) * 0.02).to(torch.float16)
+    sm = torch.rand(5120, generator=g) * 3 + 0.1
+    qw, sw, rs = ops.sq_quant_weight(W.to(hip), sm.to(hip), 5120)
+    q, s, _ = O.sq_quant_w(W.float() * sm.view(1, -1))
+    assert torch.equal(qw.cpu().to(torch.int32), q) and torch.equal(sw.cpu(), s)
+    assert torch.equal(rs.cpu(), q.sum(dim=1).to(torch.int32))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+def test_quant_act_bit_exact(hip, golden, dt):
+    from neural_compressor_amd import ops
+
+    x = torch.from_numpy(golden["sq_x"]).to(dt)
+    in_scale = torch.from_numpy(golden["sq_wrap_in_scale"])
+    sx, zp = float(golden["sq_wrap_scale"].reshape(-1)[0]), int(golden["sq_wrap_zp"].reshape(-1)[0])
+    out = ops.sq_quant_act(x.to(hip), in_scale.to(hip), sx, zp, 128)
+    ref = O.sq_quant_x(x.float() * in_scale, sx, zp) - 128
+    assert torch.equal(out[:, : x.shape[1]].cpu().to(torch.int32), ref)
+    assert int((out[:, x.shape[1]:].to(torch.int32) + 128).abs().max()) == 0  # padding = code 0
+    out2 = ops.sq_quant_act(x.to(hip), None, sx, zp, 96)
+    assert torch.equal(out2.cpu().to(torch.int32), O.sq_quant_x(x.float(), sx, zp) - 128)
+
+
+@pytest.mark.parametrize("M,N,K,dt", [(256, 256, 128, torch.bfloat16), (300, 1000, 384, torch.float16), (1, 512, 256, torch.bfloat16),
+                                      (2048, 5120, 5120, torch.bfloat16), (4096, 4096, 11008, torch.float16)])
+def test_w8a8_gemm_integer_exact(hip, M, N, K, dt):
+    """int32 accumulation is exact: y == alpha * (xq @ wq^T + corr) + bias rounded once to the output dtype."""
+    from neural_compressor_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    xq = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int32).to(torch.int8).to(hip)
+    wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int32).to(torch.int8).to(hip)
+    alpha = (torch.rand(N, generator=g) * 1e-4 + 1e-5).to(hip)
+    corr = torch.randint(-100000, 100000, (N,), generator=g, dtype=torch.int32).to(hip)
+    bias = (torch.randn(N, generator=g) * 0.5).to(dt).to(hip)
+    y = ops.w8a8_gemm(xq, wq, alpha, corr, bias, dt)
+    acc = xq.double() @ wq.double().T  # exact in fp64 (|sum| < 2^53)
+    want = (alpha.double().view(1, -1) * (acc + corr.double().view(1, -1))).float()  # the kernel's fp32 product ...
+    want = (alpha.view(1, -1) * (acc + corr.double().view(1, -1)).float() + bias.float().view(1, -1)).to(dt)  # ... and its rounding
+    assert torch.equal(y, want), float((y.float() - want.float()).abs().max())
+    y0 = ops.w8a8_gemm(xq, wq, alpha, None, None, dt)
+    assert torch.equal(y0, (alpha.view(1, -1) * acc.float()).to(dt))
+
+
+def test_w8a8_linear_matches_the_fake_quant_specification(hip, golden):
+    """W8A8Linear.from_float(SQLinearWrapper) == F.linear(quant_dequant_x(x * s), quant_dequant_w(W / s)) computed in
+    integers (oracle), and both stay near the float layer the reference's wrapper evaluates (golden)."""
+    from neural_compressor_amd.torch.algorithms.smooth_quant import SQLinearWrapper, W8A8Linear
+
+    x = torch.from_numpy(golden["sq_x"])
+    w1 = torch.from_numpy(golden["sq_w1"])
+    in_scale = torch.from_numpy(golden["sq_wrap_in_scale"])
+    lin = torch.nn.Linear(w1.shape[1], w1.shape[0], bias=True).to(hip)
+    lin.weight.data.copy_(w1)
+    torch.manual_seed(0)
+    lin.bias.data.normal_()
+    mn, mx = x.min(dim=0)[0], x.max(dim=0)[0]
+    wrap = SQLinearWrapper(lin, in_scale.clone().to(hip), [mn.to(hip), mx.to(hip)])
+    assert float(wrap.scale) == float(golden["sq_wrap_scale"].reshape(-1)[0]) and int(wrap.zero_point) == int(golden["sq_wrap_zp"].reshape(-1)[0])
+    assert np.array_equal(wrap.sq_linear.weight.detach().cpu().numpy(), golden["sq_wrap_weight"])
+    m = W8A8Linear.from_float(wrap, mn, mx, device=hip)
+    y = m(x.to(hip).half()).float().cpu()
+    want = O.sq_w8a8_linear(x.half().float(), torch.from_numpy(golden["sq_wrap_weight"]), in_scale, float(wrap.scale), int(wrap.zero_point),
+                            lin.bias.detach().cpu().half().float())
+    assert rel_fro(y, want) <= 1e-3  # fp16 output rounding
+    ref_float = torch.from_numpy(golden["sq_wrap_out"]) + lin.bias.detach().cpu()
+    assert rel_fro(y, ref_float) <= 0.05
+
+
+@pytest.mark.parametrize("folding", [False, True])
+def test_smooth_quant_tiny_llama_end_to_end(folding):
+    """prepare -> calibration -> convert on a random-init Llama: every selected Linear becomes W8A8Linear, the smoothing is
+    function-preserving (checked in float before quantisation through TorchSmoothQuant) and W8A8 logits stay close."""
+    from neural_compressor_amd.torch.algorithms.smooth_quant import SQLinearWrapper, TorchSmoothQuant, W8A8Linear
+    from neural_compressor_amd.torch.quantization import SmoothQuantConfig, convert, prepare
+
+    ids = calib_ids(n=8, seq=32)
+    fp = tiny_llama(dtype=torch.float16).to("cuda")
+    with torch.no_grad():
+        ref = fp(ids[0].to("cuda")).logits.float()
+
+    # (1) the transform alone keeps the function (reference transform() :2409-2417 checks the same, atol 1e-4 in fp32)
+    m32 = tiny_llama().to("cuda")
+    with torch.no_grad():
+        before = m32(ids[0].to("cuda")).logits
+
+    def run(model):
+        for x in ids:
+            model(x.to("cuda"))
+
+    sq = TorchSmoothQuant(m32, q_func=run, scale_sharing=True)
+    sq.transform(alpha=0.5, folding=folding)
+    with torch.no_grad():
+        after = m32(ids[0].to("cuda")).logits
+    assert float((after - before).abs().max()) <= 2e-4
+    n_wrapped = sum(isinstance(m, SQLinearWrapper) for m in m32.modules())
+    if folding:
+        assert n_wrapped == 0 and len(sq.absorb_to_layer) == 4  # two norms per block feed q/k/v and gate/up
+        assert sorted(len(v) for v in sq.absorb_to_layer.values()) == [2, 2, 3, 3]
+    else:
+        assert n_wrapped == 15  # 14 block Linears + lm_head
+        assert any(len(v) == 3 for v in sq.absorb_to_layer.values())  # q/k/v share one scale
+
+    # (2) the public flow
+    cfg = SmoothQuantConfig(alpha=0.5, folding=folding, scale_sharing=True)
+    cfg.set_local("lm_head", SmoothQuantConfig(w_dtype="fp32"))
+    model = prepare(tiny_llama(dtype=torch.float16), cfg, example_inputs=ids[0])
+    run(model)
+    q = convert(model)
+    mods = {n: m for n, m in q.named_modules() if isinstance(m, W8A8Linear)}
+    assert len(mods) == 14 and "lm_head" not in mods
+    for n, m in mods.items():
+        assert (m.input_scale is None) == (folding and ("q_proj" in n or "k_proj" in n or "v_proj" in n or "gate_proj" in n or "up_proj" in n)) or not folding
+    with torch.no_grad():
+        y = q(ids[0].to("cuda")).logits.float()
+    assert torch.isfinite(y).all()
+    assert rel_fro(y, ref) <= 0.08, rel_fro(y, ref)

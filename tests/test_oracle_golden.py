@@ -134,6 +134,33 @@ def test_awq_checkpoint_repack(golden):
     assert np.array_equal(qz, golden["awqpack_qzeros"])
 
 
+def test_smooth_quant_functions(golden):
+    """SmoothQuant restatements == the reference's in-tree functions (cal_scale, quant_dequant_w_v1, quant_dequant_x_v1,
+    SQLinearWrapper) on the same inputs."""
+    amax_x = torch.from_numpy(golden["sq_amax_x"])
+    w1, w2 = torch.from_numpy(golden["sq_w1"]), torch.from_numpy(golden["sq_w2"])
+    for a in (0.5, 0.8):
+        s = O.sq_cal_scale(amax_x.clone(), [w1, w2], a)
+        assert np.array_equal(s.numpy(), golden[f"sq_scale_a{int(a * 10)}"])
+    assert float(O.sq_cal_scale(amax_x.clone(), [w1, w2], 0.5)[5]) == 1.0
+    q, sw, qdq = O.sq_quant_w(w1)
+    assert np.array_equal(qdq.numpy(), golden["sq_qdq_w_sym"])
+    assert int(q.min()) >= -128 and int(q.max()) <= 127
+    x = torch.from_numpy(golden["sq_x"])
+    assert np.array_equal(O.sq_quant_dequant_x(x.clone(), x.min(dim=0)[0], x.max(dim=0)[0]).numpy(), golden["sq_qdq_x"])
+    in_scale = torch.from_numpy(golden["sq_wrap_in_scale"])
+    sx, zp = O.sq_act_qparams(in_scale, x.min(dim=0)[0], x.max(dim=0)[0])
+    assert np.float32(sx) == golden["sq_wrap_scale"].reshape(-1)[0] and zp == int(golden["sq_wrap_zp"].reshape(-1)[0])
+    # the wrapper holds W / input_scale and multiplies the activations by input_scale: same function as the float layer
+    assert np.allclose((w1 / in_scale.view(1, -1)).numpy(), golden["sq_wrap_weight"], rtol=0, atol=0)
+    y = torch.nn.functional.linear(x * in_scale, torch.from_numpy(golden["sq_wrap_weight"]))
+    assert np.allclose(y.numpy(), golden["sq_wrap_out"], rtol=1e-6, atol=1e-6)
+    # and the integer W8A8 form stays within the quantisation error of that float output
+    y8 = O.sq_w8a8_linear(x, torch.from_numpy(golden["sq_wrap_weight"]), in_scale, sx, zp)
+    rel = float((y8 - y).norm() / y.norm())
+    assert rel < 0.05, rel
+
+
 def test_awq_stats(golden):
     w = torch.from_numpy(golden["awq_w"])
     assert np.array_equal(O.awq_weight_scale(w, 32).numpy(), golden["awq_wscale_g32"])
