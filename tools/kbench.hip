@@ -41,6 +41,7 @@ static inline uint32_t rnd() {
   rng_state ^= rng_state << 17;
   return (uint32_t)(rng_state >> 32);
 }
+static inline float rnd_uniform() { return (float)(rnd() & 0xffffff) / 16777216.f; }  // [0, 1)
 static inline float rnd_normal() {  // sum of 4 uniforms, unit variance, zero mean
   float s = 0.f;
   for (int i = 0; i < 4; ++i) s += (float)(rnd() & 0xffffff) / 16777216.f - 0.5f;
@@ -269,6 +270,68 @@ static int run_gemv_repeat(int64_t N, int64_t K, int M) {
   return bad ? 1 : 0;
 }
 
+// K14: W8A8 GEMM -- a sampled check against a naive int32 dot product, then timing (Llama-2-13B shapes of BASELINE config #4)
+__global__ void ref_i8_rows(const int8_t* xq, const int8_t* wq, const int* rows, int nrows, int64_t N, int64_t K, int* out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (n >= N || r >= nrows) return;
+  const int8_t* a = xq + (int64_t)rows[r] * K;
+  const int8_t* b = wq + n * K;
+  int acc = 0;
+  for (int64_t k = 0; k < K; ++k) acc += (int)a[k] * (int)b[k];
+  out[(int64_t)r * N + n] = acc;
+}
+
+static int run_i8_case(int64_t M, int64_t N, int64_t K) {
+  DevBuf<int8_t> xq((size_t)M * K), wq((size_t)N * K);
+  DevBuf<float> alpha((size_t)N);
+  DevBuf<int32_t> corr((size_t)N);
+  DevBuf<uint16_t> y((size_t)M * N);
+  {
+    std::vector<int8_t> hx(xq.n), hw(wq.n);
+    for (auto& v : hx) v = (int8_t)((int)(rnd_uniform() * 256.f) - 128);
+    for (auto& v : hw) v = (int8_t)((int)(rnd_uniform() * 256.f) - 128);
+    std::vector<float> ha(N);
+    std::vector<int32_t> hc(N);
+    for (int64_t n = 0; n < N; ++n) { ha[n] = 1e-5f * (1.f + rnd_uniform()); hc[n] = (int32_t)(rnd_uniform() * 20000.f) - 10000; }
+    xq.upload(hx); wq.upload(hw); alpha.upload(ha); corr.upload(hc);
+  }
+  INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, nullptr));
+  HIPCHECK(hipDeviceSynchronize());
+  const int check_rows = 16;
+  std::vector<int> rows;
+  for (int r = 0; r < check_rows; ++r) rows.push_back((int)(((int64_t)r * 7919) % M));
+  rows[check_rows - 1] = (int)(M - 1);
+  DevBuf<int> drows(rows.size());
+  drows.upload(rows);
+  DevBuf<int> ref((size_t)check_rows * N);
+  ref_i8_rows<<<dim3((unsigned)((N + 255) / 256), (unsigned)check_rows), 256>>>(xq.p, wq.p, drows.p, check_rows, N, K, ref.p);
+  HIPCHECK(hipDeviceSynchronize());
+  std::vector<int> href = ref.download();
+  std::vector<uint16_t> hy = y.download();
+  std::vector<float> ha = alpha.download();
+  std::vector<int32_t> hc = corr.download();
+  int64_t bad = 0;
+  for (int r = 0; r < check_rows; ++r)
+    for (int64_t n = 0; n < N; ++n) {
+      const float want = ha[n] * (float)(href[(size_t)r * N + n] + hc[n]);
+      if (hy[(size_t)rows[r] * N + n] != f2bf(want)) ++bad;
+    }
+  Timer t;
+  for (int i = 0; i < 10; ++i) INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, nullptr));
+  std::vector<float> ms;
+  for (int r = 0; r < 5; ++r) {
+    t.start();
+    for (int i = 0; i < 8; ++i) INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, nullptr));
+    ms.push_back(t.stop_ms() / 8);
+  }
+  std::sort(ms.begin(), ms.end());
+  const double ops = 2.0 * M * N * K, bytes = (double)M * K + (double)N * K + 2.0 * M * N;
+  printf("W8A8 GEMM M=%ld N=%ld K=%ld: %ld mismatching outputs in %d sampled rows  median %8.4f ms %8.1f TOP/s %7.1f GB/s  (best %8.4f ms %8.1f TOP/s)  %s\n",
+         (long)M, (long)N, (long)K, (long)bad, check_rows, ms[2], ops / ms[2] / 1e9, bytes / ms[2] / 1e6, ms[0], ops / ms[0] / 1e9, bad ? "FAIL" : "OK");
+  return bad ? 1 : 0;
+}
+
 static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
   DevBuf<uint16_t> x((size_t)T * K);
   {
@@ -454,6 +517,13 @@ int main(int argc, char** argv) {
     fails += run_gemm_case(3, 1000, 416, 32, false, true, false, 3);   // ragged N, K tail of the split, gs=32
     fails += run_gemv_repeat(4096, 4096, 1);
     fails += run_gemv_repeat(4096, 11008, 16);
+  }
+  if (what == "i8gemm" || what == "all") {
+    fails += run_i8_case(300, 1000, 384);
+    fails += run_i8_case(4096, 5120, 5120);     // Llama-2-13B q/k/v/o
+    fails += run_i8_case(4096, 13824, 5120);    // gate / up
+    fails += run_i8_case(4096, 5120, 13824);    // down
+    fails += run_i8_case(8192, 8192, 8192);
   }
   if (what == "hessian" || what == "all") {
     fails += run_hessian_case(200, 320, false);     // token tail + ragged feature tile
