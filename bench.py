@@ -136,6 +136,39 @@ def bench_dequant_gemm(device, shapes, iters=20):
     return res
 
 
+def bench_w8a8_gemm(device, shapes, iters=20):
+    """BASELINE config #4's kernel (SmoothQuant W8A8, Llama-2-13B shapes): the whole W8A8Linear forward = activation
+    quantisation (HBM-bound) + INT8 MFMA GEMM; `gemm_ms` is the GEMM alone."""
+    from neural_compressor_amd import ops
+    from neural_compressor_amd.torch.algorithms.smooth_quant import W8A8Linear
+
+    res = []
+    for (M, N, K) in shapes:
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(K, N, bias=False, device=device, dtype=torch.bfloat16)
+        lin.weight.data.normal_(0, 0.02)
+        x = torch.randn(M, K, device=device, dtype=torch.bfloat16)
+        m = W8A8Linear.from_float(lin, x.float().min(dim=0)[0], x.float().max(dim=0)[0], device=device)
+        del lin
+        xq = ops.sq_quant_act(x, None, m.act_scale.item(), m.act_zp.item(), m.kp)
+        out = {}
+        for tag, fn in (("fwd", lambda: m(x)), ("gemm", lambda: ops.w8a8_gemm(xq, m.qweight, m.alpha, m.corr, None, torch.bfloat16))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            out[tag] = e0.elapsed_time(e1) / iters
+        ops_ = 2.0 * M * N * K
+        res.append(dict(M=M, N=N, K=K, fwd_ms=round(out["fwd"], 4), gemm_ms=round(out["gemm"], 4),
+                        gemm_tops=round(ops_ / out["gemm"] / 1e9, 1), fwd_tops=round(ops_ / out["fwd"] / 1e9, 1)))
+    return res
+
+
 def _cpu_baseline_worker(threads):
     """Runs in a child process: times the oracle (CPU restatement of the reference) on a bounded sample."""
     from oracle import woq_oracle as O
@@ -309,6 +342,8 @@ def main():
         torch.cuda.empty_cache()
         result["dequant_gemm"] = bench_dequant_gemm(device, shapes)
         note("dequant-GEMM shapes timed")
+        result["w8a8_gemm"] = bench_w8a8_gemm(device, [(4096, 5120, 5120), (4096, 13824, 5120), (4096, 5120, 13824)])
+        note("W8A8 shapes timed")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         note("cpu baseline done")
