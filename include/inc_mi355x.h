@@ -263,7 +263,11 @@ int inc_awq_repack(const int32_t* awq_qweight, const int32_t* awq_qzeros, int64_
  *   SQLinearWrapper._calculate_qparams (:2607-2631); in_scale may be NULL (folded smoothing).  Kp % 16 == 0.
  * inc_w8a8_gemm: y[m,n] = alpha[n] * (sum_k xq[m,k] * wq[n,k] + corr[n]) + bias[n]   (v_mfma_i32_32x32x32_i8)
  *   alpha[n] = sx * w_scale[n], corr[n] = (128 - zp) * rowsum[n] (may be NULL), bias in ydtype or NULL,
- *   y bf16 / fp16 [M,N]; K % 128 == 0 (pad with zero weight codes), xq / wq 16-byte aligned.                        */
+ *   y bf16 / fp16 [M,N]; K % 128 == 0 (pad with zero weight codes), xq / wq 16-byte aligned.
+ *   workspace (inc_w8a8_gemm_workspace_bytes, may be NULL): when the last round of 256x256 tiles would leave most
+ *   CUs idle its tiles are split along K into int32 slabs there and a second small kernel finishes them (no
+ *   initialisation needed).  Integer sums: the result is bit-identical with or without the workspace.               */
+int64_t inc_w8a8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int inc_sq_channel_minmax(const void* x, int xdtype, int64_t T, int64_t K, int64_t ld, float* mn, float* mx,
                           inc_stream_t stream);
 int inc_sq_weight_col_absmax(const void* w, int wdtype, int64_t N, int64_t K, float* out, inc_stream_t stream);
@@ -274,7 +278,8 @@ int inc_sq_quant_weight(const void* w, int wdtype, int64_t N, int64_t K, int64_t
 int inc_sq_quant_act(const void* x, int xdtype, int64_t M, int64_t K, int64_t Kp, const float* in_scale, float sx, float zp,
                      int8_t* out, inc_stream_t stream);
 int inc_w8a8_gemm(const int8_t* xq, const int8_t* wq, const float* alpha, const int32_t* corr, const void* bias, void* y,
-                  int ydtype, int64_t M, int64_t N, int64_t K, inc_stream_t stream);
+                  int ydtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
+                  inc_stream_t stream);
 
 #ifdef __cplusplus
 }

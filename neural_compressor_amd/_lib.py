@@ -51,7 +51,8 @@ SIGNATURES = {
     "inc_sq_cal_scale": (c_int, [_P, _P, c_int64, c_float, c_float, _P, _P]),
     "inc_sq_quant_weight": (c_int, [_P, c_int, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P]),
     "inc_sq_quant_act": (c_int, [_P, c_int, c_int64, c_int64, c_int64, _P, c_float, c_float, _P, _P]),
-    "inc_w8a8_gemm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, c_int64, _P]),
+    "inc_w8a8_gemm_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "inc_w8a8_gemm": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, c_int64, c_int64, _P, c_int64, _P]),
     "inc_awq_repack": (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int, _P, _P, _P]),
     "inc_gptq_find_params_mse": (
         c_int,

@@ -610,6 +610,10 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   constexpr bool NO_RD = SCHED == 12 || SCHED == 15 || SCHED == 16 || (PPM & 4);   // no fragment reads
   constexpr bool NO_LD = SCHED == 13 || SCHED == 15 || SCHED == 16 || (PPM & 1);   // no global loads / LDS-DMA
   constexpr bool NO_BAR = SCHED == 14 || SCHED == 16;                 // no per-step barrier
+  constexpr bool NO_VMWAIT = SCHED == 17;                             // loads issued, their counted waits dropped
+  constexpr bool FIXED_ADDR = SCHED == 18;                            // loads always fetch K-tile 0 (address arithmetic hoisted)
+  constexpr bool NO_WLD = SCHED == 19;                                // x LDS-DMA kept, the 6 W-side loads dropped
+  constexpr bool NO_DMA = SCHED == 20;                                // W-side loads kept, the 4 x LDS-DMAs dropped
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
   uint32_t avoff[4];
@@ -640,11 +644,11 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
 
   // one step's requests: 6 for W (4 packed words, scale, zero word) FIRST, then 4 x DMAs
   auto issue_w = [&](int kt, uint32_t (&w)[4], uint32_t& sb, uint32_t& zw) {
-    if (NO_LD) {
+    if (NO_LD || NO_WLD) {
       asm volatile("" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(sb), "=v"(zw));
       return;
     }
-    kt = kbase + (kt > nk - 1 ? nk - 1 : kt);
+    kt = FIXED_ADDR ? 0 : kbase + (kt > nk - 1 ? nk - 1 : kt);
     const uint32_t* wbase = qweight + (int64_t)kt * (TK / 8) * N;
     const int64_t g = g_shift >= 0 ? (((int64_t)kt * TK + 32 * kwh_s) >> g_shift) : 0;  // wave-uniform (kwh is)
     const uint16_t* sbase = scales + g * N;
@@ -662,8 +666,8 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
         : "memory");
   };
   auto issue_dma = [&](int kt, int astage) {
-    if (NO_LD) return;
-    kt = kbase + (kt > nk - 1 ? nk - 1 : kt);
+    if (NO_LD || NO_DMA) return;
+    kt = FIXED_ADDR ? 0 : kbase + (kt > nk - 1 ? nk - 1 : kt);
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + astage * T_ASTAGE + wave * 4096);
     lds_dma_4x1k(xtile + (int64_t)kt * TK, dst, avoff[0], avoff[1], avoff[2], avoff[3]);
   };
@@ -803,7 +807,8 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     if (SCHED != 0) INC_SB();                                                                                      \
     if (!NO_RD) read_frags(As, Bs, 1, xY, wY);                                                                               \
     if (SCHED != 0) INC_SB();                                                                                           \
-    asm volatile("s_waitcnt vmcnt(14)" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory"); \
+    if (NO_VMWAIT) asm volatile("" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory");        \
+    else asm volatile("s_waitcnt vmcnt(14)" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory"); \
     float sc_, nzs_;                                                                                               \
     group_params(DWS, DWZ, sc_, nzs_);                                                                             \
     if (SCHED != 0) dequant_into(bs_ ^ 1, 0, DW[0], sc_, nzs_);                                                         \
@@ -822,7 +827,8 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     mma8(xX, wX);                       /* group 2 */                                                              \
     if (SCHED == 0) { dequant_into(bs_ ^ 1, 2, DW[2], sc_, nzs_); dequant_into(bs_ ^ 1, 3, DW[3], sc_, nzs_); }        \
     if (SCHED != 0) INC_SB();                                                                                           \
-    asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    if (NO_VMWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+    else asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                 \
     if (!NO_BAR) __builtin_amdgcn_s_barrier();                                                                                  \
     if (!NO_RD) read_frags(Abase + ((t_ + 1) % 3) * T_ASTAGE, Bbase + (bs_ ^ 1) * T_BSTAGE + b_off, 0, xX, wX);               \
     if (SCHED != 0) INC_SB();                                                                                           \
@@ -1279,14 +1285,14 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M >= 128 && N >= 64 &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
   const int dbg = inc_small_tiles_flag(-1);
-  if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 26) || (dbg >= 31 && dbg <= 37))) {
+  if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 30) || (dbg >= 31 && dbg <= 37))) {
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
     static bool a3_attr_set = false;
     if (!a3_attr_set) {
 #define INC_A3_ATTR(B, S) (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<B, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
       INC_A3_ATTR(true, 0); INC_A3_ATTR(true, 1); INC_A3_ATTR(false, INC_3A2B_DEFAULT_SCHED);
       INC_A3_ATTR(true, 10); INC_A3_ATTR(true, 11); INC_A3_ATTR(true, 12); INC_A3_ATTR(true, 13); INC_A3_ATTR(true, 14);
-      INC_A3_ATTR(true, 15); INC_A3_ATTR(true, 16); INC_A3_ATTR(true, 3);
+      INC_A3_ATTR(true, 15); INC_A3_ATTR(true, 16); INC_A3_ATTR(true, 3); INC_A3_ATTR(true, 17); INC_A3_ATTR(true, 18); INC_A3_ATTR(true, 19); INC_A3_ATTR(true, 20);
       INC_A3_ATTR(true, 31); INC_A3_ATTR(true, 32); INC_A3_ATTR(true, 34); INC_A3_ATTR(true, 37);
 #undef INC_A3_ATTR
       a3_attr_set = true;
@@ -1318,6 +1324,10 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     else if (dbg == 24) INC_A3(true, 14);
     else if (dbg == 25) INC_A3(true, 15);
     else if (dbg == 26) INC_A3(true, 16);
+    else if (dbg == 27) INC_A3(true, 17);
+    else if (dbg == 28) INC_A3(true, 18);
+    else if (dbg == 29) INC_A3(true, 19);
+    else if (dbg == 30) INC_A3(true, 20);
     else if (sched == 0) INC_A3(true, 0);
     else INC_A3(true, 1);
 #undef INC_A3

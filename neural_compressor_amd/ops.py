@@ -506,7 +506,23 @@ def w8a8_gemm(xq, wq, alpha, corr, bias, out_dtype):
     if bias is not None and bias.dtype != out_dtype:
         bias = bias.to(out_dtype)
     y = torch.empty((M, N), dtype=out_dtype, device=dev)
+    nbytes = lib.inc_w8a8_gemm_workspace_bytes(M, N, K)
+    ws = _workspace_i8(dev, nbytes) if nbytes > 0 else None
     with torch.cuda.device(dev):
         check(lib.inc_w8a8_gemm(_ptr(xq), _ptr(wq), _ptr(alpha), _ptr(corr), _ptr(bias), _ptr(y), dtype_code(out_dtype), M, N, K,
-                                _stream()), "inc_w8a8_gemm")
+                                _ptr(ws), 0 if ws is None else ws.numel(), _stream()), "inc_w8a8_gemm")
     return y
+
+
+_ws_i8_cache = {}
+
+
+def _workspace_i8(dev, nbytes):
+    """Zero-filled on creation (arrival tickets), one per (device, stream); separate from the 4-bit GEMM's workspace
+    because both kernels keep their tickets in the first 16 KiB."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ws_i8_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _ws_i8_cache[key] = buf
+    return buf

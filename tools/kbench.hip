@@ -296,7 +296,13 @@ static int run_i8_case(int64_t M, int64_t N, int64_t K) {
     for (int64_t n = 0; n < N; ++n) { ha[n] = 1e-5f * (1.f + rnd_uniform()); hc[n] = (int32_t)(rnd_uniform() * 20000.f) - 10000; }
     xq.upload(hx); wq.upload(hw); alpha.upload(ha); corr.upload(hc);
   }
-  INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, nullptr));
+  const int64_t wsb = inc_w8a8_gemm_workspace_bytes(M, N, K);
+  DevBuf<char> ws((size_t)(wsb > 0 ? wsb : 16));
+  ws.zero();
+  DevBuf<uint16_t> y1((size_t)M * N);
+  INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y1.p, INC_BF16, M, N, K, nullptr, 0, nullptr));  // unsplit
+  INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, ws.p, wsb, nullptr));
+  INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, ws.p, wsb, nullptr));     // tickets re-armed
   HIPCHECK(hipDeviceSynchronize());
   const int check_rows = 16;
   std::vector<int> rows;
@@ -308,7 +314,8 @@ static int run_i8_case(int64_t M, int64_t N, int64_t K) {
   ref_i8_rows<<<dim3((unsigned)((N + 255) / 256), (unsigned)check_rows), 256>>>(xq.p, wq.p, drows.p, check_rows, N, K, ref.p);
   HIPCHECK(hipDeviceSynchronize());
   std::vector<int> href = ref.download();
-  std::vector<uint16_t> hy = y.download();
+  std::vector<uint16_t> hy = y.download(), hy1 = y1.download();
+  const bool split_same = memcmp(hy.data(), hy1.data(), hy.size() * 2) == 0;
   std::vector<float> ha = alpha.download();
   std::vector<int32_t> hc = corr.download();
   int64_t bad = 0;
@@ -317,15 +324,22 @@ static int run_i8_case(int64_t M, int64_t N, int64_t K) {
       const float want = ha[n] * (float)(href[(size_t)r * N + n] + hc[n]);
       if (hy[(size_t)rows[r] * N + n] != f2bf(want)) ++bad;
     }
+  if (!split_same) ++bad;
   Timer t;
-  for (int i = 0; i < 10; ++i) INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, nullptr));
-  std::vector<float> ms;
+  for (int i = 0; i < 10; ++i) INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, ws.p, wsb, nullptr));
+  std::vector<float> ms, ms1;
   for (int r = 0; r < 5; ++r) {
     t.start();
-    for (int i = 0; i < 8; ++i) INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, nullptr));
+    for (int i = 0; i < 8; ++i) INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, ws.p, wsb, nullptr));
     ms.push_back(t.stop_ms() / 8);
+    t.start();
+    for (int i = 0; i < 8; ++i) INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, corr.p, nullptr, y.p, INC_BF16, M, N, K, nullptr, 0, nullptr));
+    ms1.push_back(t.stop_ms() / 8);
   }
   std::sort(ms.begin(), ms.end());
+  std::sort(ms1.begin(), ms1.end());
+  printf("  tail split-K %s (workspace %ld B): unsplit median %8.4f ms, outputs %s\n", wsb > 0 ? "on" : "not needed", (long)wsb, ms1[2],
+         split_same ? "bit-identical" : "DIFFER");
   const double ops = 2.0 * M * N * K, bytes = (double)M * K + (double)N * K + 2.0 * M * N;
   printf("W8A8 GEMM M=%ld N=%ld K=%ld: %ld mismatching outputs in %d sampled rows  median %8.4f ms %8.1f TOP/s %7.1f GB/s  (best %8.4f ms %8.1f TOP/s)  %s\n",
          (long)M, (long)N, (long)K, (long)bad, check_rows, ms[2], ops / ms[2] / 1e9, bytes / ms[2] / 1e6, ms[0], ops / ms[0] / 1e9, bad ? "FAIL" : "OK");
@@ -575,11 +589,12 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> hx(x.n);
     for (auto& v : hx) v = f2bf(rnd_normal());
     x.upload(hx);
-    const int nv = 13, rounds = 5, iters = 8;
-    const int modes[nv] = {0, 20, 21, 22, 23, 24, 25, 26, 6, 31, 32, 34, 37};
+    const int nv = 17, rounds = 5, iters = 8;
+    const int modes[nv] = {0, 20, 21, 22, 23, 24, 25, 26, 6, 31, 32, 34, 37, 27, 28, 29, 30};
     const char* labels[nv] = {"full step", "- dequant arithmetic", "- ds_write of W", "- fragment reads", "- global loads + DMA", "- barrier",
                               "MFMA + barrier only", "MFMA only", "ping-pong full", "ping-pong - loads", "ping-pong - dequant/write",
-                              "ping-pong - frag reads", "ping-pong MFMA+barriers"};
+                              "ping-pong - frag reads", "ping-pong MFMA+barriers", "- vmcnt waits only", "loads of K-tile 0 only",
+                              "- the 6 W-side loads", "- the 4 x LDS-DMAs"};
     std::vector<std::vector<float>> ms(nv);
     Timer t;
     for (int i = 0; i < 10; ++i)
