@@ -28,6 +28,8 @@ import copy
 from collections import OrderedDict
 from functools import partial
 
+import os
+
 import torch
 
 from .... import ops
@@ -258,12 +260,14 @@ class _Loss:
         self.sum = torch.zeros(1, dtype=torch.float32, device=device)
         self.val = torch.zeros(1, dtype=torch.float32, device=device)
 
-    def add(self, a, b):
+    def add(self, a, b, n=1):
+        """`n`: how many equally sized calibration batches `a` / `b` hold (stacked along dim 0 by the batched search):
+        n * mean over the stack == the sum of the per-batch means."""
         a = a if a.is_contiguous() else a.contiguous()
         b = b if b.is_contiguous() else b.contiguous()
         self.sum.zero_()
         ops.mse_accumulate(a, b, out=self.sum)
-        self.val += self.sum / a.numel()
+        self.val += self.sum * (n / a.numel())
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -380,7 +384,8 @@ class ActAwareWeightQuant:
             x_max = _get_act_scale(input_val)
             org_w = {n: m.weight.detach().clone() for n, m in mods.items()}
             multi = len(module_tuple) > 1
-            org_out = self.block_inference(block) if multi else self.module_inference(mods[names[0]], input_val)
+            evaluate = (lambda: self._search_block_outputs(block)) if multi else (lambda: self._search_module_outputs(mods[names[0]], input_val))
+            org_out = evaluate()
             n_grid = 20
             losses, cand = [], []
             for step in range(n_grid):
@@ -395,9 +400,8 @@ class ActAwareWeightQuant:
                                       full_range=self.use_full_range)
                     m.weight.data = wq / scales.view(1, -1)
                 loss = _Loss(self.device)
-                cur_out = self.block_inference(block) if multi else self.module_inference(mods[names[0]], input_val)
-                for o1, o2 in zip(org_out, cur_out):
-                    loss.add(o1, o2)
+                for (o1, n1), (o2, _) in zip(org_out, evaluate()):
+                    loss.add(o1, o2, n1)
                 losses.append(loss.val)
                 cand.append(scales)
                 for n, m in mods.items():
@@ -441,7 +445,7 @@ class ActAwareWeightQuant:
                 logger.info("[CLIP] Processing module: %s", module_name)
                 module = fetch_module(self.model, module_name)
                 org_w = module.weight.detach().clone()
-                org_out = self.module_inference(module, input_val)
+                org_out = self._search_module_outputs(module, input_val)
                 n_grid, max_shrink = 100, 0.1
                 losses, ratios = [], []
                 for i_s in range(int(max_shrink * n_grid)):
@@ -454,8 +458,8 @@ class ActAwareWeightQuant:
                     else:
                         module.weight.data = wq
                     loss = _Loss(self.device)
-                    for o1, o2 in zip(org_out, self.module_inference(module, input_val)):
-                        loss.add(o1, o2)
+                    for (o1, n1), (o2, _) in zip(org_out, self._search_module_outputs(module, input_val)):
+                        loss.add(o1, o2, n1)
                     losses.append(loss.val)
                     ratios.append(ratio)
                     if isinstance(module, MulLinear):
@@ -497,6 +501,7 @@ class ActAwareWeightQuant:
 
     # -- forwards ------------------------------------------------------------------------------------------
     def update_block_input(self, input_list):
+        self._block_chunks = None  # the stacked copies used by the batched search belong to the previous block
         for i, inp in enumerate(input_list):
             if len(self.total_block_args[i]) > 0:
                 self.total_block_args[i][0] = inp
@@ -515,6 +520,91 @@ class ActAwareWeightQuant:
                 out = out[0]
             total_out.append(out)
         return total_out
+
+    # -- batched evaluation for the grid searches ----------------------------------------------------------------------
+    # The searches only compare losses, and a Linear (or a whole decoder block whose keyword arguments are the same for
+    # every calibration batch) treats the rows of a stacked input independently, so the ~20 forwards per grid are run on
+    # stacks of `search_batch` calibration batches (INC_MI355X_AWQ_SEARCH_BATCH, default 16; 1 = the reference's
+    # one-batch-at-a-time loop): larger GEMMs, 16x fewer launches, same sums.  The activations handed to the next block
+    # still come from the per-batch `block_inference`.
+    @property
+    def search_batch(self):
+        return max(1, int(os.environ.get("INC_MI355X_AWQ_SEARCH_BATCH", "16")))
+
+    def _stack(self, tensors):
+        B = self.search_batch
+        if B <= 1 or len(tensors) < 2 or any(t.shape != tensors[0].shape for t in tensors):
+            return [(t, 1) for t in tensors]
+        return [(torch.cat(tensors[i : i + B], dim=0), len(tensors[i : i + B])) for i in range(0, len(tensors), B)]
+
+    def _search_module_outputs(self, module, inputs):
+        cache = self.__dict__.setdefault("_module_chunks", {})
+        key = id(inputs)
+        if key not in cache or cache[key][0] is not inputs:
+            cache.clear()  # one input list at a time: the stacks of the previous module tuple are dropped
+            cache[key] = (inputs, self._stack(inputs))
+        outs = []
+        for x, n in cache[key][1]:
+            out = module(x)
+            outs.append((out[0] if isinstance(out, tuple) else out, n))
+        return outs
+
+    @staticmethod
+    def _same_kwargs(a, b):
+        if a.keys() != b.keys():
+            return False
+        for k in a:
+            va, vb = a[k], b[k]
+            if va is vb:
+                continue
+            if isinstance(va, torch.Tensor) and isinstance(vb, torch.Tensor):
+                if va.shape != vb.shape or not torch.equal(va, vb):
+                    return False
+            elif isinstance(va, (tuple, list)) and isinstance(vb, (tuple, list)) and len(va) == len(vb):
+                for xa, xb in zip(va, vb):
+                    if isinstance(xa, torch.Tensor) and isinstance(xb, torch.Tensor):
+                        if xa.shape != xb.shape or not torch.equal(xa, xb):
+                            return False
+                    elif xa != xb:
+                        return False
+            elif va != vb:
+                return False
+        return True
+
+    def _search_block_outputs(self, block):
+        chunks = getattr(self, "_block_chunks", None)
+        if chunks is None:
+            args0, kw0 = self.total_block_args[0], self.total_block_kwargs[0]
+            hidden_in_args = len(args0) > 0
+            get = (lambda a, k: a[0]) if hidden_in_args else (lambda a, k: k["hidden_states"])
+            stackable = self.search_batch > 1 and len(self.total_block_args) > 1 and all(
+                len(a) == len(args0) and get(a, k).shape == get(args0, kw0).shape and get(a, k).shape[0] == 1
+                and all(x is y or (isinstance(x, torch.Tensor) and isinstance(y, torch.Tensor) and x.shape == y.shape and torch.equal(x, y))
+                        for x, y in zip(a[1:], args0[1:]))
+                and self._same_kwargs({kk: v for kk, v in k.items() if kk != "hidden_states"},
+                                      {kk: v for kk, v in kw0.items() if kk != "hidden_states"})
+                for a, k in zip(self.total_block_args, self.total_block_kwargs))
+            if stackable:
+                hs = [get(a, k) for a, k in zip(self.total_block_args, self.total_block_kwargs)]
+                chunks = [("stack", x, n) for x, n in self._stack(hs)]
+            else:
+                chunks = [("single", i, 1) for i in range(len(self.total_block_args))]
+            self._block_chunks = chunks
+        outs = []
+        for kind, x, n in chunks:
+            if kind == "single":
+                args, kwargs = self.total_block_args[x], self.total_block_kwargs[x]
+            else:
+                args0, kw0 = self.total_block_args[0], self.total_block_kwargs[0]
+                if len(args0) > 0:
+                    args, kwargs = [x] + list(args0[1:]), kw0
+                else:
+                    args, kwargs = args0, dict(kw0, hidden_states=x)
+            if kwargs.get("layer_past", None) is not None:
+                kwargs["layer_past"] = None
+            out = block(*args, **kwargs)
+            outs.append((out[0] if isinstance(out, tuple) else out, n))
+        return outs
 
     def module_inference(self, model, inputs):
         total_out = []
