@@ -39,7 +39,7 @@ def main():
     import torch
     from neural_compressor.torch.quantization import GPTQConfig, RTNConfig, convert, prepare, quantize
 
-    from tests.model_zoo import calib_ids, tiny_llama
+    from tests.model_zoo import calib_ids, tiny_gptj, tiny_llama
 
     ids = calib_ids()
 
@@ -96,6 +96,26 @@ def main():
             out["logits_fp"] = tiny_llama()(ids[0]).logits.float().numpy()
         np.savez_compressed(os.path.join(HERE, f"awq_tiny_llama_{tag}.npz"), **out)
         print("awq", tag, "modules:", int(out["n_modules"]))
+
+    # GPT-J (the reference tests' own model family): GPTQ sym g32 and RTN asym g32
+    model = tiny_gptj()
+    model = prepare(model, GPTQConfig(model_path=tmp, bits=4, group_size=32, use_sym=True, block_size=128))
+    run_fn(model)
+    q = convert(model)
+    out = {}
+    dump_modules(q, out)
+    with torch.no_grad():
+        out["logits"] = q(ids[0]).logits.float().numpy()
+        out["logits_fp"] = tiny_gptj()(ids[0]).logits.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "gptq_tiny_gptj_sym_g32.npz"), **out)
+    print("gptj gptq modules:", int(out["n_modules"]))
+    q = quantize(tiny_gptj(), RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
+    out = {}
+    dump_modules(q, out)
+    with torch.no_grad():
+        out["logits"] = q(ids[0]).logits.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "rtn_tiny_gptj_asym_g32.npz"), **out)
+    print("gptj rtn modules:", int(out["n_modules"]))
 
     model = tiny_llama()
     q = quantize(model, RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))

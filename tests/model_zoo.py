@@ -59,6 +59,20 @@ def tiny_llama(seed=0, hidden=64, layers=2, heads=4, inter=128, vocab=128, dtype
     return model
 
 
+def tiny_gptj(seed=0, dtype=torch.float32):
+    """Random-init GPTJForCausalLM, the architecture of the reference tests' `tiny-random-GPTJForCausalLM`
+    (test/torch/quantization/weight_only/test_gptq.py:32-37): parallel attention / MLP behind ONE LayerNorm, partial rotary,
+    biased fc layers, lm_head with bias."""
+    from transformers import GPTJConfig, GPTJForCausalLM
+
+    cfg = GPTJConfig(n_embd=64, n_layer=2, n_head=4, rotary_dim=8, n_inner=128, vocab_size=128, n_positions=256,
+                     bos_token_id=1, eos_token_id=2, attn_implementation="eager")
+    torch.manual_seed(seed)
+    model = GPTJForCausalLM(cfg).to(dtype)
+    model.eval()
+    return model
+
+
 def calib_ids(n=8, seq=32, vocab=128, seed=1):
     g = torch.Generator().manual_seed(seed)
     return [torch.randint(0, vocab, (1, seq), generator=g) for _ in range(n)]

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.model_zoo import calib_ids, digest, opt125m_like, tiny_llama
+from tests.model_zoo import calib_ids, digest, opt125m_like, tiny_gptj, tiny_llama
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -57,6 +57,51 @@ def test_rtn_tiny_llama_bit_exact():
         y = q(calib_ids()[0].to("cuda")).logits.float().cpu()
     ref = torch.from_numpy(g["logits"])
     assert float((y - ref).norm() / ref.norm()) <= 1e-2
+
+
+def test_rtn_tiny_gptj_bit_exact():
+    """The reference tests' own model family (GPT-J: biased Linears, parallel attention / MLP): RTN buffers bit-identical."""
+    from neural_compressor_amd.torch.quantization import RTNConfig, quantize
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rtn_tiny_gptj_asym_g32.npz"))
+    q = quantize(tiny_gptj(), RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
+    mods = _woq_modules(q)
+    assert len(mods) == int(g["n_modules"]) == 12 and "lm_head" not in mods
+    for name, m in mods.items():
+        assert np.array_equal(m.qweight.cpu().numpy(), g[f"{name}.qweight"]), name
+        assert np.array_equal(m.qzeros.cpu().numpy(), g[f"{name}.qzeros"]), name
+        assert np.array_equal(m.scales.cpu().numpy().view(np.uint16), g[f"{name}.scales"].view(np.uint16)), name
+    assert any(m.bias is not None for m in mods.values())  # fc_in / fc_out carry their bias into the packed module
+    with torch.no_grad():
+        y = q(calib_ids()[0].to("cuda")).logits.float().cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert float((y - ref).norm() / ref.norm()) <= 1e-2
+
+
+def test_gptq_tiny_gptj_vs_reference():
+    """GPTQ on GPT-J (reference test_gptq.py:32-60 model): q/k/v and fc_in all read ln_1's output, so ONE Hessian serves
+    four Linears here; same module set and near-identical codes as the reference's CPU run."""
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gptq_tiny_gptj_sym_g32.npz"))
+    ids = calib_ids()
+    model = prepare(tiny_gptj(), GPTQConfig(bits=4, group_size=32, use_sym=True, block_size=128))
+    for x in ids:
+        model(x)
+    q = convert(model)
+    mods = _woq_modules(q)
+    assert len(mods) == int(g["n_modules"]) == 12
+    worst = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items())
+    first = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items() if ".h.0." in n)
+    assert first >= 0.98 and worst >= 0.90, (first, worst)
+    for n, m in mods.items():
+        s, rs = m.scales.float().cpu(), torch.from_numpy(g[f"{n}.scales"].astype(np.float32))
+        assert float((s - rs).norm() / rs.norm()) <= 2e-2, n
+    with torch.no_grad():
+        y = q(ids[0].to("cuda")).logits.float().cpu()
+    ref, fp = torch.from_numpy(g["logits"]), torch.from_numpy(g["logits_fp"])
+    assert float((y - ref).norm() / ref.norm()) <= 5e-2
+    assert float((y - fp).norm() / fp.norm()) <= 1.5 * float((ref - fp).norm() / fp.norm()) + 1e-3  # as close to float as the reference
 
 
 def _nibble_match(a, b):
