@@ -37,9 +37,11 @@ def main():
     _install_stubs()
     sys.path.insert(0, REF)
     import torch
+    import transformers  # noqa: F401  -- BEFORE the reference: its WOQ white list only includes transformers.Conv1D when
+    #                                      transformers is already in sys.modules (torch/utils/environ.py:44-49), as in user code
     from neural_compressor.torch.quantization import GPTQConfig, RTNConfig, convert, prepare, quantize
 
-    from tests.model_zoo import calib_ids, tiny_gptj, tiny_llama
+    from tests.model_zoo import calib_ids, tiny_gpt2, tiny_gptj, tiny_llama
 
     ids = calib_ids()
 
@@ -116,6 +118,17 @@ def main():
         out["logits"] = q(ids[0]).logits.float().numpy()
     np.savez_compressed(os.path.join(HERE, "rtn_tiny_gptj_asym_g32.npz"), **out)
     print("gptj rtn modules:", int(out["n_modules"]))
+
+    # GPT-2: transformers.Conv1D layers (weight stored [in, out]).  RTN only: the reference's GPTQ export crashes on a
+    # non-square Conv1D (`Q.t_()` leaves scale [out, G] against a [in, out] weight in quant_weight_w_scale, gptq.py:795-801:
+    # "The size of tensor a (64) must match the size of tensor b (4)"), so there is no reference output to pin GPTQ to.
+    q = quantize(tiny_gpt2(), RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
+    out = {}
+    dump_modules(q, out)
+    with torch.no_grad():
+        out["logits"] = q(ids[0]).logits.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "rtn_tiny_gpt2_asym_g32.npz"), **out)
+    print("gpt2 rtn modules:", int(out["n_modules"]))
 
     model = tiny_llama()
     q = quantize(model, RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))

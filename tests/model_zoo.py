@@ -73,6 +73,20 @@ def tiny_gptj(seed=0, dtype=torch.float32):
     return model
 
 
+def tiny_gpt2(seed=0, dtype=torch.float32):
+    """Random-init GPT2LMHeadModel: its projections are `transformers.Conv1D` (weight [in, out]), the second layer type
+    the reference's weight-only algorithms accept."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    cfg = GPT2Config(n_embd=64, n_layer=2, n_head=4, n_inner=128, vocab_size=128, n_positions=256, bos_token_id=1,
+                     eos_token_id=2, tie_word_embeddings=False, attn_implementation="eager",
+                     use_cache=False)  # the reference re-runs blocks with the captured kwargs: a live KV cache would grow
+    torch.manual_seed(seed)
+    model = GPT2LMHeadModel(cfg).to(dtype)
+    model.eval()
+    return model
+
+
 def calib_ids(n=8, seq=32, vocab=128, seed=1):
     g = torch.Generator().manual_seed(seed)
     return [torch.randint(0, vocab, (1, seq), generator=g) for _ in range(n)]

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.model_zoo import calib_ids, digest, opt125m_like, tiny_gptj, tiny_llama
+from tests.model_zoo import calib_ids, digest, opt125m_like, tiny_gpt2, tiny_gptj, tiny_llama
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -102,6 +102,59 @@ def test_gptq_tiny_gptj_vs_reference():
     ref, fp = torch.from_numpy(g["logits"]), torch.from_numpy(g["logits_fp"])
     assert float((y - ref).norm() / ref.norm()) <= 5e-2
     assert float((y - fp).norm() / fp.norm()) <= 1.5 * float((ref - fp).norm() / fp.norm()) + 1e-3  # as close to float as the reference
+
+
+def test_rtn_tiny_gpt2_conv1d_bit_exact():
+    """transformers.Conv1D layers (weight [in, out]; reference rtn.py:198-205 transposes): buffers bit-identical."""
+    from neural_compressor_amd.torch.quantization import RTNConfig, quantize
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rtn_tiny_gpt2_asym_g32.npz"))
+    q = quantize(tiny_gpt2(), RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
+    mods = _woq_modules(q)
+    assert len(mods) == int(g["n_modules"]) == 8
+    for name, m in mods.items():
+        assert np.array_equal(m.qweight.cpu().numpy(), g[f"{name}.qweight"]), name
+        assert np.array_equal(m.qzeros.cpu().numpy(), g[f"{name}.qzeros"]), name
+        assert np.array_equal(m.scales.cpu().numpy().view(np.uint16), g[f"{name}.scales"].view(np.uint16)), name
+    with torch.no_grad():
+        y = q(calib_ids()[0].to("cuda")).logits.float().cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert float((y - ref).norm() / ref.norm()) <= 1e-2
+
+
+def test_gptq_conv1d_layer_equals_the_transposed_linear(hip):
+    """GPTQ on a transformers.Conv1D (gptq.py:1103-1105, 1170-1172, 1327-1328 transpose in and out).  The reference's own
+    export crashes on a non-square Conv1D (see tests/golden/make_golden_models.py), so the pin is the oracle's fasterquant
+    on W^T plus agreement with the same solve run as an nn.Linear."""
+    import transformers
+
+    import oracle.woq_oracle as O
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import GPTQ
+
+    g = torch.Generator().manual_seed(3)
+    K, N = 128, 192
+    Wt = torch.randn(K, N, generator=g) * 0.05  # Conv1D stores [in, out]
+    conv = transformers.Conv1D(N, K).to(hip)
+    conv.weight.data.copy_(Wt)
+    lin = torch.nn.Linear(K, N, bias=False).to(hip)
+    lin.weight.data.copy_(Wt.T)
+    xs = [torch.randn(1, 48, K, generator=g) for _ in range(4)]
+    out = {}
+    for tag, layer in (("conv", conv), ("lin", lin)):
+        gq = GPTQ(layer, device=hip)
+        gq.configure(dict(bits=4, sym=True, dtype="int", mse=False))
+        for x in xs:
+            gq.add_batch(x.to(hip))
+        scale, _, zero, Q = gq.fasterquant(layer.weight.data, blocksize=128, percdamp=0.01, groupsize=32)
+        out[tag] = (scale.cpu(), Q.cpu(), gq.codes.cpu())
+    assert out["conv"][1].shape == (K, N) and torch.equal(out["conv"][1].T, out["lin"][1])
+    assert torch.equal(out["conv"][0], out["lin"][0]) and torch.equal(out["conv"][2], out["lin"][2])
+    H, n = torch.zeros(K, K), 0
+    for x in xs:
+        H, n = O.gptq_add_batch(H, n, x)
+    r = O.gptq_fasterquant(Wt.T.contiguous(), H, bits=4, sym=True, blocksize=128, percdamp=0.01, groupsize=32)
+    ints = O.gptq_export_ints(r["Q"], r["scale"], r["zero"], True, 32, None) + 8
+    assert float((out["conv"][2].to(torch.int32) == ints).float().mean()) >= 0.99
 
 
 def _nibble_match(a, b):
