@@ -42,6 +42,19 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert _lib.lib.inc_woq_gemm_workspace_bytes(4096, 4096, 4096) == 0
 
 
+def test_new_entry_points_validate_their_arguments():
+    from neural_compressor_amd import _lib
+
+    L = _lib.lib
+    assert L.inc_w8a8_gemm(None, None, None, None, None, None, 2, 1, 1, 128, None, 0, None) == -1           # null pointers
+    assert L.inc_w8a8_gemm_workspace_bytes(4096, 5120, 13824) > 0 and L.inc_w8a8_gemm_workspace_bytes(4096, 5120, 5120) == 0
+    assert L.inc_w8a8_gemm_workspace_bytes(8192, 8192, 8192) == 0 and L.inc_w8a8_gemm_workspace_bytes(64, 64, 100) == 0
+    assert L.inc_sq_quant_act(None, 2, 1, 16, 16, None, 1.0, 0.0, None, None) == -1
+    assert L.inc_sq_channel_minmax(None, 2, 1, 1, 1, None, None, None) == -1
+    assert L.inc_awq_repack(None, None, 8, 8, 1, 4, None, None, None) == -1
+    assert L.inc_gptq_find_params_mse(None, 1, 1, 0, 1, 1, 4, 1, 100, 0.8, 2.4, None, None, 1, 0, None) == -1
+
+
 def test_no_cpu_fallback():
     import pytest
     import torch
@@ -54,3 +67,9 @@ def test_no_cpu_fallback():
 
     with pytest.raises(RuntimeError, match="HIP device"):
         MI355XWeightOnlyLinear(8, 8, device="cpu")
+    from neural_compressor_amd.torch.algorithms.smooth_quant import W8A8Linear
+
+    with pytest.raises(RuntimeError, match="HIP device"):
+        W8A8Linear(128, 8, device="cpu")
+    with pytest.raises(RuntimeError, match="HBM"):
+        ops.sq_quant_act(torch.zeros(2, 16), None, 1.0, 0, 16)
