@@ -213,6 +213,8 @@ class W8A8Linear(torch.nn.Module):
         if self._sx is None:  # one host read at the first call: the static activation parameters are launch arguments
             self._sx, self._zp = float(self.act_scale.item()), float(self.act_zp.item())
         out_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else self.float_type
+        if x2d.shape[0] == 0:
+            return torch.empty((*lead, self.out_features), dtype=out_dtype, device=x.device)
         xq = ops.sq_quant_act(x2d, self.input_scale, self._sx, self._zp, self.kp)
         y = ops.w8a8_gemm(xq, self.qweight, self.alpha, self.corr, self.bias, out_dtype)
         return y.reshape(*lead, self.out_features)

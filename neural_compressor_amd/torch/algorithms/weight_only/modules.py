@@ -255,6 +255,8 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
             x = x.to(torch.float16)
         lead = x.shape[:-1]
         x2d = x.reshape(-1, self.in_features)
+        if x2d.shape[0] == 0:  # empty batch: nothing to launch (F.linear returns an empty tensor too)
+            return x2d.new_empty((*lead, self.out_features))
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
         plan = self._forward_plan()

@@ -160,6 +160,20 @@ def test_forward_with_act_order_g_idx_runs_fused(hip, bits, M, dt):
     assert rel_fro(ref2.cpu(), ref.cpu()) > 0.1  # the two layouts really are different matrices
 
 
+def test_empty_batch_forward(hip):
+    """A zero-row input returns a zero-row output (F.linear semantics) instead of reaching the kernels' M > 0 check."""
+    from neural_compressor_amd.torch.algorithms.smooth_quant import W8A8Linear
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    m = MI355XWeightOnlyLinear(128, 64, bits=4, group_size=32, device=hip)
+    y = m(torch.zeros(2, 0, 128, dtype=torch.bfloat16, device=hip))
+    assert tuple(y.shape) == (2, 0, 64) and y.dtype == torch.bfloat16
+    lin = torch.nn.Linear(128, 64, bias=False).to(hip).half()
+    q = W8A8Linear.from_float(lin, -torch.ones(128), torch.ones(128), device=hip)
+    y = q(torch.zeros(0, 128, dtype=torch.float16, device=hip))
+    assert tuple(y.shape) == (0, 64) and y.dtype == torch.float16
+
+
 def test_awq_checkpoint_repack(hip, golden):
     """K9: AutoAWQ words -> optimum layout, bit-exact against the reference's output (golden) and, at a Llama-2-7B
     layer size, against the oracle; then the repacked module's forward equals the AWQ dequantisation."""
