@@ -76,4 +76,9 @@ class SmoothQuantQuantizer(Quantizer):
         model.sq_info = {"alpha": first.get("alpha", 0.5), "folding": first.get("folding", False),
                          "absorb_to_layer": sq.absorb_to_layer}
         logger.info("Smooth quantization done.")
+        from types import MethodType
+
+        from .save_load import save
+
+        model.save = MethodType(save, model)  # reference smooth_quant.py:139-141
         return model

@@ -1,6 +1,8 @@
 """GPU: SmoothQuant W8A8 (BASELINE config #4) -- kernels K10-K14 against the oracle / the reference's golden outputs, the
 W8A8 module against the integer restatement, and the model-level flow (prepare -> calibrate -> convert)."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -196,3 +198,31 @@ def test_smooth_quant_tiny_llama_end_to_end(folding):
         y = q(ids[0].to("cuda")).logits.float()
     assert torch.isfinite(y).all()
     assert rel_fro(y, ref) <= 0.08, rel_fro(y, ref)
+
+
+def test_smooth_quant_save_load_roundtrip(tmp_path):
+    from neural_compressor_amd.torch.algorithms.smooth_quant import W8A8Linear, load
+    from neural_compressor_amd.torch.quantization import SmoothQuantConfig, convert, prepare
+
+    ids = calib_ids(n=4, seq=32)
+    cfg = SmoothQuantConfig(alpha=0.6, folding=True, scale_sharing=True)
+    cfg.set_local("lm_head", SmoothQuantConfig(w_dtype="fp32"))
+    model = prepare(tiny_llama(dtype=torch.float16), cfg, example_inputs=ids[0])
+    for x in ids:
+        model(x.to("cuda"))
+    q = convert(model)
+    with torch.no_grad():
+        y0 = q(ids[0].to("cuda")).logits
+    q.save(str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == ["qconfig.json", "quantized_weight.pt"]
+    r = load(str(tmp_path), tiny_llama(dtype=torch.float16))
+    a = {n: m for n, m in q.named_modules() if isinstance(m, W8A8Linear)}
+    b = {n: m for n, m in r.named_modules() if isinstance(m, W8A8Linear)}
+    assert a.keys() == b.keys() and len(a) == 14
+    for n in a:
+        for k, v in a[n].state_dict().items():
+            assert torch.equal(v, b[n].state_dict()[k]), (n, k)
+    with torch.no_grad():
+        y1 = r(ids[0].to("cuda")).logits
+    assert torch.equal(y0, y1)  # same integers, same folded norms, same kernels
+    assert r.sq_info["folding"] is True and abs(r.sq_info["alpha"] - 0.6) < 1e-12
