@@ -73,10 +73,19 @@ def allreduce_hessian(H, nsamples, group=None):
     """
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return H, nsamples
-    n = torch.tensor([float(nsamples)], dtype=torch.float64, device=H.device)
     H.mul_(float(nsamples))  # back to (2 * sum X^T X) so that ranks can be added
-    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(H, op=dist.ReduceOp.SUM, group=group)
+    if H.is_cuda and dist.get_backend(group) == "gloo":
+        # CPU-side collective (tests on a single-GPU box: two processes share one MI355X, gloo between them); the
+        # production backend is "nccl" = RCCL, which reduces the HBM-resident tensor in place over xGMI
+        n = torch.tensor([float(nsamples)], dtype=torch.float64)
+        host = H.cpu()
+        dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        H.copy_(host)
+    else:
+        n = torch.tensor([float(nsamples)], dtype=torch.float64, device=H.device)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(H, op=dist.ReduceOp.SUM, group=group)
     total = int(round(float(n.item())))
     if total > 0:
         H.div_(float(total))

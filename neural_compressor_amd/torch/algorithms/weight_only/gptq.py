@@ -196,6 +196,18 @@ class HessianAccumulator:
         if self._fill >= self.STAGE_TOKENS:
             self.flush()
 
+    def allreduce(self, group=None):
+        """Sample-sharded calibration (neural_compressor_amd/distributed.py, mode "sample"): fold what is staged, then
+        combine the per-rank running means into the global one -- H = sum_r (n_r / n) H_r -- over RCCL.  Every rank ends
+        up with the same H and the same sample count, so the factorisation and the column loop that follow are identical
+        on all ranks."""
+        from ....distributed import allreduce_hessian
+
+        self.flush()
+        if self.H is None:  # this rank saw no batch for the layer
+            self.H = torch.zeros((self.columns, self.columns), dtype=torch.float32, device=self.device)
+        self.H, self._n = allreduce_hessian(self.H, self._n, group=group)
+
     def flush(self):
         if self._pending == 0:
             return
@@ -384,6 +396,13 @@ class RAWGPTQuantizer(object):
         self.nsamples = nsamples
         self.share_hessians = kwargs.get("share_hessians", True)
         self.block_callback = kwargs.get("block_callback", None)  # used by the multi-GPU driver
+        # sample-sharded multi-GPU calibration: every rank feeds ITS calibration samples through prepare()/run_fn and the
+        # per-layer Hessians are all-reduced before each solve; pass True (default process group) or a process group
+        self.hessian_allreduce = kwargs.get("hessian_allreduce", None)
+        if self.hessian_allreduce is None and os.environ.get("INC_MI355X_GPTQ_SAMPLE_SHARDED", "0") == "1":
+            import torch.distributed as dist
+
+            self.hessian_allreduce = bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
     # -- config handling (reference :330-398) --------------------------------------------------------
     _DEFAULTS = dict(
@@ -671,6 +690,14 @@ class RAWGPTQuantizer(object):
                     solvers[name].acc = solvers[owner].acc
                 else:  # pragma: no cover - different damping per layer: cannot share the factorisation
                     raise RuntimeError(f"{name} shares its input with {owner} but not its GPTQ settings; pass share_hessians=False")
+            if self.hessian_allreduce:
+                group = None if self.hessian_allreduce is True else self.hessian_allreduce
+                done = set()
+                for name in layers:  # same order on every rank: one all-reduce per DISTINCT accumulator
+                    acc = solvers[name].acc
+                    if id(acc) not in done:
+                        done.add(id(acc))
+                        acc.allreduce(group)
             # Step 2.4: solve (reference :690-747).  The column loop treats every weight ROW independently, so Linears
             # that share one Hessian (q/k/v, gate/up) and one GPTQ setting are stacked along N and solved in ONE pass:
             # a third of the serial 128-column steps and three times the rows in flight per step, same results.
@@ -756,7 +783,7 @@ class GPTQuantizer(INCQuantizer):
             model, weight_config=self.quant_config, nsamples=nsamples, use_max_length=use_max_length,
             max_seq_length=max_seq_length, device=device, use_layer_wise=use_layer_wise, model_path=model_path,
             quant_lm_head=quant_lm_head, use_block_wise=use_block_wise,
-            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback")},
+            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback", "hessian_allreduce")},
         )
         self.gptq_quantizer.prepare_for_calibration()
         return self.gptq_quantizer.model

@@ -469,3 +469,55 @@ def test_save_load_default_awq_keeps_mul_linear(tmp_path):
         assert torch.equal(muls0[n], muls1[n])
     for (n0, p0), (n1, p1) in zip(sorted(q.state_dict().items()), sorted(r.state_dict().items())):
         assert n0 == n1 and torch.equal(p0.cpu(), p1.cpu()), n0
+
+
+def _sample_sharded_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      INC_MI355X_GPTQ_SAMPLE_SHARDED="1")
+    import torch.distributed as dist
+
+    from neural_compressor_amd import distributed as D
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    torch.cuda.set_device(0)
+    D.init_from_env(backend="gloo")
+    ids = calib_ids()
+    mine = D.shard_samples(len(ids), rank, world)
+    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, use_sym=True, block_size=128))
+    for j in mine:
+        model(ids[j])
+    q = convert(model)
+    out[rank] = {n: m.qweight.cpu() for n, m in _woq_modules(q).items()}
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gptq_sample_sharded_two_ranks_equals_single_process():
+    """Multi-GPU mode "sample" (distributed.py): two processes (here sharing the one MI355X, gloo between them) each
+    calibrate on half of the samples, all-reduce every Hessian and must produce the SAME packed model, which in turn
+    matches the single-process run on all samples up to fp32 summation order in the Hessian."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_sample_sharded_worker, args=(2, port, out), nprocs=2, join=True)
+        res = {r: dict(v) for r, v in out.items()}
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 14
+    for n in res[0]:
+        assert torch.equal(res[0][n], res[1][n]), n  # identical H after the all-reduce -> identical solve on every rank
+    ids = calib_ids()
+    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, use_sym=True, block_size=128))
+    for x in ids:
+        model(x)
+    single = {n: m.qweight.cpu() for n, m in _woq_modules(convert(model)).items()}
+    first = min(_nibble_match(res[0][n].numpy(), single[n].numpy()) for n in single if ".layers.0." in n)
+    worst = min(_nibble_match(res[0][n].numpy(), single[n].numpy()) for n in single)
+    assert first >= 0.99 and worst >= 0.95, (first, worst)
