@@ -16,8 +16,13 @@ __all__ = ["PostTrainingQuantConfig"]
 
 class PostTrainingQuantConfig:
     def __init__(self, approach="weight_only", op_type_dict=None, op_name_dict=None, recipes=None, **kwargs):
-        if approach != "weight_only":
-            raise NotImplementedError(f"approach={approach!r}: only 'weight_only' is in the MI355X hot-path scope (SURVEY.md section 8)")
+        recipes = recipes or {}
+        # 2.x SmoothQuant: approach "static" (the default there) + recipes={"smooth_quant": True, "smooth_quant_args": {...}}
+        # (reference docs/source/smooth_quant.md); plain static INT8 without smoothing is IPEX / PT2E territory
+        self.smooth_quant = bool(recipes.get("smooth_quant", False))
+        if approach != "weight_only" and not (approach in ("static", "post_training_static_quant") and self.smooth_quant):
+            raise NotImplementedError(f"approach={approach!r}: only 'weight_only' and 'static' with recipes['smooth_quant'] are in the "
+                                      "MI355X hot-path scope (SURVEY.md section 8)")
         self.approach = approach
         self.op_type_dict = op_type_dict or {".*": {"weight": {"bits": 4, "group_size": 32, "scheme": "sym", "algorithm": "RTN"}}}
         self.op_name_dict = op_name_dict or {}
@@ -54,6 +59,16 @@ class PostTrainingQuantConfig:
 
     def to_3x(self):
         """Global config from the '.*' (or first) op_type entry; op_name_dict entries become name-local configs."""
+        if self.smooth_quant and self.approach != "weight_only":
+            from .torch.quantization import SmoothQuantConfig
+
+            a = self.recipes.get("smooth_quant_args", {})
+            cfg = SmoothQuantConfig(alpha=a.get("alpha", 0.5), folding=bool(a.get("folding", False)),
+                                    scale_sharing=bool(a.get("scale_sharing", False)))
+            for pattern, entry in self.op_name_dict.items():
+                if entry.get("weight", {}).get("dtype") == "fp32" or entry.get("activation", {}).get("dtype") == "fp32":
+                    cfg.set_local(pattern, SmoothQuantConfig(w_dtype="fp32"))
+            return cfg
         entries = dict(self.op_type_dict)
         base_entry = entries.pop(".*", None) or next(iter(entries.values()))
         cfg = self._one(base_entry)

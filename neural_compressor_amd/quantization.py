@@ -9,7 +9,7 @@ __all__ = ["fit"]
 
 
 def fit(model, conf, calib_dataloader=None, calib_func=None, eval_func=None, eval_dataloader=None, eval_metric=None, **kwargs):
-    """Weight-only post-training quantisation with the 2.x call shape.
+    """Weight-only (and SmoothQuant W8A8) post-training quantisation with the 2.x call shape.
 
     `calib_dataloader` yields model inputs (a tensor, a dict of keyword tensors, or an `(inputs, labels)` pair);
     `calib_func(model)` may be given instead.  Accuracy-driven tuning (`eval_func` & co.) belongs to the 2.x strategy
@@ -31,11 +31,11 @@ def fit(model, conf, calib_dataloader=None, calib_func=None, eval_func=None, eva
             else:
                 m(batch)
 
-    needs_calib = cfg.name in ("gptq", "awq")
+    needs_calib = cfg.name in ("gptq", "awq", "smooth_quant")
     if needs_calib and calib_dataloader is None and calib_func is None:
         raise ValueError(f"{cfg.name.upper()} needs calibration data: pass calib_dataloader or calib_func")
     example = None
-    if cfg.name == "awq":
+    if cfg.name in ("awq", "smooth_quant"):
         example = kwargs.get("example_inputs")
         if example is None and calib_dataloader is not None:
             first = next(iter(calib_dataloader))

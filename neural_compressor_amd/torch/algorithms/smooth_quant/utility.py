@@ -175,7 +175,7 @@ class W8A8Linear(torch.nn.Module):
         self.register_buffer("act_zp", torch.zeros(1, dtype=torch.int32, device=dev))
         self.register_buffer("input_scale", torch.ones(in_features, dtype=torch.float32, device=dev) if has_input_scale else None)
         self.register_buffer("bias", torch.zeros(out_features, dtype=float_type, device=dev) if bias else None)
-        self._sx = self._zp = None
+        self._sx = self._zp = self._ver = None
 
     @classmethod
     @torch.no_grad()
@@ -210,8 +210,9 @@ class W8A8Linear(torch.nn.Module):
         x = input
         lead = x.shape[:-1]
         x2d = x.reshape(-1, self.in_features)
-        if self._sx is None:  # one host read at the first call: the static activation parameters are launch arguments
-            self._sx, self._zp = float(self.act_scale.item()), float(self.act_zp.item())
+        ver = (self.act_scale.data_ptr(), self.act_scale._version, self.act_zp._version)
+        if self._sx is None or self._ver != ver:  # one host read per (re)load: the static activation parameters are launch arguments
+            self._sx, self._zp, self._ver = float(self.act_scale.item()), float(self.act_zp.item()), ver
         out_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else self.float_type
         if x2d.shape[0] == 0:
             return torch.empty((*lead, self.out_features), dtype=out_dtype, device=x.device)

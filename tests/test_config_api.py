@@ -163,3 +163,17 @@ def test_front_end_configs_roundtrip(tmp_path):
     assert extra.version == "gemm" and extra.group_size == 128
     unused = r.update(bits=8, not_a_field=1)
     assert r.bits == 8 and unused == {"not_a_field": 1}
+
+
+def test_2x_shim_maps_the_smooth_quant_recipe():
+    from neural_compressor_amd.config import PostTrainingQuantConfig
+
+    conf = PostTrainingQuantConfig(approach="static", recipes={"smooth_quant": True, "smooth_quant_args": {"alpha": 0.7, "folding": True}},
+                                   op_name_dict={"lm_head": {"weight": {"dtype": "fp32"}, "activation": {"dtype": "fp32"}}})
+    cfg = conf.to_3x()
+    assert cfg.name == "smooth_quant" and cfg.alpha == 0.7 and cfg.folding is True
+    model = build_simple_torch_model()
+    mapping = cfg.to_config_mapping(model_info=cfg.get_model_info(model))
+    assert all(c.name == "smooth_quant" for c in mapping.values())
+    with pytest.raises(NotImplementedError):
+        PostTrainingQuantConfig(approach="static")  # plain static INT8 is out of scope
