@@ -225,6 +225,90 @@ __global__ __launch_bounds__(512) void w8a8_gemm_kernel(const int8_t* __restrict
   }
 }
 
+// ---- M <= 16 (decode): HBM-bound on the int8 weights, v_dot4_i32_i8 on the vector ALUs -------------------------------------
+// A wave streams GV_ROWS weight rows at a time, 16 bytes per lane per row per iteration (1 KiB contiguous per row: full
+// lines); the activations of the current K chunk (M x 4 KiB) sit in LDS and are read once per iteration for all rows
+// (one ds_read_b128 per activation row).  int32 partial sums stay in registers, a xor-butterfly folds the 64 lanes at
+// the end.  Algorithmic bytes: N*K (weights once) + M*K + 2*M*N.
+constexpr int GV_ROWS = 4;     // weight rows per wave
+constexpr int GV_KC = 4096;    // bytes of K staged in LDS per chunk
+constexpr int GV_MAXM = 16;
+
+template <bool IS_BF16, int MT>
+__global__ __launch_bounds__(256) void w8a8_gemv_kernel(const int8_t* __restrict__ xq, const int8_t* __restrict__ wq,
+                                                        const float* __restrict__ alpha, const int32_t* __restrict__ corr,
+                                                        const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int M,
+                                                        int64_t N, int64_t K) {
+  __shared__ __attribute__((aligned(16))) int8_t xs[MT * GV_KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * GV_ROWS;
+  const int8_t* wrow[GV_ROWS];
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r) {
+    int64_t n = n0 + r;
+    if (n > N - 1) n = N - 1;
+    wrow[r] = wq + n * K;
+  }
+  int acc[GV_ROWS][MT];
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[r][m] = 0;
+
+  for (int64_t kc = 0; kc < K; kc += GV_KC) {
+    const int len = (int)((K - kc) < GV_KC ? (K - kc) : GV_KC);  // multiple of 16
+    __syncthreads();
+    for (int i = tid; i < MT * (len / 16); i += 256) {
+      const int m = i / (len / 16), c = i - m * (len / 16);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (m < M) v = *reinterpret_cast<const uint4*>(xq + (int64_t)m * K + kc + 16 * c);
+      *reinterpret_cast<uint4*>(xs + m * GV_KC + 16 * c) = v;
+    }
+    __syncthreads();
+    for (int k0 = lane * 16; k0 < len; k0 += 1024) {
+      uint4 w[GV_ROWS];
+#pragma unroll
+      for (int r = 0; r < GV_ROWS; ++r) {
+        const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wrow[r] + kc + k0));  // streamed once
+        w[r] = make_uint4((uint32_t)t[0], (uint32_t)t[1], (uint32_t)t[2], (uint32_t)t[3]);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(xs + m * GV_KC + k0);
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r) {
+          int a = acc[r][m];
+          a = __builtin_amdgcn_sdot4((int)w[r].x, (int)xv.x, a, false);
+          a = __builtin_amdgcn_sdot4((int)w[r].y, (int)xv.y, a, false);
+          a = __builtin_amdgcn_sdot4((int)w[r].z, (int)xv.z, a, false);
+          a = __builtin_amdgcn_sdot4((int)w[r].w, (int)xv.w, a, false);
+          acc[r][m] = a;
+        }
+      }
+    }
+  }
+  // fold the 64 lanes; afterwards every lane holds every sum and lane (r * MT + m) stores y[m, n0 + r]
+  int mine = 0;
+#pragma unroll
+  for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      int v = acc[r][m];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == r * MT + m) mine = v;
+    }
+  if (lane < GV_ROWS * MT) {
+    const int r = lane / MT, m = lane - r * MT;
+    const int64_t n = n0 + r;
+    if (n < N && m < M) {
+      float v = alpha[n] * (float)(mine + (corr ? corr[n] : 0));
+      if (bias) v += IS_BF16 ? bf16_bits_to_f32(bias[n]) : f16_bits_to_f32(bias[n]);
+      y[(int64_t)m * N + n] = IS_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+    }
+  }
+}
+
 // tail tiles: sum the `split` slabs of a tile (same register-order layout: thread tid of the tile's workgroup owns element
 // ((nf*4+mf)*16 + r)*512 + tid) and run the GEMM's epilogue.  One workgroup of 512 threads per tail tile.
 template <bool IS_BF16>
@@ -282,7 +366,7 @@ __global__ __launch_bounds__(512) void w8a8_tail_finish_kernel(const int* __rest
 extern "C" {
 
 int64_t inc_w8a8_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M <= 0 || N <= 0 || K <= 0 || (K % IK) != 0) return 0;
+  if (M <= GV_MAXM || N <= 0 || K <= 0 || (K % IK) != 0) return 0;
   const int64_t tiles = ceil_div64(M, IM) * ceil_div64(N, IN);
   int64_t full;
   const int split = i8_tail_plan(tiles, (int)(K / IK), &full);
@@ -304,6 +388,18 @@ int inc_w8a8_gemm(const int8_t* xq, const int8_t* wq, const float* alpha, const 
     (void)hipFuncSetAttribute((const void*)w8a8_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)w8a8_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
+  }
+  if (M <= GV_MAXM) {  // decode: stream the weights once, dot products on the vector ALUs
+    const unsigned g = (unsigned)ceil_div64(N, 4 * GV_ROWS);
+    hipStream_t sv = inc_s(stream);
+    const bool bf = ydtype == INC_BF16;
+#define INC_GV(B, MT) w8a8_gemv_kernel<B, MT><<<g, 256, 0, sv>>>(xq, wq, alpha, corr, (const uint16_t*)bias, (uint16_t*)y, (int)M, N, K)
+    if (M == 1) { if (bf) INC_GV(true, 1); else INC_GV(false, 1); }
+    else if (M <= 4) { if (bf) INC_GV(true, 4); else INC_GV(false, 4); }
+    else if (M <= 8) { if (bf) INC_GV(true, 8); else INC_GV(false, 8); }
+    else { if (bf) INC_GV(true, 16); else INC_GV(false, 16); }
+#undef INC_GV
+    INC_LAUNCH_RETURN();
   }
   const int64_t tiles = ceil_div64(M, IM) * ceil_div64(N, IN);
   int64_t full = tiles;

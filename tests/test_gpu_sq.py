@@ -85,6 +85,8 @@ def test_quant_act_bit_exact(hip, golden, dt):
 
 
 @pytest.mark.parametrize("M,N,K,dt", [(256, 256, 128, torch.bfloat16), (300, 1000, 384, torch.float16), (1, 512, 256, torch.bfloat16),
+                                      (1, 5120, 5120, torch.float16), (3, 1001, 4224, torch.bfloat16), (8, 13824, 5120, torch.bfloat16),
+                                      (16, 5120, 13824, torch.float16), (17, 640, 256, torch.bfloat16),
                                       (2048, 5120, 5120, torch.bfloat16), (4096, 4096, 11008, torch.float16)])
 def test_w8a8_gemm_integer_exact(hip, M, N, K, dt):
     """int32 accumulation is exact: y == alpha * (xq @ wq^T + corr) + bias rounded once to the output dtype."""

@@ -534,6 +534,8 @@ int main(int argc, char** argv) {
   }
   if (what == "i8gemm" || what == "all") {
     fails += run_i8_case(300, 1000, 384);
+    fails += run_i8_case(1, 5120, 5120);        // decode
+    fails += run_i8_case(16, 13824, 5120);
     fails += run_i8_case(4096, 5120, 5120);     // Llama-2-13B q/k/v/o
     fails += run_i8_case(4096, 13824, 5120);    // gate / up
     fails += run_i8_case(4096, 5120, 13824);    // down
