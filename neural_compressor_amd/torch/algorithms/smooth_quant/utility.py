@@ -215,9 +215,11 @@ class W8A8Linear(torch.nn.Module):
             self._sx, self._zp, self._ver = float(self.act_scale.item()), float(self.act_zp.item()), ver
         out_dtype = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else self.float_type
         if x2d.shape[0] == 0:
-            return torch.empty((*lead, self.out_features), dtype=out_dtype, device=x.device)
+            return torch.empty((*lead, self.out_features), dtype=torch.float32 if x.dtype == torch.float32 else out_dtype, device=x.device)
         xq = ops.sq_quant_act(x2d, self.input_scale, self._sx, self._zp, self.kp)
         y = ops.w8a8_gemm(xq, self.qweight, self.alpha, self.corr, self.bias, out_dtype)
+        if x.dtype == torch.float32:  # an fp32 model keeps seeing fp32 activations (the kernel's epilogue emits 16-bit)
+            y = y.float()
         return y.reshape(*lead, self.out_features)
 
     def recover(self):
