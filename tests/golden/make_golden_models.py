@@ -119,6 +119,27 @@ def main():
     np.savez_compressed(os.path.join(HERE, "rtn_tiny_gptj_asym_g32.npz"), **out)
     print("gptj rtn modules:", int(out["n_modules"]))
 
+    # AWQ on GPT-J with the reference's DEFAULT absorb discovery (its torch.jit trace works on this architecture):
+    # ln_1 folds q/k/v/fc_in, out_proj and fc_out get a MulLinear
+    model = tiny_gptj()
+    model.config.use_cache = False
+    model = prepare(model, AWQConfig(bits=4, group_size=32, use_sym=False, use_auto_scale=True, use_auto_clip=True), example_inputs=ids[0])
+    run_fn(model)
+    q = convert(model)
+    out = {}
+    dump_modules(q, out)
+    for name, mod in q.named_modules():
+        if type(mod).__name__ == "MulLinear":
+            out[f"{name}.input_scale"] = mod.input_scale.float().numpy()
+        if type(mod).__name__ == "LayerNorm":
+            out[f"{name}.weight"] = mod.weight.detach().float().numpy()
+            out[f"{name}.bias"] = mod.bias.detach().float().numpy()
+    with torch.no_grad():
+        out["logits"] = q(ids[0]).logits.float().numpy()
+        out["logits_fp"] = tiny_gptj()(ids[0]).logits.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "awq_tiny_gptj_default.npz"), **out)
+    print("awq gptj modules:", int(out["n_modules"]))
+
     # GPT-2: transformers.Conv1D layers (weight stored [in, out]).  RTN only: the reference's GPTQ export crashes on a
     # non-square Conv1D (`Q.t_()` leaves scale [out, G] against a [in, out] weight in quant_weight_w_scale, gptq.py:795-801:
     # "The size of tensor a (64) must match the size of tensor b (4)"), so there is no reference output to pin GPTQ to.

@@ -379,6 +379,44 @@ def test_awq_tiny_llama_vs_reference(tag):
     assert np.linalg.norm(y - g["logits"]) / np.linalg.norm(g["logits"]) <= 0.1
 
 
+def test_awq_tiny_gptj_default_discovery_vs_reference():
+    """GPT-J is the architecture on which the reference's torch.jit-trace discovery works: WITHOUT an absorb dict both
+    implementations must arrive at the same structure (ln_1 folds q/k/v/fc_in; out_proj and fc_out get a MulLinear),
+    near-identical searched scales and an equally good quantised model."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MulLinear
+    from neural_compressor_amd.torch.quantization import AWQConfig, convert, prepare
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "awq_tiny_gptj_default.npz"))
+    ids = calib_ids()
+    model = tiny_gptj()
+    model.config.use_cache = False
+    model = prepare(model, AWQConfig(bits=4, group_size=32, use_sym=False, use_auto_scale=True, use_auto_clip=True), example_inputs=ids[0])
+    for x in ids:
+        model(x)
+    q = convert(model)
+    mods = _woq_modules(q)
+    assert len(mods) == int(g["n_modules"]) == 12
+    ref_mul = sorted(k[: -len(".input_scale")] for k in g.files if k.endswith(".input_scale"))
+    our_mul = sorted(n for n, m in q.named_modules() if isinstance(m, MulLinear))
+    assert our_mul == ref_mul == sorted(f"transformer.h.{i}.{n}" for i in (0, 1) for n in ("attn.out_proj", "mlp.fc_out"))
+    named = dict(q.named_modules())
+    close = 0
+    for name in ref_mul:
+        ours = named[name].input_scale.float().cpu().numpy()
+        close += int(np.linalg.norm(ours - g[f"{name}.input_scale"]) / np.linalg.norm(g[f"{name}.input_scale"]) <= 1e-3)
+    norms = [k[: -len(".weight")] for k in g.files if k.endswith("ln_1.weight")]
+    for k in norms:  # the folded LayerNorm carries 1/scale in weight AND bias
+        w = named[k].weight.detach().float().cpu().numpy()
+        close += int(np.linalg.norm(w - g[f"{k}.weight"]) / np.linalg.norm(g[f"{k}.weight"]) <= 1e-3)
+    assert close >= 0.6 * (len(ref_mul) + len(norms)), close  # argmin over a 20-point grid: neighbours may swap
+    with torch.no_grad():
+        y = _to_half(q)(ids[0].to("cuda")).logits.float().cpu()
+    ref, fp = torch.from_numpy(g["logits"]), torch.from_numpy(g["logits_fp"])
+    ours_err = float((y - fp).norm() / fp.norm())
+    ref_err = float((ref - fp).norm() / fp.norm())
+    assert ours_err <= 1.25 * ref_err + 2e-3, (ours_err, ref_err)
+
+
 def test_awq_absorb_discovery_without_tracing():
     """The hook-based producer search + numeric fold check finds what the reference's GraphTrace is meant to find on
     Llama: the two RMSNorms absorb q/k/v and gate/up; o_proj and down_proj have no absorber."""
