@@ -41,7 +41,7 @@ def main():
     #                                      transformers is already in sys.modules (torch/utils/environ.py:44-49), as in user code
     from neural_compressor.torch.quantization import GPTQConfig, RTNConfig, convert, prepare, quantize
 
-    from tests.model_zoo import calib_ids, tiny_gpt2, tiny_gptj, tiny_llama
+    from tests.model_zoo import calib_ids, tiny_gpt2, tiny_gptj, tiny_llama, tiny_opt
 
     ids = calib_ids()
 
@@ -139,6 +139,25 @@ def main():
         out["logits_fp"] = tiny_gptj()(ids[0]).logits.float().numpy()
     np.savez_compressed(os.path.join(HERE, "awq_tiny_gptj_default.npz"), **out)
     print("awq gptj modules:", int(out["n_modules"]))
+
+    # OPT (BASELINE config #1's architecture): RTN INT8 per-channel (config #1's algorithm) and GPTQ INT4
+    q = quantize(tiny_opt(), RTNConfig(bits=8, group_size=-1, use_layer_wise=False))
+    out = {}
+    dump_modules(q, out)
+    with torch.no_grad():
+        out["logits"] = q(ids[0]).logits.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "rtn_tiny_opt_int8_pc.npz"), **out)
+    print("opt rtn modules:", int(out["n_modules"]))
+    model = prepare(tiny_opt(), GPTQConfig(model_path=tmp, bits=4, group_size=32, use_sym=False, block_size=128))
+    run_fn(model)
+    q = convert(model)
+    out = {}
+    dump_modules(q, out)
+    with torch.no_grad():
+        out["logits"] = q(ids[0]).logits.float().numpy()
+        out["logits_fp"] = tiny_opt()(ids[0]).logits.float().numpy()
+    np.savez_compressed(os.path.join(HERE, "gptq_tiny_opt_asym_g32.npz"), **out)
+    print("opt gptq modules:", int(out["n_modules"]))
 
     # GPT-2: transformers.Conv1D layers (weight stored [in, out]).  RTN only: the reference's GPTQ export crashes on a
     # non-square Conv1D (`Q.t_()` leaves scale [out, G] against a [in, out] weight in quant_weight_w_scale, gptq.py:795-801:

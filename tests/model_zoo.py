@@ -87,6 +87,20 @@ def tiny_gpt2(seed=0, dtype=torch.float32):
     return model
 
 
+def tiny_opt(seed=0, dtype=torch.float32):
+    """Random-init OPTForCausalLM: the architecture of BASELINE config #1 (OPT-125M): biased q/k/v/out_proj and fc1/fc2,
+    LayerNorm with bias, ReLU, learned positions; `model.decoder.layers` is the transformer stack."""
+    from transformers import OPTConfig, OPTForCausalLM
+
+    cfg = OPTConfig(hidden_size=64, ffn_dim=128, num_hidden_layers=2, num_attention_heads=4, vocab_size=128,
+                    max_position_embeddings=256, word_embed_proj_dim=64, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                    attn_implementation="eager", use_cache=False)
+    torch.manual_seed(seed)
+    model = OPTForCausalLM(cfg).to(dtype)
+    model.eval()
+    return model
+
+
 def calib_ids(n=8, seq=32, vocab=128, seed=1):
     g = torch.Generator().manual_seed(seed)
     return [torch.randint(0, vocab, (1, seq), generator=g) for _ in range(n)]

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.model_zoo import calib_ids, digest, opt125m_like, tiny_gpt2, tiny_gptj, tiny_llama
+from tests.model_zoo import calib_ids, digest, opt125m_like, tiny_gpt2, tiny_gptj, tiny_llama, tiny_opt
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -102,6 +102,46 @@ def test_gptq_tiny_gptj_vs_reference():
     ref, fp = torch.from_numpy(g["logits"]), torch.from_numpy(g["logits_fp"])
     assert float((y - ref).norm() / ref.norm()) <= 5e-2
     assert float((y - fp).norm() / fp.norm()) <= 1.5 * float((ref - fp).norm() / fp.norm()) + 1e-3  # as close to float as the reference
+
+
+def test_rtn_int8_per_channel_tiny_opt_bit_exact():
+    """BASELINE config #1's algorithm (RTN INT8 per-channel) on the real OPT architecture (HF OPTForCausalLM, biased
+    projections): every packed buffer bit-identical to the reference's CPU adaptor."""
+    from neural_compressor_amd.torch.quantization import RTNConfig, quantize
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rtn_tiny_opt_int8_pc.npz"))
+    q = quantize(tiny_opt(), RTNConfig(bits=8, group_size=-1, use_layer_wise=False))
+    mods = _woq_modules(q)
+    assert len(mods) == int(g["n_modules"]) == 12
+    for name, m in mods.items():
+        assert np.array_equal(m.qweight.cpu().numpy(), g[f"{name}.qweight"]), name
+        assert np.array_equal(m.qzeros.cpu().numpy(), g[f"{name}.qzeros"]), name
+        assert np.array_equal(m.scales.cpu().numpy().view(np.uint16), g[f"{name}.scales"].view(np.uint16)), name
+    with torch.no_grad():
+        y = q(calib_ids()[0].to("cuda")).logits.float().cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert float((y - ref).norm() / ref.norm()) <= 5e-3
+
+
+def test_gptq_tiny_opt_vs_reference():
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gptq_tiny_opt_asym_g32.npz"))
+    ids = calib_ids()
+    model = prepare(tiny_opt(), GPTQConfig(bits=4, group_size=32, use_sym=False, block_size=128))
+    for x in ids:
+        model(x)
+    q = convert(model)
+    mods = _woq_modules(q)
+    assert len(mods) == int(g["n_modules"]) == 12
+    first = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items() if ".layers.0." in n)
+    worst = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items())
+    assert first >= 0.98 and worst >= 0.90, (first, worst)
+    with torch.no_grad():
+        y = q(ids[0].to("cuda")).logits.float().cpu()
+    ref, fp = torch.from_numpy(g["logits"]), torch.from_numpy(g["logits_fp"])
+    assert float((y - ref).norm() / ref.norm()) <= 5e-2
+    assert float((y - fp).norm() / fp.norm()) <= 1.5 * float((ref - fp).norm() / fp.norm()) + 1e-3
 
 
 def test_rtn_tiny_gpt2_conv1d_bit_exact():
