@@ -123,6 +123,58 @@ def test_rtn_int8_per_channel_tiny_opt_bit_exact():
     assert float((y - ref).norm() / ref.norm()) <= 5e-3
 
 
+def test_rtn_quant_lm_head_leaves_a_tied_embedding_alone():
+    """Reference test_rtn.py:220-246: with tie_word_embeddings the lm_head shares its Parameter with the embedding; after
+    RTNConfig(quant_lm_head=True) the embedding must still be the original, unquantised tensor."""
+    from transformers import OPTConfig, OPTForCausalLM
+
+    from neural_compressor_amd.torch.quantization import RTNConfig, convert, prepare
+
+    cfg = OPTConfig(hidden_size=64, ffn_dim=128, num_hidden_layers=1, num_attention_heads=4, vocab_size=128, max_position_embeddings=64,
+                    word_embed_proj_dim=64, bos_token_id=1, eos_token_id=2, pad_token_id=0, tie_word_embeddings=True)
+    torch.manual_seed(0)
+    model = OPTForCausalLM(cfg).eval()
+    emb = model.model.decoder.embed_tokens.weight
+    assert emb is model.lm_head.weight, "the lm_head weight is not tied, please check!"
+    before = emb.detach().clone()
+    q = convert(prepare(model, RTNConfig(quant_lm_head=True, use_layer_wise=False)))
+    assert "lm_head" in _woq_modules(q)
+    after = q.model.decoder.embed_tokens.weight
+    assert after is emb and torch.equal(after.detach().cpu(), before)
+    with torch.no_grad():
+        y = q(calib_ids()[0].to("cuda")).logits
+    assert torch.isfinite(y).all()
+
+
+def test_mixed_algorithms_rtn_plus_gptq():
+    """Reference test_mixed_algos.py:20-43: `RTNConfig(white_list=mlp) + GPTQConfig(white_list=attn)` applies BOTH algorithms,
+    each to its own layers; the attention layers must equal a GPTQ-only run, the MLP layers an RTN-only run."""
+    from neural_compressor_amd.torch.quantization import GPTQConfig, RTNConfig, quantize
+
+    ids = calib_ids()
+
+    def run_fn(model):
+        for x in ids:
+            model(x)
+
+    combined = RTNConfig(white_list=[".*mlp.*"], use_layer_wise=False) + GPTQConfig(white_list=[".*attn.*"])
+    q = quantize(tiny_gptj(), combined, run_fn=run_fn)
+    mods = _woq_modules(q)
+    assert len(mods) == 12 and "lm_head" not in mods
+    rtn_only = _woq_modules(quantize(tiny_gptj(), RTNConfig(white_list=[".*mlp.*"], use_layer_wise=False)))
+    assert sorted(rtn_only) == sorted(n for n in mods if ".mlp." in n) and len(rtn_only) == 4
+    for n, m in rtn_only.items():
+        assert torch.equal(m.qweight, mods[n].qweight) and torch.equal(m.scales, mods[n].scales), n
+    gptq_only = _woq_modules(quantize(tiny_gptj(), GPTQConfig(white_list=[".*attn.*"]), run_fn=run_fn))
+    assert sorted(gptq_only) == sorted(n for n in mods if ".attn." in n) and len(gptq_only) == 8
+    # block 0 of the GPTQ part sees identical calibration inputs in both runs (RTN has not touched anything upstream of it yet)
+    for n, m in gptq_only.items():
+        if ".h.0." in n:
+            assert torch.equal(m.qweight, mods[n].qweight), n
+    with torch.no_grad():
+        assert torch.isfinite(q(ids[0].to("cuda")).logits).all()
+
+
 def test_gptq_tiny_opt_vs_reference():
     from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
 
