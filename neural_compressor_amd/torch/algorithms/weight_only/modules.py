@@ -247,8 +247,10 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
     def forward(self, input):
         """y = x W^T + b with W dequantised on the fly (reference modules.py:594-610).
 
-        bf16 / fp16 inputs are computed in their own dtype (fp32 accumulate); any other dtype is cast to fp16,
-        which is what the reference does on an accelerator (`input.type(self.weight.dtype)` with an fp16 weight).
+        bf16 / fp16 inputs are computed in their own dtype (fp32 accumulate); any other dtype is cast to fp16 for the
+        multiplication (what the reference does on an accelerator: `input.type(self.weight.dtype)` with an fp16 weight)
+        and an fp32 input gets an fp32 output back, as on the reference's CPU path (:598-600), so an fp32 model keeps
+        running after some of its layers are packed (true_sequential re-runs the block mid-way).
         """
         x = input
         if x.dtype not in (torch.bfloat16, torch.float16):
@@ -256,7 +258,7 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         lead = x.shape[:-1]
         x2d = x.reshape(-1, self.in_features)
         if x2d.shape[0] == 0:  # empty batch: nothing to launch (F.linear returns an empty tensor too)
-            return x2d.new_empty((*lead, self.out_features))
+            return x2d.new_empty((*lead, self.out_features), dtype=torch.float32 if input.dtype == torch.float32 else x2d.dtype)
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
         plan = self._forward_plan()
@@ -276,6 +278,8 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
             w = self.recover(dtype=x2d.dtype)
             b = None if self.bias is None else self.bias.to(x2d.dtype)
             y = torch.nn.functional.linear(x2d, w, b)
+        if input.dtype == torch.float32:
+            y = y.float()
         return y.reshape(*lead, self.out_features)
 
     def _forward_plan(self):

@@ -28,6 +28,8 @@ def dump_modules(q, out):
             out[f"{name}.qweight"] = mod.qweight.numpy()
             out[f"{name}.qzeros"] = mod.qzeros.numpy()
             out[f"{name}.scales"] = mod.scales.numpy()
+            if getattr(mod, "g_idx", None) is not None:
+                out[f"{name}.g_idx"] = mod.g_idx.numpy()
             n += 1
     out["n_modules"] = np.int64(n)
 
@@ -53,6 +55,10 @@ def main():
     for tag, kw in {
         "sym_g32": dict(bits=4, group_size=32, use_sym=True, block_size=128),
         "asym_g32": dict(bits=4, group_size=32, use_sym=False, block_size=128),
+        # the option tests of the reference's test_gptq.py (act_order :137-160, use_mse_search, true_sequential :187-208)
+        "act_order": dict(bits=4, group_size=32, use_sym=True, block_size=128, act_order=True),
+        "true_seq": dict(bits=4, group_size=32, use_sym=True, block_size=128, true_sequential=True),
+        "mse": dict(bits=4, group_size=32, use_sym=False, block_size=128, use_mse_search=True),
     }.items():
         model = tiny_llama()
         cfg = GPTQConfig(model_path=tmp, **kw)

@@ -551,12 +551,15 @@ def test_fused_gemm_split_k_medium_m(hip, M):
     assert torch.equal(m(x), y)
 
 
-def test_forward_matches_reference_accelerator_semantics(hip):
-    """fp32 input -> cast to fp16 and fp16 out, as the reference does on an accelerator (modules.py:605)."""
+def test_forward_dtype_semantics(hip):
+    """fp32 input: multiplied in fp16 (the accelerator branch of the reference, modules.py:605) and handed back as fp32 (its
+    CPU branch, :598-600), so an fp32 model keeps running with packed layers inside; 16-bit inputs keep their dtype."""
     m = _packed_layer(hip, 128, 256, 32, 4, True, seed=5)
     x = torch.randn(3, 5, 256, device=hip)
     y = m(x)
-    assert y.dtype == torch.float16 and y.shape == (3, 5, 128)
+    assert y.dtype == torch.float32 and y.shape == (3, 5, 128)
+    assert torch.equal(y, m(x.half()).float())  # the same fp16 product
+    assert m(x.bfloat16()).dtype == torch.bfloat16
 
 
 # ---------------------------------------------------------------------------------------------------
