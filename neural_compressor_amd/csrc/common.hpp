@@ -117,6 +117,21 @@ __device__ __forceinline__ void lds_dma_4x1k(const void* base, uint32_t lds_dst,
       : "memory", "scc");
 }
 
+// logical tile index -> (tm, tn), walking the tile grid in bands of 8 tile-rows, column by column inside a band.  The W8A8
+// GEMM first gives every XCD a contiguous range of logical indices (block b runs on XCD b % 8); with this order such a
+// range is an 8 x c patch instead of a 2 x 4c strip, so the tiles an XCD runs concurrently share more operand panels in
+// its L2 when both operand tiles have the same size (the 4-bit GEMM, whose x tile is 4x its W tile, keeps row-major).
+__device__ __forceinline__ void banded_tile_decode(int idx, int tiles_m, int tiles_n, int& tm, int& tn) {
+  constexpr int BAND = 8;
+  const int per_band = BAND * tiles_n;
+  const int band = idx / per_band;
+  const int first = band * BAND;
+  const int rows = (tiles_m - first) < BAND ? (tiles_m - first) : BAND;
+  const int r = idx - band * per_band;
+  tm = first + r % rows;
+  tn = r / rows;
+}
+
 // dispatch a runtime dtype code to a template parameter
 #define INC_DISPATCH_DTYPE(code, NAME, ...)                  \
   switch (code) {                                            \

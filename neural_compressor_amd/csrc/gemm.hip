@@ -595,6 +595,8 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective XCD remap
   }
+  // row-major inside an XCD's range: a 2 x 16 strip shares the 32 KiB x tiles 16 ways and the 8 KiB W tiles 2 ways -- 192 KiB of
+  // unique operand bytes per K-step for 32 tiles; the 8 x 4 patch of banded_tile_decode needs 288 KiB and measured 15 % slower
   const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
   const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
   const int tid = threadIdx.x, lane = tid & 63;

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512) void w8a8_gemm_kernel(const int8_t* __restrict
                                                         int split, int* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (int)((N + IN - 1) / IN);
+  const int tiles_m = (int)((M + IM - 1) / IM);
   int wg = blockIdx.x, ks = 0, tail_id = -1;
   if (wg < full_tiles) {
     const int q = full_tiles / 8, xcd = wg % 8, idx = wg / 8;  // full_tiles is a multiple of 256 (or all tiles when no split)
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(512) void w8a8_gemm_kernel(const int8_t* __restrict
     ks = j - tail_id * split;
     wg = full_tiles + tail_id;
   }
-  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  int tm, tn;
+  banded_tile_decode(wg, tiles_m, tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * IM, n0 = (int64_t)tn * IN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -317,8 +319,10 @@ __global__ __launch_bounds__(512) void w8a8_tail_finish_kernel(const int* __rest
                                                                uint16_t* __restrict__ y, int64_t M, int64_t N, int y_vec_ok,
                                                                int full_tiles, int split) {
   const int tiles_n = (int)((N + IN - 1) / IN);
+  const int tiles_m = (int)((M + IM - 1) / IM);
   const int tail_id = blockIdx.x, wg = full_tiles + tail_id;
-  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  int tm, tn;
+  banded_tile_decode(wg, tiles_m, tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * IM, n0 = (int64_t)tn * IN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;

@@ -12,3 +12,17 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
   echo "pass [$pass] exit $?"
 done
 find "$ROOT/gpurun_out/pmc" -name "*.csv" | head -20
+
+python - <<'PY'
+import collections, csv, glob, json, os, re
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in glob.glob(os.path.join(root, "gpurun_out/pmc/*/pmc_counter_collection.csv")):
+    for r in csv.DictReader(open(d)):
+        name = re.sub(r"^void |\(anonymous namespace\)::|\(.*$", "", r["Kernel_Name"])
+        agg[f"{name} grid={r['Grid_Size']}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": max(len(v) for v in cs.values())} for k, cs in agg.items()}
+json.dump(out, open(os.path.join(root, "gpurun_out/pmc/pmc_per_dispatch_means.json"), "w"), indent=1, sort_keys=True)
+for k, v in sorted(out.items()):
+    print(k, {c: round(x, 1) for c, x in v.items()})
+PY

@@ -572,7 +572,7 @@ int main(int argc, char** argv) {
         INCCHECK(inc_woq_gemm(x1.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, 1, N, K, W.G, 128, 4, ws.p, wsb, nullptr));
     }
     {
-      const int64_t T = 2048, K = 11008;
+      const int64_t T = 16384, K = 11008;  // the bench's launch shape: 8 staged samples per launch
       DevBuf<uint16_t> x((size_t)T * K);
       std::vector<uint16_t> hx(x.n);
       for (auto& v : hx) v = f2bf(rnd_normal());
@@ -580,6 +580,24 @@ int main(int argc, char** argv) {
       DevBuf<float> H((size_t)K * K);
       H.zero();
       for (int i = 0; i < 5; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
+    }
+    {
+      const int64_t M = 4096, N = 5120, K = 13824;  // W8A8 GEMM, Llama-2-13B down_proj (tail K-split active)
+      DevBuf<int8_t> xq((size_t)M * K), wq((size_t)N * K);
+      std::vector<int8_t> hx(xq.n), hw(wq.n);
+      for (auto& v : hx) v = (int8_t)((int)(rnd_uniform() * 256.f) - 128);
+      for (auto& v : hw) v = (int8_t)((int)(rnd_uniform() * 256.f) - 128);
+      xq.upload(hx);
+      wq.upload(hw);
+      DevBuf<float> alpha((size_t)N);
+      alpha.upload(std::vector<float>(N, 1e-5f));
+      DevBuf<uint16_t> y((size_t)M * N);
+      const int64_t wsb = inc_w8a8_gemm_workspace_bytes(M, N, K);
+      DevBuf<char> ws((size_t)(wsb > 0 ? wsb : 16));
+      for (int i = 0; i < 5; ++i)
+        INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, nullptr, nullptr, y.p, INC_BF16, M, N, K, ws.p, wsb, nullptr));
+      for (int i = 0; i < 5; ++i)
+        INCCHECK(inc_w8a8_gemm(xq.p, wq.p, alpha.p, nullptr, nullptr, y.p, INC_BF16, 1, N, K, nullptr, 0, nullptr));
     }
     HIPCHECK(hipDeviceSynchronize());
     printf("prof workload done\n");
