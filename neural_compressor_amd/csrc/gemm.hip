@@ -1239,8 +1239,9 @@ static int big_splitk(int64_t M, int64_t N, int64_t K, int* steps_out) {
   int splits = 1;
   if (tiles < 192 && (K % 128) == 0 && (N % 4) == 0) {
     splits = (int)(256 / tiles);
+    const int cap = tiles <= 16 ? 16 : 8;
+    if (splits > cap) splits = cap;
     while (splits > 1 && (nk / splits) < 4) --splits;
-    if (splits > 8) splits = 8;
   }
   int steps = (int)ceil_div64(nk, splits);
   steps += steps & 1;  // the K-loop is unrolled by two
@@ -1252,7 +1253,7 @@ static int big_splitk(int64_t M, int64_t N, int64_t K, int* steps_out) {
 int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M > 16) {
     int steps;
-    const int splits = M >= 128 && N >= 64 ? big_splitk(M, N, K, &steps) : 1;
+    const int splits = M > 16 && N >= 64 ? big_splitk(M, N, K, &steps) : 1;
     return splits > 1 ? WS_COUNTER_BYTES + (int64_t)splits * M * N * 4 : 0;  // slabs start AFTER the counter block
   }
   int64_t slices = ceil_div64(K, 32 * VS * 4);
@@ -1284,7 +1285,9 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   int g_shift = -2;
   if (group_size >= K) g_shift = -1;
   else if (group_size >= 32 && (group_size & (group_size - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < group_size) ++g_shift; }
-  const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M >= 128 && N >= 64 &&
+  // 16 < M < 128 (batched decode) runs the same 256-row tile with most rows clamped: with split-K over up to 16 slabs that is
+  // 30 us at 64 x 4096 x 4096 where the 128x128 register-staged kernel needed 208 us (and 615 us at 17 x 4096 x 11008)
+  const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M > 16 && N >= 64 &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
   const int dbg = inc_small_tiles_flag(-1);
   if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 30) || (dbg >= 31 && dbg <= 37))) {

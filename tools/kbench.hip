@@ -522,6 +522,9 @@ int main(int argc, char** argv) {
     fails += run_gemm_case(8192, 4096, 4096, 128, false, true, true, 32);
     fails += run_gemm_case(512, 4096, 4096, 128, true, false, true, 64);
     fails += run_gemm_case(128, 4096, 4096, 128, true, false, true, 64);
+    fails += run_gemm_case(64, 4096, 4096, 128, true, false, true, 64);
+    fails += run_gemm_case(32, 11008, 4096, 128, true, false, true, 32);
+    fails += run_gemm_case(17, 4096, 11008, 128, true, false, true, 17);
   }
   if (what == "gemv" || what == "all") {
     fails += run_gemm_case(1, 4096, 4096, 128, true, false, true, 1);
