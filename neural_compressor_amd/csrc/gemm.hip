@@ -328,6 +328,26 @@ __device__ __forceinline__ uint4 dequant8(uint32_t w, float s_over_u, float nzs)
   return o;
 }
 
+// two 8-bit packed words (k0..3, k4..7 of one column) -> 8 x rn16(int8(q - z) * s).  The difference wraps to int8 exactly like the
+// reference's recover(), which unpacks 8-bit codes and zero points into int8 tensors and subtracts there (modules.py:377-443:
+// an asymmetric code more than 127 away from its zero point flips sign) -- and like inc_woq_dequant / the first-generation
+// kernel (dequant_word).  The product of an int8 and an 11-bit scale is exact in fp32: one rounding, in the 16-bit conversion.
+template <bool IS_BF16>
+__device__ __forceinline__ uint4 dequant8_from_bytes(uint32_t w0, uint32_t w1, float s, int z) {
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[j] = (float)(int)(int8_t)(uint8_t)(((w0 >> (8 * j)) & 0xffu) - (uint32_t)z) * s;
+    f[4 + j] = (float)(int)(int8_t)(uint8_t)(((w1 >> (8 * j)) & 0xffu) - (uint32_t)z) * s;
+  }
+  uint4 o;
+  o.x = cvt_pair<IS_BF16>(f[0], f[1]);
+  o.y = cvt_pair<IS_BF16>(f[2], f[3]);
+  o.z = cvt_pair<IS_BF16>(f[4], f[5]);
+  o.w = cvt_pair<IS_BF16>(f[6], f[7]);
+  return o;
+}
+
 // ABL != 0: timing-only ablations for tools/kbench (results are WRONG): 1 = no dequant arithmetic, 2 = x fragments read
 // once per K-step, 3 = no global traffic inside the K-loop, 4 = no MFMA
 template <bool IS_BF16, int ABL = 0>
@@ -578,7 +598,10 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
 // not bound by instruction placement -- a variant that spread the 10 VMEM requests between the carried group's MFMAs
 // changed nothing either -- but by the sum of its parts.
 #define INC_3A2B_DEFAULT_SCHED 1
-template <bool IS_BF16, int SCHED>
+// BITS = 8 (weight-only INT8, BASELINE config #1's packed layers): the same kernel with a 16 KiB packed W tile per step --
+// a thread fetches 8 words (4 k each) of its column instead of 4 (8 k each), two words make one 16-byte fragment row, the
+// integer -> float step is v_cvt_f32_ubyte*, a step has 14 VMEM requests instead of 10 (the counted waits follow).
+template <bool IS_BF16, int SCHED, int BITS = 4>
 __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
     const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
@@ -631,11 +654,13 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   const int bcol = tid & 255, kwh = tid >> 8;
   int64_t ncol = n0 + bcol;
   if (ncol > N - 1) ncol = N - 1;
-  uint32_t wvoff[4];
+  constexpr int NPK = 32 / BITS;       // codes per packed word: 8 / 4
+  constexpr int NWD = 32 / NPK;        // words of one column per thread and step (32 k): 4 / 8
+  uint32_t wvoff[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wvoff[j] = (uint32_t)(((int64_t)(4 * kwh + j) * N + ncol) * 4);
-  const uint32_t svoff = (uint32_t)(ncol * 2), zvoff = (uint32_t)((ncol >> 3) * 4);
-  const int zshift = 4 * (int)(ncol & 7);
+  for (int j = 0; j < NWD; ++j) wvoff[j] = (uint32_t)(((int64_t)(NWD * kwh + j) * N + ncol) * 4);
+  const uint32_t svoff = (uint32_t)(ncol * 2), zvoff = (uint32_t)((ncol / NPK) * 4);
+  const int zshift = BITS * (int)(ncol % NPK);
   const int bdst0 = (((bcol >> 5) * 4 + 2 * kwh) * 64 + (bcol & 31)) * 16;
   const int kwh_s = __builtin_amdgcn_readfirstlane(tid >> 8);
   // split-K (medium M: fewer tiles than CUs): this workgroup multiplies K-tiles [kbase, kbase + nk) and, when `partial`
@@ -645,13 +670,13 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   const int nk = min(steps_per_split, nk_all - kbase);
 
   // one step's requests: 6 for W (4 packed words, scale, zero word) FIRST, then 4 x DMAs
-  auto issue_w = [&](int kt, uint32_t (&w)[4], uint32_t& sb, uint32_t& zw) {
+  auto issue_w = [&](int kt, uint32_t (&w)[8], uint32_t& sb, uint32_t& zw) {
     if (NO_LD || NO_WLD) {
       asm volatile("" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(sb), "=v"(zw));
       return;
     }
     kt = FIXED_ADDR ? 0 : kbase + (kt > nk - 1 ? nk - 1 : kt);
-    const uint32_t* wbase = qweight + (int64_t)kt * (TK / 8) * N;
+    const uint32_t* wbase = qweight + (int64_t)kt * (TK / NPK) * N;
     const int64_t g = g_shift >= 0 ? (((int64_t)kt * TK + 32 * kwh_s) >> g_shift) : 0;  // wave-uniform (kwh is)
     const uint16_t* sbase = scales + g * N;
     const uint32_t* zbase = qzeros + g * NW;
@@ -666,6 +691,15 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(sb), "=&v"(zw)
         : "v"(wvoff[0]), "v"(wvoff[1]), "v"(wvoff[2]), "v"(wvoff[3]), "v"(svoff), "v"(zvoff), "s"(wbase), "s"(sbase), "s"(zbase)
         : "memory");
+    if constexpr (BITS == 8)
+      asm volatile(
+          "global_load_dword %0, %4, %8\n\t"
+          "global_load_dword %1, %5, %8\n\t"
+          "global_load_dword %2, %6, %8\n\t"
+          "global_load_dword %3, %7, %8"
+          : "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+          : "v"(wvoff[4]), "v"(wvoff[5]), "v"(wvoff[6]), "v"(wvoff[7]), "s"(wbase)
+          : "memory");
   };
   auto issue_dma = [&](int kt, int astage) {
     if (NO_LD || NO_DMA) return;
@@ -702,32 +736,41 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     acc[i >> 2][i & 3] = mfma32<IS_BF16>(wbv[i >> 2], xa[i & 3], acc[i >> 2][i & 3]);
   };
 #define INC_SB() __builtin_amdgcn_sched_barrier(0)
-  auto dequant_into = [&](int bstage, int kk, uint32_t word, float sc, float nzs) {
+  // the kk-th 8-k fragment row of this thread's column: one 4-bit word, or two 8-bit words
+  auto dequant_into = [&](int bstage, int kk, const uint32_t (&wd)[8], float sc, float nzs) {
     char* dst = Bbase + bstage * T_BSTAGE + bdst0;
-    const uint4 v = NO_DEQ ? make_uint4(word, word, word, word) : dequant8<IS_BF16>(word, sc, nzs);
+    uint4 v;
+    if constexpr (BITS == 4) {
+      const uint32_t word = wd[kk];
+      v = NO_DEQ ? make_uint4(word, word, word, word) : dequant8<IS_BF16>(word, sc, nzs);
+    } else {
+      v = dequant8_from_bytes<IS_BF16>(wd[2 * kk], wd[2 * kk + 1], sc, (int)nzs);  // 8-bit: `nzs` carries the zero point itself
+    }
     if (NO_WR) asm volatile("" : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
     else *reinterpret_cast<uint4*>(dst + ((kk >> 1) * 64 + 32 * (kk & 1)) * 16) = v;
   };
   auto group_params = [&](uint32_t sb, uint32_t zw, float& sc, float& nzs) {
     const float sc0 = f16_bits_to_f32((uint16_t)sb);
-    uint32_t zz = ((zw >> zshift) & 15u) + 1u;  // modules.py:407-410
-    zz = zz > 15u ? 0u : zz;
-    nzs = -(float)zz * sc0;
-    sc = sc0 * inv_u;
+    constexpr uint32_t qmax = (1u << BITS) - 1u;
+    uint32_t zz = ((zw >> zshift) & qmax) + 1u;  // modules.py:407-410
+    zz = zz > qmax ? 0u : zz;
+    nzs = BITS == 4 ? -(float)zz * sc0 : (float)zz;  // 8-bit: the zero point itself (the int8 wrap of q - z needs it as an integer)
+    sc = BITS == 4 ? sc0 * inv_u : sc0;               // the 4-bit path converts through the fp8 decoder (q * 2^-9)
   };
 
   // ---- prologue: x stage 0 and W stage 0 complete; queue = [W words of tile 1 (6), DMA of x tile 1 (4)] ---------------
-  uint32_t wa[4], wsa, wza;  // W register set A: tiles with ODD index
-  uint32_t wb_[4], wsb, wzb; // W register set B: tiles with EVEN index >= 2
+  uint32_t wa[8], wsa, wza;  // W register set A: tiles with ODD index (4-bit: entries 0..3 only)
+  uint32_t wb_[8], wsb, wzb; // W register set B: tiles with EVEN index >= 2
   {
-    uint32_t w0[4], s0, z0;
+    uint32_t w0[8], s0, z0;
     issue_w(0, w0, s0, z0);
     issue_dma(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(s0), "+v"(z0) : : "memory");
+    if constexpr (BITS == 8) asm volatile("" : "+v"(w0[4]), "+v"(w0[5]), "+v"(w0[6]), "+v"(w0[7]) : : "memory");
     float sc, nzs;
     group_params(s0, z0, sc, nzs);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) dequant_into(0, kk, w0[kk], sc, nzs);
+    for (int kk = 0; kk < 4; ++kk) dequant_into(0, kk, w0, sc, nzs);
   }
   if (PP && wm) issue_w(1, wb_, wsb, wzb);  // the second half enters the loop one load segment later: sets swapped
   else issue_w(1, wa, wsa, wza);
@@ -753,6 +796,20 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   // issue of one hides behind the MFMAs of the other.  Half-step h: wm 0 computes tile h/2 at even h, wm 1 at odd h.  To
   // keep every tile complete one half-step before its first reader, wm 1 works one tile further ahead in its load segment
   // (loads tile t+3, dequantises tile t+2); stage numbers become wave-uniform run-time values, the loop body is one code.
+  // counted waits: a step issues NVM = NWD + 2 + 4 requests (W words, scale, zero word, 4 x DMAs); "words" retires the
+  // W-side requests of the PREVIOUS step (that step's 4 DMAs and this step's NVM stay in flight), "tile" retires the
+  // previous step's DMAs (this step's NVM stay in flight)
+  auto wait_words = [&](uint32_t (&dw)[8], uint32_t& ds, uint32_t& dz) {
+    if (NO_VMWAIT) asm volatile("" : "+v"(dw[0]), "+v"(dw[1]), "+v"(dw[2]), "+v"(dw[3]), "+v"(ds), "+v"(dz) : : "memory");
+    else if constexpr (BITS == 4) asm volatile("s_waitcnt vmcnt(14)" : "+v"(dw[0]), "+v"(dw[1]), "+v"(dw[2]), "+v"(dw[3]), "+v"(ds), "+v"(dz) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(18)" : "+v"(dw[0]), "+v"(dw[1]), "+v"(dw[2]), "+v"(dw[3]), "+v"(ds), "+v"(dz) : : "memory");
+    if constexpr (BITS == 8) asm volatile("" : "+v"(dw[4]), "+v"(dw[5]), "+v"(dw[6]), "+v"(dw[7]) : : "memory");
+  };
+  auto wait_tile = [&]() {
+    if (NO_VMWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if constexpr (BITS == 4) asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  };
 #define INC_3A2B_COMPUTE(As, Bs)                                                                                   \
   {                                                                                                                \
     if (!NO_RD) read_frags(As, Bs, 0, xX, wX);                                                                                 \
@@ -775,13 +832,13 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   {                                                                                                                \
     issue_w((T) + 2, LW, LWS, LWZ);                                                                                \
     issue_dma((T) + 2, ((T) + 2) % 3);                                                                             \
-    asm volatile("s_waitcnt vmcnt(14)" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory"); \
+    wait_words(DW, DWS, DWZ);                                                                                      \
     float sc_, nzs_;                                                                                               \
     group_params(DWS, DWZ, sc_, nzs_);                                                                             \
-    dequant_into(((T) & 1) ^ 1, 0, DW[0], sc_, nzs_);                                                              \
-    dequant_into(((T) & 1) ^ 1, 1, DW[1], sc_, nzs_);                                                              \
-    dequant_into(((T) & 1) ^ 1, 2, DW[2], sc_, nzs_);                                                              \
-    dequant_into(((T) & 1) ^ 1, 3, DW[3], sc_, nzs_);                                                              \
+    dequant_into(((T) & 1) ^ 1, 0, DW, sc_, nzs_);                                                                 \
+    dequant_into(((T) & 1) ^ 1, 1, DW, sc_, nzs_);                                                                 \
+    dequant_into(((T) & 1) ^ 1, 2, DW, sc_, nzs_);                                                                 \
+    dequant_into(((T) & 1) ^ 1, 3, DW, sc_, nzs_);                                                                 \
     INC_SB();                                                                                                      \
   }
 #define INC_3A2B_STEP3(T, LW, LWS, LWZ, DW, DWS, DWZ)                                                              \
@@ -793,7 +850,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     __builtin_amdgcn_s_barrier();                                                                                  \
     INC_SB(); /* keep the load segment's address arithmetic on its own side of the barrier */                     \
     INC_3A2B_LOADSEG(t_ + wm, LW, LWS, LWZ, DW, DWS, DWZ)                                                          \
-    asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    wait_tile();                                                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                  \
   }
 #define INC_3A2B_STEP(T, LW, LWS, LWZ, DW, DWS, DWZ)                                                              \
@@ -809,28 +866,26 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
     if (SCHED != 0) INC_SB();                                                                                      \
     if (!NO_RD) read_frags(As, Bs, 1, xY, wY);                                                                               \
     if (SCHED != 0) INC_SB();                                                                                           \
-    if (NO_VMWAIT) asm volatile("" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory");        \
-    else asm volatile("s_waitcnt vmcnt(14)" : "+v"(DW[0]), "+v"(DW[1]), "+v"(DW[2]), "+v"(DW[3]), "+v"(DWS), "+v"(DWZ) : : "memory"); \
+    wait_words(DW, DWS, DWZ);                                                                                      \
     float sc_, nzs_;                                                                                               \
     group_params(DWS, DWZ, sc_, nzs_);                                                                             \
-    if (SCHED != 0) dequant_into(bs_ ^ 1, 0, DW[0], sc_, nzs_);                                                         \
+    if (SCHED != 0) dequant_into(bs_ ^ 1, 0, DW, sc_, nzs_);                                                         \
     mma8(xX, wX);                       /* group 0 */                                                              \
-    if (SCHED == 0) dequant_into(bs_ ^ 1, 0, DW[0], sc_, nzs_);                                                        \
+    if (SCHED == 0) dequant_into(bs_ ^ 1, 0, DW, sc_, nzs_);                                                        \
     if (SCHED != 0) INC_SB();                                                                                           \
     if (!NO_RD) read_frags(As, Bs, 2, xX, wX);                                                                                 \
     if (SCHED != 0) INC_SB();                                                                                           \
-    if (SCHED != 0) dequant_into(bs_ ^ 1, 1, DW[1], sc_, nzs_);                                                         \
+    if (SCHED != 0) dequant_into(bs_ ^ 1, 1, DW, sc_, nzs_);                                                         \
     mma8(xY, wY);                       /* group 1 */                                                              \
-    if (SCHED == 0) dequant_into(bs_ ^ 1, 1, DW[1], sc_, nzs_);                                                        \
+    if (SCHED == 0) dequant_into(bs_ ^ 1, 1, DW, sc_, nzs_);                                                        \
     if (SCHED != 0) INC_SB();                                                                                           \
     if (!NO_RD) read_frags(As, Bs, 3, xY, wY);                                                                                 \
     if (SCHED != 0) INC_SB();                                                                                           \
-    if (SCHED != 0) { dequant_into(bs_ ^ 1, 2, DW[2], sc_, nzs_); dequant_into(bs_ ^ 1, 3, DW[3], sc_, nzs_); }         \
+    if (SCHED != 0) { dequant_into(bs_ ^ 1, 2, DW, sc_, nzs_); dequant_into(bs_ ^ 1, 3, DW, sc_, nzs_); }         \
     mma8(xX, wX);                       /* group 2 */                                                              \
-    if (SCHED == 0) { dequant_into(bs_ ^ 1, 2, DW[2], sc_, nzs_); dequant_into(bs_ ^ 1, 3, DW[3], sc_, nzs_); }        \
+    if (SCHED == 0) { dequant_into(bs_ ^ 1, 2, DW, sc_, nzs_); dequant_into(bs_ ^ 1, 3, DW, sc_, nzs_); }        \
     if (SCHED != 0) INC_SB();                                                                                           \
-    if (NO_VMWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
-    else asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+    wait_tile();                                                                                                   \
     if (!NO_BAR) __builtin_amdgcn_s_barrier();                                                                                  \
     if (!NO_RD) read_frags(Abase + ((t_ + 1) % 3) * T_ASTAGE, Bbase + (bs_ ^ 1) * T_BSTAGE + b_off, 0, xX, wX);               \
     if (SCHED != 0) INC_SB();                                                                                           \
@@ -838,7 +893,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
   if (PP) {
     if (wm) {  // load segment "-1": tile 2 -> x stage 2 / set A, tile 1 (set B) -> W stage 1
       INC_3A2B_LOADSEG(0, wa, wsa, wza, wb_, wsb, wzb)
-      asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_tile();
       __builtin_amdgcn_s_barrier();
     }
     for (int t0 = 0; t0 < nk; t0 += 2) {
@@ -1290,7 +1345,37 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M > 16 && N >= 64 &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
   const int dbg = inc_small_tiles_flag(-1);
-  if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 30) || (dbg >= 31 && dbg <= 37))) {
+  // weight-only INT8 (BASELINE config #1's layers): the 3A2B kernel's 8-bit instantiation, same tiling and split-K plan
+  const bool big8_ok = bits == 8 && (K % 128) == 0 && g_shift != -2 && M > 16 && N >= 64 && dbg == 0 &&
+                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 4) < (int64_t)1 << 31;
+  if (big8_ok) {
+    const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;
+    static bool a8_attr_set = false;
+    if (!a8_attr_set) {
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<true, INC_3A2B_DEFAULT_SCHED, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<false, INC_3A2B_DEFAULT_SCHED, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      a8_attr_set = true;
+    }
+    const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
+    const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
+    int steps = (int)(K / TK);
+    int splits = big_splitk(M, N, K, &steps);
+    float* part = nullptr;
+    if (splits > 1) {
+      if (y_vec_ok && workspace && workspace_bytes >= WS_COUNTER_BYTES + (int64_t)splits * M * N * 4)
+        part = (float*)((char*)workspace + WS_COUNTER_BYTES);
+      else { splits = 1; steps = (int)(K / TK); }
+    }
+    dim3 g2(grid, (unsigned)splits);
+    if (bf) woq_gemm_w4_3a2b_kernel<true, INC_3A2B_DEFAULT_SCHED, 8><<<g2, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps);
+    else woq_gemm_w4_3a2b_kernel<false, INC_3A2B_DEFAULT_SCHED, 8><<<g2, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps);
+    if (part) {
+      int64_t rb = ceil_div64(M * N / 4, 256);
+      if (rb > 4096) rb = 4096;
+      if (bf) splitk_slab_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
+      else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
+    }
+  } else if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 30) || (dbg >= 31 && dbg <= 37))) {
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
     static bool a3_attr_set = false;
     if (!a3_attr_set) {

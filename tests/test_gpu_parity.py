@@ -551,6 +551,30 @@ def test_fused_gemm_split_k_medium_m(hip, M):
     assert torch.equal(m(x), y)
 
 
+@pytest.mark.parametrize("M,N,K,gs,sym,dtype", [
+    (300, 1000, 384, 128, False, torch.bfloat16),      # ragged M / N, asym zero points, several groups
+    (64, 768, 768, -1, True, torch.float16),           # config #1's format: per-channel (one group), batched decode size
+    (4096, 3072, 768, -1, False, torch.bfloat16),      # OPT-125M fc1 at a prefill size
+    (512, 4096, 4096, 128, True, torch.bfloat16),      # split-K slabs
+])
+def test_fused_gemm_int8_weights_3a2b(hip, M, N, K, gs, sym, dtype):
+    """Weight-only INT8 (BASELINE config #1's packed layers) on the 3A2B kernel's 8-bit instantiation: equals HIP dequant
+    (pinned to the oracle above) + matmul to output rounding, is bit-reproducible and exactly linear in x."""
+    m = _packed_layer(hip, N, K, gs, 8, sym, seed=M + N + K, bias=True)
+    torch.manual_seed(M)
+    x = torch.randn(M, K, device=hip, dtype=dtype)
+    y = m(x)
+    w = m.recover(dtype=dtype).float()
+    ref = x.float() @ w.t() + m.bias.float()
+    # both sides round once to 16 bits; different fp32 summation orders flip a few roundings (one ulp = 2^-8 relative in bf16)
+    assert rel_fro(y.float(), ref.to(dtype).float()) <= (2e-3 if dtype == torch.bfloat16 else 1e-3)
+    assert rel_fro(y.float(), ref) <= (4e-3 if dtype == torch.bfloat16 else 1e-3)
+    assert torch.equal(m(x), y)
+    if dtype == torch.bfloat16:  # exact power-of-two scaling (fp16 outputs can be subnormal, where it does not hold)
+        m.bias = None
+        assert torch.equal(m(x * 2), m(x) * 2)
+
+
 def test_forward_dtype_semantics(hip):
     """fp32 input: multiplied in fp16 (the accelerator branch of the reference, modules.py:605) and handed back as fp32 (its
     CPU branch, :598-600), so an fp32 model keeps running with packed layers inside; 16-bit inputs keep their dtype."""
