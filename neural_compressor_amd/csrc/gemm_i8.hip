@@ -45,8 +45,11 @@ static inline int i8_tail_plan(int64_t tiles, int nk, int64_t* full_tiles) {
   if (tail == 0) { return 1; }
   int split = (int)(I_CUS / tail);
   if (split > 8) split = 8;
-  // measured (profiles/r1j): 27 K-steps per split gain 14 %, 10 per split lose 8 % (prologue + 256 KiB slab + second kernel)
-  while (split > 1 && nk / split < 24) --split;
+  // measured (profiles/r1j): 27 K-steps per split gain 14 %, 10 per split lose 8 % (prologue + 256 KiB slab + second kernel).
+  // With fewer tiles than a quarter of the CUs (medium M: batched decode) most of the chip would sit idle, and only the
+  // 32-row blocks that hold real rows are parked in the slabs, so short splits pay there.
+  const int min_steps = tiles < I_CUS / 4 ? 4 : 24;
+  while (split > 1 && nk / split < min_steps) --split;
   if (split <= 1) { *full_tiles = tiles; return 1; }
   return split;
 }
@@ -186,9 +189,11 @@ __global__ __launch_bounds__(512) void w8a8_gemm_kernel(const int8_t* __restrict
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-      for (int mf = 0; mf < 4; ++mf)
+      for (int mf = 0; mf < 4; ++mf) {
+        if (m0 + wm * 128 + mf * 32 >= M) continue;  // a 32-row block without a real row is neither stored nor read back
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[((nf * 4 + mf) * 16 + r) * 512 + tid] = acc[nf][mf][r];
+      }
     return;
   }
 
@@ -343,11 +348,20 @@ __global__ __launch_bounds__(512) void w8a8_tail_finish_kernel(const int* __rest
         }
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf) {
+        if (m0 + wm * 128 + mf * 32 >= M) continue;
         const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
-        int a4[4] = {0, 0, 0, 0};
-        for (int o = 0; o < split; ++o)
+        // all loads of a thread are independent: issue them together (split <= 8), then add in slab order
+        int part[8][4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a4[e] += base[(int64_t)o * (IM * IN) + ((nf * 4 + mf) * 16 + 4 * rq + e) * 512 + tid];
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            part[o][e] = o < split ? __builtin_nontemporal_load(base + (int64_t)o * (IM * IN) + ((nf * 4 + mf) * 16 + 4 * rq + e) * 512 + tid) : 0;
+        int a4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a4[e] += part[o][e];
         if (m >= M) continue;
         float v[4];
 #pragma unroll

@@ -539,6 +539,8 @@ int main(int argc, char** argv) {
     fails += run_i8_case(300, 1000, 384);
     fails += run_i8_case(1, 5120, 5120);        // decode
     fails += run_i8_case(16, 13824, 5120);
+    fails += run_i8_case(64, 5120, 5120);       // batched decode
+    fails += run_i8_case(128, 13824, 5120);
     fails += run_i8_case(4096, 5120, 5120);     // Llama-2-13B q/k/v/o
     fails += run_i8_case(4096, 13824, 5120);    // gate / up
     fails += run_i8_case(4096, 5120, 13824);    // down
