@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinc_mi355x.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 INC_OK = 0
 INC_F32, INC_F16, INC_BF16 = 0, 1, 2

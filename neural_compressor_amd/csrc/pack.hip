@@ -342,7 +342,7 @@ extern "C" {
 void inc_debug_set_small_tiles(int on) { (void)inc_small_tiles_flag(on < 0 ? 0 : on); }
 
 
-int inc_abi_version(void) { return 1; }
+int inc_abi_version(void) { return 2; }  // 2: + find_params_mse, awq_repack, sq_*, w8a8_* (SmoothQuant), chol_diag_block
 const char* inc_target_arch(void) { return "gfx950"; }
 const char* inc_error_string(int code) {
   switch (code) {
