@@ -621,6 +621,33 @@ def test_save_load_roundtrip_rtn(tmp_path, fmt):
     assert float((y1 - y0).norm() / y0.norm()) <= (1e-3 if fmt == "default" else 2e-2)
 
 
+def test_save_load_huggingface_gptq_desc_act(tmp_path):
+    """GPTQ with act_order -> HF / AutoGPTQ-style directory (`desc_act: true`, per-element g_idx in the safetensors) -> reload:
+    identical buffers, and the reloaded modules take the fused kernel on the K-sorted words."""
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, load, prepare
+
+    ids = calib_ids()
+    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, use_sym=True, act_order=True))
+    for x in ids:
+        model(x)
+    q = convert(model)
+    q.save(str(tmp_path), format="huggingface")
+    import json
+
+    qc = json.load(open(tmp_path / "quantize_config.json"))
+    assert qc["desc_act"] is True and qc["bits"] == 4 and qc["group_size"] == 32 and qc["quant_method"] == "gptq"
+    r = load(str(tmp_path), format="huggingface", device="cuda")
+    b0, b1 = _buffers(q), _buffers(r)
+    assert b0.keys() == b1.keys() and any(k.endswith("g_idx") for k in b0)
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+    with torch.no_grad():
+        y0 = _to_half(q)(ids[0].to("cuda")).logits.float()
+        y1 = _to_half(r)(ids[0].to("cuda")).logits.float()
+    assert float((y1 - y0).norm() / y0.norm()) <= 2e-2
+    assert all(m._plan == "fused_act_order" for m in _woq_modules(r).values())
+
+
 def test_save_load_default_awq_keeps_mul_linear(tmp_path):
     """AWQ checkpoints carry `<name>.input_scale` + `<name>.linear.qweight`: the loader re-inserts MulLinear (reference :479-482)."""
     from neural_compressor_amd.torch.algorithms.weight_only.modules import MulLinear
