@@ -177,3 +177,13 @@ def test_2x_shim_maps_the_smooth_quant_recipe():
     assert all(c.name == "smooth_quant" for c in mapping.values())
     with pytest.raises(NotImplementedError):
         PostTrainingQuantConfig(approach="static")  # plain static INT8 is out of scope
+
+
+def test_short_rows_are_dropped_like_the_reference():
+    from neural_compressor_amd.transformers.quantization.utils import _as_batches
+
+    rows = [torch.arange(40), torch.arange(10), torch.arange(64).reshape(2, 32)]
+    got = list(_as_batches(rows, None, 32, 100, 2))
+    assert [tuple(b.shape) for b in got] == [(2, 32), (1, 32)]
+    with pytest.raises(AssertionError):
+        list(_as_batches([torch.arange(4)], None, 32, 8, 2))

@@ -98,16 +98,6 @@ def test_gptq_front_end_equals_prepare_convert(float_dir):
     assert all(mod._plan == "fused_act_order" for mod in _woq(q).values())
 
 
-def test_short_rows_are_dropped_like_the_reference():
-    from neural_compressor_amd.transformers.quantization.utils import _as_batches
-
-    rows = [torch.arange(40), torch.arange(10), torch.arange(64).reshape(2, 32)]
-    got = list(_as_batches(rows, None, 32, 100, 2))
-    assert [tuple(b.shape) for b in got] == [(2, 32), (1, 32)]
-    with pytest.raises(AssertionError):
-        list(_as_batches([torch.arange(4)], None, 32, 8, 2))
-
-
 def test_autoawq_checkpoint_is_repacked_on_load(tmp_path):
     """A directory in AutoAWQ's GEMM format ([K, N/8] interleaved words, config.json quantization_config
     quant_method=awq) opens with packed modules whose weights equal AutoAWQ's dequantisation (reference
