@@ -187,3 +187,67 @@ def test_short_rows_are_dropped_like_the_reference():
     assert [tuple(b.shape) for b in got] == [(2, 32), (1, 32)]
     with pytest.raises(AssertionError):
         list(_as_batches([torch.arange(4)], None, 32, 8, 2))
+
+
+def test_gptq_forward_groups_stack_only_compatible_batches(monkeypatch):
+    """RAWGPTQuantizer._forward_groups (pure host logic): cached batches are stacked only when everything but the hidden
+    states is the same tensor value, the leading dimension is 1 and the shapes agree; INC_MI355X_GPTQ_FORWARD_BATCH bounds it."""
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import RAWGPTQuantizer
+
+    rq = object.__new__(RAWGPTQuantizer)
+    pos = torch.arange(8).view(1, 8)
+    hs = [torch.randn(1, 8, 4) for _ in range(6)]
+    hs[4] = torch.randn(1, 5, 4)  # a shorter sample cannot ride with the others
+    rq.cache_positional_arguments = [list(hs)]
+    rq.cache_key_arguments = {"position_ids": [pos.clone() for _ in range(6)], "mask": [None] * 6}
+    assert rq._forward_groups(6, in_kwargs=False) == [[0, 1, 2, 3], [4], [5]]
+    assert rq._forward_groups(6, in_kwargs=False) == [[0, 1, 2, 3], [4], [5]]  # cached
+    rq2 = object.__new__(RAWGPTQuantizer)
+    rq2.cache_positional_arguments = []
+    rq2.cache_key_arguments = {"hidden_states": [torch.randn(1, 8, 4) for _ in range(5)],
+                               "position_ids": [pos, pos, pos + 1, pos + 1, pos + 1]}  # different positions split the run
+    monkeypatch.setenv("INC_MI355X_GPTQ_FORWARD_BATCH", "8")
+    assert rq2._forward_groups(5, in_kwargs=True) == [[0, 1], [2, 3, 4]]
+    rq3 = object.__new__(RAWGPTQuantizer)
+    rq3.cache_positional_arguments = [[torch.randn(2, 8, 4) for _ in range(3)]]  # user batches of 2: never stacked
+    rq3.cache_key_arguments = {}
+    assert rq3._forward_groups(3, in_kwargs=False) == [[0], [1], [2]]
+    monkeypatch.setenv("INC_MI355X_GPTQ_FORWARD_BATCH", "1")
+    rq4 = object.__new__(RAWGPTQuantizer)
+    rq4.cache_positional_arguments = [[torch.randn(1, 8, 4) for _ in range(3)]]
+    rq4.cache_key_arguments = {}
+    assert rq4._forward_groups(3, in_kwargs=False) == [[0], [1], [2]]
+
+
+def test_awq_search_stacking_helpers(monkeypatch):
+    from neural_compressor_amd.torch.algorithms.weight_only.awq import ActAwareWeightQuant
+
+    aw = object.__new__(ActAwareWeightQuant)
+    monkeypatch.setenv("INC_MI355X_AWQ_SEARCH_BATCH", "4")
+    xs = [torch.randn(1, 3, 2) for _ in range(6)]
+    st = aw._stack(xs)
+    assert [(tuple(t.shape), n) for t, n in st] == [((4, 3, 2), 4), ((2, 3, 2), 2)]
+    assert torch.equal(st[1][0], torch.cat(xs[4:], 0))
+    assert [n for _, n in aw._stack(xs[:5] + [torch.randn(1, 4, 2)])] == [1] * 6  # ragged: one at a time
+    p = torch.arange(3)
+    assert aw._same_kwargs({"a": p, "b": (p, None), "c": 1}, {"a": p.clone(), "b": (p.clone(), None), "c": 1})
+    assert not aw._same_kwargs({"a": p}, {"a": p + 1})
+    assert not aw._same_kwargs({"a": p}, {"b": p})
+
+
+def test_hf_config_export_and_device_map_checks():
+    from neural_compressor_amd.torch.algorithms.weight_only.save_load import change_config_to_hf_format
+    from neural_compressor_amd.transformers.models.modeling_auto import _device_of
+
+    g = GPTQConfig(bits=4, group_size=128, use_sym=True, act_order=True, percdamp=0.02, true_sequential=True)
+    fp = GPTQConfig(dtype="fp32")
+    hf = change_config_to_hf_format({("model.layers.0.q", "Linear"): g, ("model.layers.0.k", "Linear"): g, ("lm_head", "Linear"): fp})
+    assert (hf["bits"], hf["group_size"], hf["sym"], hf["desc_act"], hf["damp_percent"], hf["true_sequential"], hf["quant_method"]) == (
+        4, 128, True, True, 0.02, True, "gptq")
+    with pytest.raises(ValueError):
+        change_config_to_hf_format({("lm_head", "Linear"): g})  # a quantised lm_head cannot be expressed in that format
+    with pytest.raises(AssertionError):
+        change_config_to_hf_format({("a", "Linear"): g, ("b", "Linear"): GPTQConfig(bits=8, group_size=128)})
+    assert str(_device_of({"": "cuda:0"})) == "cuda:0" and str(_device_of("auto")) == "cuda"
+    with pytest.raises(RuntimeError):
+        _device_of("cpu")
