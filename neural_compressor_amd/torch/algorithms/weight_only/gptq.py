@@ -510,11 +510,11 @@ class RAWGPTQuantizer(object):
         """One forward of `block` over every cached calibration batch (reference :690-702 / :749-762).
 
         Cached batches that differ only in their hidden states (same shape, leading dimension 1, every other argument
-        the same tensor values) are stacked `forward_batch` at a time (INC_MI355X_GPTQ_FORWARD_BATCH, default 4; 1 = one
+        the same tensor values) are stacked `forward_batch` at a time (INC_MI355X_GPTQ_FORWARD_BATCH, default 8; 1 = one
         batch per forward as the reference does): a decoder block treats the rows of a stacked input independently, the
         running-mean Hessian update is the same sum either way (`add_batch` counts the leading dimension, gptq.py:1117),
         and the per-batch outputs are handed on as slices.  What changes is the size of the GEMMs the model's own
-        forward runs (M = 8192 instead of 2048 at the BASELINE calibration shape) and 4x fewer elementwise launches."""
+        forward runs (M = 16384 instead of 2048 at the BASELINE calibration shape) and 8x fewer elementwise launches."""
         batch_num = self.cache_key_arguments.pop("batch_num")
         in_kwargs = "hidden_states" in self.cache_key_arguments
         for group in self._forward_groups(batch_num, in_kwargs):
@@ -540,7 +540,7 @@ class RAWGPTQuantizer(object):
         cached = getattr(self, "_fgroups", None)
         if cached is not None and cached[0] == batch_num:
             return cached[1]
-        fb = max(1, int(os.environ.get("INC_MI355X_GPTQ_FORWARD_BATCH", "4")))
+        fb = max(1, int(os.environ.get("INC_MI355X_GPTQ_FORWARD_BATCH", "8")))
 
         def same(a, b):
             if a is b:
