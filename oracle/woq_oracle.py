@@ -281,14 +281,20 @@ def gptq_add_batch(H, nsamples, inp):
     return H, nsamples
 
 
-def gptq_hinv(H, percdamp=0.01):
-    """gptq.py:1186-1189, 1221-1231 -> (Hinv upper Cholesky factor of the damped inverse, dead mask). H is copied."""
+def gptq_damped(H, percdamp=0.01):
+    """gptq.py:1186-1189, 1221-1227: dead-column fix + damping -> (damped copy of H, dead mask)."""
     H = H.clone()
     dead = torch.diag(H) == 0
     H[dead, dead] = 1
     damp = percdamp * torch.mean(torch.diag(H))
     diag = torch.arange(H.shape[0])
     H[diag, diag] += damp
+    return H, dead
+
+
+def gptq_hinv(H, percdamp=0.01):
+    """gptq.py:1186-1189, 1221-1231 -> (Hinv upper Cholesky factor of the damped inverse, dead mask). H is copied."""
+    H, dead = gptq_damped(H, percdamp)
     H = torch.linalg.cholesky(H)
     H = torch.cholesky_inverse(H)
     H = torch.linalg.cholesky(H, upper=True)
@@ -296,10 +302,13 @@ def gptq_hinv(H, percdamp=0.01):
 
 
 def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, groupsize=-1, act_order=False,
-                     static_groups=False, Hinv=None, mse=False):
+                     static_groups=False, Hinv=None, mse=False, trace=False):
     """GPTQ.fasterquant (gptq.py:1143-1351) for int dtype.  Returns dict(scale [N,G], zero [N,G], Q fp32 [N,K], perm).
 
     `Hinv` (optional) injects a precomputed factor so the column loop can be tested in isolation.
+    `trace` (test instrumentation, not part of the reference): also return `Win` [N,K], the value of every weight at
+    the moment it was quantised (loop order, i.e. permuted columns with act_order) -- what a parity test needs to tell
+    a rounding-tie flip (|w/scale| within float noise of a .5 boundary) from a real difference.
     """
     W = W.clone().float()
     quantizer = GPTQQuantParams(bits, sym, mse=mse)
@@ -332,6 +341,7 @@ def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, grou
         H = torch.cholesky_inverse(H)
         Hinv = torch.linalg.cholesky(H, upper=True)
     scale, zero = [], []
+    Win = torch.zeros_like(W) if trace else None
     for i1 in range(0, columns, blocksize):
         i2 = min(i1 + blocksize, columns)
         count = i2 - i1
@@ -353,6 +363,8 @@ def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, grou
                     if act_order:
                         idx = perm[idx]
                     quantizer = groups[idx // groupsize]
+            if trace:
+                Win[:, i1 + i] = w
             q = quantizer.quantize(w.unsqueeze(1)).flatten()
             Q1[:, i] = q
             err1 = (w - q) / d
@@ -367,7 +379,10 @@ def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, grou
     if scale == []:
         scale.append(quantizer.scale)
         zero.append(quantizer.zero)
-    return dict(scale=torch.cat(scale, dim=1), zero=torch.cat(zero, dim=1), Q=Q, perm=perm)
+    out = dict(scale=torch.cat(scale, dim=1), zero=torch.cat(zero, dim=1), Q=Q, perm=perm)
+    if trace:
+        out["Win"] = Win
+    return out
 
 
 def quant_weight_w_scale(weight, scale, zp=None, group_size=-1):
@@ -452,17 +467,22 @@ def awq_act_scale(input_val):
 # =====================================================================================================
 # forward
 # =====================================================================================================
-def woq_linear(x, qweight, scales_f16, qzeros, bias, N, K, bits, group_size, compute_dtype=torch.bfloat16, g_idx=None):
-    """INCWeightOnlyLinear.forward (modules.py:594-610) == F.linear(x, recover(), bias), evaluated in fp32 on the
-    weight rounded to `compute_dtype` (SURVEY.md 8(c) comparator (4))."""
-    w = torch.from_numpy(woq_recover(qweight, scales_f16, qzeros, N, K, bits, group_size, g_idx).astype(np.float32))
-    # recover() is exact-product-then-round-to-fp16; the kernels round the exact product to compute_dtype instead
+def woq_dense_weight(qweight, scales_f16, qzeros, N, K, bits, group_size, compute_dtype=torch.bfloat16, g_idx=None):
+    """The dense weight forward() multiplies by: recover() (modules.py:413-443) is the exact product
+    int8(q - zp) * scale rounded once to fp16; the kernels round the same exact product to `compute_dtype` instead."""
     G = scales_f16.shape[0]
     iw, z = woq_unpack_optimum(qweight, qzeros, N, K, G, bits)
     gi = (np.arange(K) // group_size) if g_idx is None else np.asarray(g_idx)
     d = (iw.astype(np.int16) - z[:, gi].astype(np.int16)).astype(np.int8).astype(np.float32)
     s = np.ascontiguousarray(np.asarray(scales_f16).T).astype(np.float32)[:, gi]
-    w = torch.from_numpy(d * s).to(compute_dtype).float()
+    return torch.from_numpy(d * s).to(compute_dtype).float()
+
+
+def woq_linear(x, qweight, scales_f16, qzeros, bias, N, K, bits, group_size, compute_dtype=torch.bfloat16, g_idx=None, dense=None):
+    """INCWeightOnlyLinear.forward (modules.py:594-610) == F.linear(x, recover(), bias), evaluated in fp32 on the
+    weight rounded to `compute_dtype` (SURVEY.md 8(c) comparator (4)).  `dense`: a cached woq_dense_weight(...) of the
+    same arguments (tests that call this many times on one layer)."""
+    w = dense if dense is not None else woq_dense_weight(qweight, scales_f16, qzeros, N, K, bits, group_size, compute_dtype, g_idx)
     y = torch.nn.functional.linear(x.to(compute_dtype).float(), w, None if bias is None else bias.float())
     return y
 
