@@ -9,11 +9,17 @@ random init) with the BASELINE calibration set (128 samples x 2048 tokens, synth
     -> Cholesky-inverse + blocked column loop for the 7 Linears (inc_gptq_quant_block / inc_gptq_lazy_update)
     -> second forward with the quantised weights (feeds the next block) -> on-device packing (inc_woq_pack),
 driven through the public API objects (prepare -> run_fn -> RAWGPTQuantizer.quantize_block).
-`value` = wall-clock seconds to GPTQ-quantise Llama-2-7B (32 such blocks) = 32 * T / (K * N): with N GPUs every rank
-owns different blocks (layer-per-GPU sharding, calibration activations broadcast from rank 0 over RCCL/xGMI inside
-the timed region), so the job finishes N blocks per step time -> "weak" scaling (per-GPU work fixed).
-The second half of the metric, the fused INT4->bf16 dequant-GEMM, is timed on the BASELINE shapes and reported in
-`dequant_gemm`; `roofline` describes the kernel that dominates the step (chosen from the measured breakdown).
+`value` = wall-clock seconds to GPTQ-quantise Llama-2-7B (32 such blocks) = 32 * T / K, T = time of the K timed steps.
+With N > 1 the N ranks quantise ONE model together (neural_compressor_amd/distributed.py, mode "sample+rows", exact
+reference semantics): calibration samples are sharded (block forwards + Hessian accumulation run on 128/N samples per
+rank, no activation crosses GPUs), the i-th distinct Hessian of the block is reduced to rank i % N, factorised there and
+its factor broadcast over RCCL/xGMI, every column loop runs row-sharded and the codes / scales are all-gathered; every
+rank ends with the same packed block.  Total work is fixed -> "strong" scaling; nothing is divided by N.
+`e2e` times the thing the north_star names once more, without extrapolation: a full 32-block model through
+prepare -> run_fn (calibration capture) -> convert, wall-clock.  The second half of the metric, the fused INT4->bf16
+dequant-GEMM, is timed on the BASELINE shapes and reported in `dequant_gemm`; `roofline` describes the kernel that
+dominates the step (chosen from the measured breakdown); `awq_block` / `smoothquant_block` are BASELINE configs #3 / #4
+at full layer size (one block each).
 """
 
 import argparse
@@ -73,15 +79,20 @@ class KernelClock:
 
 
 def _pmc_traffic(key):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes of THIS workload
-    (profiles/r1_pmc/bench_traffic.json, produced by scripts/gpu_pmc_bench.sh: FETCH_SIZE doubled as the MI355X guide
-    prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE); null when no PMC pass has been recorded."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc", "bench_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(key, {}).get("traffic_bytes_per_launch")
-    except Exception:
-        return None
+    """HBM bytes per launch of the roofline kernel.  PMC counters cannot be read from inside the process being timed:
+    they come from separate `rocprofv3 --pmc` passes over THIS command (scripts/gpu_pmc_bench.sh: FETCH_SIZE doubled as
+    the MI355X guide prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE), whose per-launch means are
+    committed under profiles/ (newest round first); null when no PMC pass has been recorded for this kernel."""
+    for rnd in ("r2_pmc", "r1_pmc"):
+        path = os.path.join(ROOT, "profiles", rnd, "bench_traffic.json")
+        try:
+            with open(path) as f:
+                v = json.load(f).get(key, {}).get("traffic_bytes_per_launch")
+            if v is not None:
+                return v, f"profiles/{rnd}/bench_traffic.json"
+        except Exception:
+            pass
+    return None, None
 
 
 def build_model(n_layers, device):
@@ -227,6 +238,91 @@ def cpu_baseline(timeout_s=240):
     )
 
 
+def calib_ids(samples, seq):
+    g = torch.Generator().manual_seed(1)
+    return [torch.randint(0, 32000, (1, seq), generator=g) for _ in range(samples)]
+
+
+def bench_e2e(device, args, rank, world, note):
+    """The north_star's own quantity, not extrapolated: Llama-2-7B-shaped model (32 blocks), GPTQ INT4 g128 sym,
+    `samples` x `seq` calibration tokens, wall-clock of prepare -> run_fn (embedding + capture of block-0 inputs) ->
+    convert (32 blocks, packing included).  Model construction (random init) is outside, like loading a checkpoint."""
+    from neural_compressor_amd import distributed as D
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    model = build_model(args.e2e_blocks, device)
+    ids = calib_ids(args.samples, args.seq)
+    mine = D.shard_samples(len(ids), rank, world) if world > 1 else range(len(ids))
+    cfg = GPTQConfig(bits=4, group_size=128, use_sym=True, block_size=128, percdamp=0.01, act_order=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        model = prepare(model, cfg)
+        for j in mine:
+            model(ids[j].to(device))
+        t1 = time.perf_counter()
+        model = convert(model)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    wall = D.barrier_max_time(time.perf_counter() - t0, device=device)
+    packed = sum(isinstance(m, MI355XWeightOnlyLinear) for m in model.modules())
+    note(f"e2e: {args.e2e_blocks} blocks in {wall:.2f}s ({packed} packed modules)")
+    out = dict(wall_s=round(wall, 3), blocks=args.e2e_blocks, packed_modules=packed, prepare_and_capture_s=round(t1 - t0, 3),
+               samples=args.samples, seq_len=args.seq, n_gpus=world,
+               what="prepare -> run_fn -> convert of a Llama-2-7B-shaped model, wall-clock incl. capture and packing")
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_awq_sq_blocks(device, note):
+    """BASELINE configs #3 (AWQ INT4 g128, auto-scale + auto-clip; one Llama-2-7B-shaped block, 128 x 512 tokens) and #4
+    (SmoothQuant W8A8 calibrate + convert; one Llama-2-13B-shaped block, 32 x 2048 tokens): wall-clock per block."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from neural_compressor_amd.torch.quantization import AWQConfig, SmoothQuantConfig, convert, prepare
+
+    def llama(hidden, inter, heads):
+        cfg = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=1, num_attention_heads=heads,
+                          num_key_value_heads=heads, vocab_size=32000, max_position_embeddings=4096, tie_word_embeddings=False)
+        torch.manual_seed(0)
+        with torch.device(device):
+            m = LlamaForCausalLM(cfg)
+        m = m.to(torch.bfloat16).eval()
+        m.config.use_cache = False
+        return m
+
+    out = {}
+    g = torch.Generator().manual_seed(1)
+    for tag, dims, n, seq, cfg in (
+        ("awq_block", (4096, 11008, 32), 128, 512, AWQConfig(bits=4, group_size=128, use_sym=False, use_auto_scale=True, use_auto_clip=True)),
+        ("smoothquant_block", (5120, 13824, 40), 32, 2048, SmoothQuantConfig(alpha=0.5, folding=False, scale_sharing=True)),
+    ):
+        model = llama(*dims)
+        ids = [torch.randint(0, 32000, (1, seq), generator=g) for _ in range(n)]
+        if tag == "smoothquant_block":
+            cfg.set_local("lm_head", SmoothQuantConfig(w_dtype="fp32"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            model = prepare(model, cfg, example_inputs=ids[0].to(device))
+            for x in ids:
+                model(x.to(device))
+            model = convert(model)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[tag] = dict(seconds_per_block=round(dt, 3), samples=n, seq_len=seq, hidden=dims[0], ffn=dims[1],
+                        model_estimate_s=round(dt * (32 if tag == "awq_block" else 40), 1))
+        note(f"{tag}: {dt:.2f}s")
+        del model
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,8 +330,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--e2e-blocks", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true")
     args = ap.parse_args()
 
     def note(msg):  # progress on stderr: the single JSON line on stdout stays clean
@@ -249,20 +348,24 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1:
+        # ONE model, N ranks: samples sharded, Hessians reduced to their owner rank, factors broadcast, row-sharded solves
+        os.environ["INC_MI355X_GPTQ_MULTI_GPU"] = "sample+rows"
 
     n_blocks = args.warmup + args.steps
     note(f"building {n_blocks}-block Llama-2-7B-shaped model on {device}")
-    model = build_model(n_blocks, device)
-    g = torch.Generator().manual_seed(1)
-    ids = [torch.randint(0, 32000, (1, args.seq), generator=g) for _ in range(args.samples)]
+    model = build_model(n_blocks, device)  # same seed on every rank: the ranks hold replicas of the one model
+    ids = calib_ids(args.samples, args.seq)
+    mine = D.shard_samples(len(ids), rank, world) if world > 1 else range(len(ids))
 
     cfg = GPTQConfig(bits=4, group_size=128, use_sym=True, block_size=128, percdamp=0.01, act_order=False)
     model = prepare(model, cfg)
     with torch.no_grad():
-        for x in ids:  # run_fn: embeddings only, block-0 inputs captured in HBM (gptq.py:413-433 semantics)
-            model(x.to(device))
-    note("calibration inputs captured")
+        for j in mine:  # run_fn: embeddings only, block-0 inputs captured in HBM (gptq.py:413-433 semantics)
+            model(ids[j].to(device))
+    note(f"calibration inputs captured ({len(mine)} of {len(ids)} samples on this rank)")
     rq = model.quantizer.gptq_quantizer
+    assert (rq.dist_ctx is not None) == (world > 1)
     rq.remove_prepare_for_calibration()
     blocks = rq.gptq_related_blocks["transformers"]
 
@@ -271,20 +374,9 @@ def main():
     clock.wrap(ops, "gptq_quant_block", lambda w, *a: "quant_block", lambda w, *a: 2.0 * w.shape[0] * w.shape[1] * 4)
     clock.wrap(ops, "gptq_lazy_update", lambda w, h, e, i1, c: "lazy_update", lambda w, h, e, i1, c: 2.0 * w.shape[0] * c * max(w.shape[1] - i1 - c, 0))
 
-    def one_step(i):
-        if world > 1:
-            # layer-per-GPU sharding: rank 0 holds the float model's activations for the block each rank is about to
-            # quantise and broadcasts them over xGMI (one 2 GiB message), inside the timed region
-            key = "hidden_states" if "hidden_states" in rq.cache_key_arguments else None
-            lst = rq.cache_key_arguments[key] if key else rq.cache_positional_arguments[0]
-            stacked = torch.cat(lst, dim=0)
-            stacked = D.broadcast_calibration(stacked, src=0)
-            lst[:] = list(stacked.split(1, dim=0))
-        rq.quantize_block(blocks[i], i)
-
     with torch.no_grad():
         for i in range(args.warmup):
-            one_step(i)
+            rq.quantize_block(blocks[i], i)
             torch.cuda.synchronize()
             note(f"warmup block {i} done")
         torch.cuda.synchronize()
@@ -293,7 +385,7 @@ def main():
         clock.enabled = True
         t0 = time.perf_counter()
         for i in range(args.warmup, n_blocks):
-            one_step(i)
+            rq.quantize_block(blocks[i], i)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -302,7 +394,7 @@ def main():
     note(f"timed region done: {elapsed:.2f}s for {args.steps} blocks")
     elapsed = D.barrier_max_time(elapsed, device=device)
     ms_per_step = elapsed * 1e3 / args.steps
-    value = 32.0 * elapsed / (args.steps * world)
+    value = 32.0 * elapsed / args.steps  # N ranks work on the SAME blocks: nothing is divided by N
 
     kern = clock.summary()
     breakdown = {k: dict(launches=v["launches"], total_ms=round(v["total_ms"], 3), avg_ms=round(v["avg_ms"], 4)) for k, v in kern.items()}
@@ -316,34 +408,46 @@ def main():
         Kdom = int(dom.split("K")[-1])
         nt = -(-Kdom // 256)
         executed = (nt * (nt + 1) / 2) / (nt * nt)  # the kernel multiplies the upper-triangular 256x256 tiles only
+        all_work = sum(x["work"] for x in hess.values())
+        all_ms = sum(x["total_ms"] for x in hess.values())
+        traffic, traffic_src = _pmc_traffic(dom)
         roofline = dict(kernel=f"hessian_syrk_16bit_256_kernel<bf16> ({dom}; algorithmic flops 2*T*K^2 per launch)", bound="mfma",
                         achieved=round(achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=_pmc_traffic(dom),
+                        frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                         avg_launch_ms=round(v["avg_ms"], 4), launches=v["launches"],
                         tokens_per_launch=int(round(v["work"] / v["launches"] / (2.0 * Kdom * Kdom))),
                         executed_frac=round(achieved * executed / BF16_MFMA_PEAK_TFLOPS, 4),
+                        all_launches_frac=round(all_work / (all_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                         note="algorithmic = the full X^T X product (SURVEY 8d); the syrk kernel executes the upper-triangular tiles "
-                             f"only ({executed:.3f} of it): executed_frac is the matrix-pipe view of the same time")
+                             f"only ({executed:.3f} of it): executed_frac is the matrix-pipe view of the same time; all_launches_frac = "
+                             "algorithmic flops of EVERY Hessian launch of the timed region (all K) / their summed time")
 
     result = dict(
         metric="llama2_7b_gptq_int4_g128_quantize_wall_clock", value=round(value, 3), unit="s", n_gpus=world,
         steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 2), higher_is_better=False,
-        scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+        scaling="strong", vs_baseline=None, dtype="bf16", data="synthetic",
         config=dict(workload="Llama-2-7B GPTQ INT4 group_size=128 sym, 128 calib samples x 2048 tokens; step = one transformer block "
                              "(7 Linears: 4x[4096,4096], 2x[11008,4096], 1x[4096,11008]); value = 32 blocks",
                     samples=args.samples, seq_len=args.seq, block_size=128, percdamp=0.01,
                     arithmetic="bf16 activations/weights (MFMA, fp32 accumulate), fp32 Hessian + Cholesky + column loop, int4 codes",
-                    parallelism=("single GPU" if world == 1 else f"layer-per-GPU x{world}, RCCL broadcast of calibration activations")),
+                    parallelism=("single GPU" if world == 1 else
+                                 f"ONE model on {world} ranks: samples sharded {world}-way, Hessians reduced to owner ranks + factor broadcast "
+                                 "(RCCL), row-sharded column loop + all-gather; exact reference semantics")),
         roofline=roofline, kernel_breakdown=breakdown,
     )
+    del model, rq, blocks
+    torch.cuda.empty_cache()
+    if not args.no_e2e:
+        result["e2e"] = bench_e2e(device, args, rank, world, note)
     if rank == 0 and not args.no_gemm:
-        shapes = [(4096, 4096, 4096), (4096, 11008, 4096), (4096, 4096, 11008), (1, 4096, 4096), (16, 4096, 4096)]
-        del model, rq, blocks
-        torch.cuda.empty_cache()
+        shapes = [(4096, 4096, 4096), (4096, 11008, 4096), (4096, 4096, 11008), (8192, 4096, 4096)]
+        shapes += [(m, 4096, 4096) for m in (1, 16, 32, 64, 128, 256, 512)] + [(1, 11008, 4096), (1, 4096, 11008)]
         result["dequant_gemm"] = bench_dequant_gemm(device, shapes)
         note("dequant-GEMM shapes timed")
         result["w8a8_gemm"] = bench_w8a8_gemm(device, [(4096, 5120, 5120), (4096, 13824, 5120), (4096, 5120, 13824)])
         note("W8A8 shapes timed")
+    if rank == 0 and world == 1 and not args.no_extra_configs:
+        result.update(bench_awq_sq_blocks(device, note))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         note("cpu baseline done")

@@ -45,11 +45,9 @@ int inc_abi_version(void);                 /* bumps on any signature change     
 const char* inc_error_string(int code);    /* static string for an INC_ERR_* code                */
 const char* inc_target_arch(void);         /* "gfx950"                                           */
 
-/* debug (A/B runs): 0 = newest kernels; 1 = route GEMM / Hessian / column loop to their first-generation kernels
- * (which remain the generic fall-backs); 2 = second-generation 256x256 two-stage dequant-GEMM, newest elsewhere;
- * 4 / 6 = the other instruction schedules of the 3A2B dequant-GEMM (compiler-ordered / ping-pong), 20-26 and 31-37 =
- * timing-only ablations of its step (wrong results by construction) -- tools/kbench gemm | ablate                  */
-void inc_debug_set_small_tiles(int on);
+/* The library keeps no mutable process-global state: every call is a function of its arguments and the stream.
+ * (The A/B switch of tools/kbench, inc_debug_set_small_tiles, exists only in the harness build
+ * tools/libinc_mi355x_kbench.so, compiled from the same sources with -DINC_KBENCH.)                              */
 
 /* ---- K1/K2: bit packing ------------------------------------------------------------------- *
  * inc_pack_rows  == INCWeightOnlyLinear.pack_tensor   (weight_only/modules.py:580, :445, :546,
@@ -145,9 +143,12 @@ int inc_groupwise_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_o
                         float* zp_out, int64_t N, int64_t K, int group_size, int bits, int scheme,
                         float quantile, int full_range, inc_stream_t stream);
 
-/* sum((a-b)^2) over n elements -> *out (fp32, accumulated with atomics: zero it first).
- * == the loss of search_clip (utility.py:468) and AWQ's output-MSE (awq.py:336-344, 450-458).   */
-int inc_mse_accumulate(const void* a, const void* b, int dtype, int64_t n, float* out,
+/* *out += sum((a-b)^2) over n elements, in fp64 with a FIXED summation order (same input -> same bits on every
+ * launch; zero *out first).  == the loss of search_clip (utility.py:468) and AWQ's output-MSE (awq.py:336-344,
+ * 450-458), which the reference accumulates in Python doubles and takes an argmin over.  `workspace`: at least
+ * inc_mse_accumulate_workspace_bytes() bytes of caller-owned device memory (per-workgroup partials).              */
+int64_t inc_mse_accumulate_workspace_bytes(void);
+int inc_mse_accumulate(const void* a, const void* b, int dtype, int64_t n, double* out, void* workspace,
                        inc_stream_t stream);
 
 /* ---- K5: GPTQ Hessian accumulation ---------------------------------------------------------- *

@@ -226,10 +226,10 @@ int inc_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, 
                         inc_stream_t stream) {
   INC_CHECK_ARG(A && Linv && n > 0 && n <= CB && lda >= n && ldi >= n);
   const size_t smem = (size_t)(2 * CB * CP + CB * 8 + 64) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  if (inc_attr_needed(attr_set)) {
     (void)hipFuncSetAttribute((const void*)chol_diag_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+    inc_attr_done(attr_set);
   }
   chol_diag_block_kernel<<<1, 256, smem, inc_s(stream)>>>(A, lda, n, Linv, ldi, info, tag);
   INC_LAUNCH_RETURN();

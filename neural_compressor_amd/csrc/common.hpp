@@ -20,11 +20,27 @@ static inline hipStream_t inc_s(inc_stream_t s) { return reinterpret_cast<hipStr
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Debug switch (tools/kbench A/B, tests): route the GEMM / Hessian entry points to their first-generation
-// 128x128 tilings, which stay in the library as the generic fall-back for odd shapes.  Initial value from
-// the environment (INC_MI355X_SMALL_TILES=1), changeable through inc_debug_set_small_tiles().
+// Timing / A-B switch of tools/kbench: routes the GEMM / Hessian entry points to other generations or to timing-only
+// ablations of a kernel.  It exists ONLY in the harness build of the library (tools/Makefile compiles these sources with
+// -DINC_KBENCH into tools/libinc_mi355x_kbench.so); in libinc_mi355x.so the flag is the constant 0, the ablation
+// instantiations are not compiled and there is no process-global state.
+#ifdef INC_KBENCH
 int inc_small_tiles_flag(int set_to);  // defined in pack.hip; set_to < 0 -> query only
+#else
+static inline constexpr int inc_small_tiles_flag(int) { return 0; }
+#endif
 static inline bool inc_force_small_tiles() { return inc_small_tiles_flag(-1) == 1; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: every launcher keeps a static bitmask of
+// the devices it has configured its kernels on.  Thread-safe -- a racing second thread repeats an idempotent call.
+#include <atomic>
+static inline uint64_t inc_device_bit() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return 1ull << (dev & 63);
+}
+static inline bool inc_attr_needed(const std::atomic<uint64_t>& mask) { return !(mask.load(std::memory_order_acquire) & inc_device_bit()); }
+static inline void inc_attr_done(std::atomic<uint64_t>& mask) { mask.fetch_or(inc_device_bit(), std::memory_order_release); }
 
 // ---- 16-bit float <-> fp32 (bit-exact, round-to-nearest-even) -------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {

@@ -1350,11 +1350,11 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 4) < (int64_t)1 << 31;
   if (big8_ok) {
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;
-    static bool a8_attr_set = false;
-    if (!a8_attr_set) {
+    static std::atomic<uint64_t> a8_attr_set{0};
+    if (inc_attr_needed(a8_attr_set)) {
       (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<true, INC_3A2B_DEFAULT_SCHED, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<false, INC_3A2B_DEFAULT_SCHED, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      a8_attr_set = true;
+      inc_attr_done(a8_attr_set);
     }
     const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
     const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
@@ -1377,15 +1377,18 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     }
   } else if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 30) || (dbg >= 31 && dbg <= 37))) {
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
-    static bool a3_attr_set = false;
-    if (!a3_attr_set) {
+    static std::atomic<uint64_t> a3_attr_set{0};
+    if (inc_attr_needed(a3_attr_set)) {
 #define INC_A3_ATTR(B, S) (void)hipFuncSetAttribute((const void*)woq_gemm_w4_3a2b_kernel<B, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
-      INC_A3_ATTR(true, 0); INC_A3_ATTR(true, 1); INC_A3_ATTR(false, INC_3A2B_DEFAULT_SCHED);
+      INC_A3_ATTR(true, INC_3A2B_DEFAULT_SCHED); INC_A3_ATTR(false, INC_3A2B_DEFAULT_SCHED);
+#ifdef INC_KBENCH  // harness build: the other schedules and the timing-only ablations (tools/kbench)
+      INC_A3_ATTR(true, 1 - INC_3A2B_DEFAULT_SCHED);
       INC_A3_ATTR(true, 10); INC_A3_ATTR(true, 11); INC_A3_ATTR(true, 12); INC_A3_ATTR(true, 13); INC_A3_ATTR(true, 14);
       INC_A3_ATTR(true, 15); INC_A3_ATTR(true, 16); INC_A3_ATTR(true, 3); INC_A3_ATTR(true, 17); INC_A3_ATTR(true, 18); INC_A3_ATTR(true, 19); INC_A3_ATTR(true, 20);
       INC_A3_ATTR(true, 31); INC_A3_ATTR(true, 32); INC_A3_ATTR(true, 34); INC_A3_ATTR(true, 37);
+#endif
 #undef INC_A3_ATTR
-      a3_attr_set = true;
+      inc_attr_done(a3_attr_set);
     }
     const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
     const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
@@ -1399,9 +1402,10 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     }
     dim3 g2(grid, (unsigned)splits);
 #define INC_A3(B, S) woq_gemm_w4_3a2b_kernel<B, S><<<g2, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps)
-    // debug flag 4 / 6 time the other schedules of the bf16 kernel (tools/kbench A/B)
-    const int sched = dbg == 4 ? 0 : INC_3A2B_DEFAULT_SCHED;
     if (!bf) INC_A3(false, INC_3A2B_DEFAULT_SCHED);
+#ifdef INC_KBENCH
+    // harness build: flag 4 / 6 time the other schedules of the bf16 kernel, 20..37 its timing-only ablations
+    else if (dbg == 4) INC_A3(true, 1 - INC_3A2B_DEFAULT_SCHED);
     else if (dbg == 6) INC_A3(true, 3);
     else if (dbg == 31) INC_A3(true, 31);
     else if (dbg == 32) INC_A3(true, 32);
@@ -1418,8 +1422,8 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     else if (dbg == 28) INC_A3(true, 18);
     else if (dbg == 29) INC_A3(true, 19);
     else if (dbg == 30) INC_A3(true, 20);
-    else if (sched == 0) INC_A3(true, 0);
-    else INC_A3(true, 1);
+#endif
+    else INC_A3(true, INC_3A2B_DEFAULT_SCHED);
 #undef INC_A3
     if (part) {
       int64_t rb = ceil_div64(M * N / 4, 256);
@@ -1429,11 +1433,11 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     }
   } else if (big_ok && !inc_force_small_tiles()) {
     const size_t smem = (size_t)2 * T_ASTAGE + 2 * T_BSTAGE;  // 128 KiB
-    static bool big_attr_set = false;
-    if (!big_attr_set) {
+    static std::atomic<uint64_t> big_attr_set{0};
+    if (inc_attr_needed(big_attr_set)) {
       (void)hipFuncSetAttribute((const void*)woq_gemm_w4_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)hipFuncSetAttribute((const void*)woq_gemm_w4_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      big_attr_set = true;
+      inc_attr_done(big_attr_set);
     }
     const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
     const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
@@ -1442,13 +1446,13 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   } else if (M > 16) {
     const int x_vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const size_t smem = (size_t)2 * 2 * GM * GP * sizeof(uint16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};
+    if (inc_attr_needed(attr_set)) {
       (void)hipFuncSetAttribute((const void*)woq_gemm_tile_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)hipFuncSetAttribute((const void*)woq_gemm_tile_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)hipFuncSetAttribute((const void*)woq_gemm_tile_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)hipFuncSetAttribute((const void*)woq_gemm_tile_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_set = true;
+      inc_attr_done(attr_set);
     }
     const unsigned grid = (unsigned)(ceil_div64(M, GM) * ceil_div64(N, GN));
 #define INC_TILE(B, F) woq_gemm_tile_kernel<B, F><<<grid, 256, smem, s>>>(xp, qw, scales, qz, g_idx, bp, yp, M, N, K, KW, NW, group_size, x_vec_ok)

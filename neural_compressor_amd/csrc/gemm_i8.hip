@@ -401,11 +401,11 @@ int inc_w8a8_gemm(const int8_t* xq, const int8_t* wq, const float* alpha, const 
   INC_CHECK_ARG(((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(wq)) & 15) == 0);
   INC_CHECK_ARG((int64_t)IM * K < ((int64_t)1 << 32));
   const size_t smem = (size_t)2 * I_STAGE;  // 128 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  if (inc_attr_needed(attr_set)) {
     (void)hipFuncSetAttribute((const void*)w8a8_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)w8a8_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+    inc_attr_done(attr_set);
   }
   if (M <= GV_MAXM) {  // decode: stream the weights once, dot products on the vector ALUs
     const unsigned g = (unsigned)ceil_div64(N, 4 * GV_ROWS);

@@ -901,23 +901,23 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
   } else if (xdtype == INC_BF16 || xdtype == INC_F16) {
     const int vec_ok = (ldx % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const size_t smem = (size_t)2 * 2 * HB * HPITCH * sizeof(uint16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};
+    if (inc_attr_needed(attr_set)) {
       (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr_set = true;
+      inc_attr_done(attr_set);
     }
     if (K >= H2 && vec_ok && (K % 8) == 0 && !inc_force_small_tiles()) {
       const int nt2 = (int)ceil_div64(K, H2);
       const int ntiles2 = nt2 * (nt2 + 1) / 2;
       const size_t smem2 = (size_t)2 * H2_STAGE * sizeof(uint16_t);  // 144 KiB
-      static bool attr2_set = false;
-      if (!attr2_set) {
+      static std::atomic<uint64_t> attr2_set{0};
+      if (inc_attr_needed(attr2_set)) {
         (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-        attr2_set = true;
+        inc_attr_done(attr2_set);
       }
       const uint16_t* xp = (const uint16_t*)x;
       const bool tail = (T % HK) != 0;
@@ -966,12 +966,12 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
   const unsigned blocks = (unsigned)ceil_div64(N, QROWS);
   const float maxq = (float)((1 << bits) - 1);
   hipStream_t s = inc_s(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  if (inc_attr_needed(attr_set)) {
     (void)hipFuncSetAttribute((const void*)gptq_quant_block_kernel<INC_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)gptq_quant_block_kernel<INC_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)gptq_quant_block_kernel<INC_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+    inc_attr_done(attr_set);
   }
   // second-generation kernel: full 128-column block starting on a 128-column boundary, 1 / 2 / 4 groups per block
   int gpb = 0;
@@ -980,13 +980,13 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
   else if (group_size == 32) gpb = 4;
   if (gpb && count == QB && (i1 % QB) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles()) {
     const size_t smem4 = (size_t)QB * QB * 4;  // 64 KiB: Hinv1 tile, reused as the output stage
-    static bool attr4_set = false;
+    static std::atomic<uint64_t> attr4_set{0};
 #define INC_Q4_ATTR(DT, GP) (void)hipFuncSetAttribute((const void*)gptq_quant_block_q4_kernel<DT, GP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)
-    if (!attr4_set) {
+    if (inc_attr_needed(attr4_set)) {
       INC_Q4_ATTR(INC_F32, 1); INC_Q4_ATTR(INC_F32, 2); INC_Q4_ATTR(INC_F32, 4);
       INC_Q4_ATTR(INC_F16, 1); INC_Q4_ATTR(INC_F16, 2); INC_Q4_ATTR(INC_F16, 4);
       INC_Q4_ATTR(INC_BF16, 1); INC_Q4_ATTR(INC_BF16, 2); INC_Q4_ATTR(INC_BF16, 4);
-      attr4_set = true;
+      inc_attr_done(attr4_set);
     }
 #undef INC_Q4_ATTR
     const unsigned blocks4 = (unsigned)ceil_div64(N, Q4R);
@@ -1015,20 +1015,20 @@ int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t 
     int nchunks = (int)ceil_div64(512, row_tiles);  // ~512 workgroups when the trailing matrix is wide enough
     if (nchunks > ncol_tiles) nchunks = ncol_tiles;
     const size_t smem2 = (size_t)2 * L2T * L2T * 4;  // 128 KiB
-    static bool attr2_set = false;
-    if (!attr2_set) {
+    static std::atomic<uint64_t> attr2_set{0};
+    if (inc_attr_needed(attr2_set)) {
       (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-      attr2_set = true;
+      inc_attr_done(attr2_set);
     }
     gptq_lazy_update_v2_kernel<true><<<dim3((unsigned)nchunks, (unsigned)row_tiles), 256, smem2, inc_s(stream)>>>(
         w, Hinv, err, N, K, i1, i2, nchunks, ncol_tiles);
     INC_LAUNCH_RETURN();
   }
   const size_t smem = (size_t)LT * LAP * 4 + (size_t)QB * LT * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  if (inc_attr_needed(attr_set)) {
     (void)hipFuncSetAttribute((const void*)gptq_lazy_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+    inc_attr_done(attr_set);
   }
   dim3 grid((unsigned)ceil_div64(K - i2, LT), (unsigned)ceil_div64(N, LT));
   gptq_lazy_update_kernel<<<grid, 256, smem, inc_s(stream)>>>(w, Hinv, err, N, K, i1, count);

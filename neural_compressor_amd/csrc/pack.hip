@@ -331,18 +331,20 @@ inline int grid_1d(int64_t total, int block = 256) {
 
 }  // namespace
 
-#include <stdlib.h>
+#ifdef INC_KBENCH  // harness build only (tools/Makefile): the A/B switch of tools/kbench
 int inc_small_tiles_flag(int set_to) {
-  static int v = [] { const char* e = getenv("INC_MI355X_SMALL_TILES"); return (e && e[0] == '1') ? 1 : 0; }();
+  static int v = 0;
   if (set_to >= 0) v = set_to;
   return v;
 }
+extern "C" void inc_debug_set_small_tiles(int on) { (void)inc_small_tiles_flag(on < 0 ? 0 : on); }
+#endif
 
 extern "C" {
-void inc_debug_set_small_tiles(int on) { (void)inc_small_tiles_flag(on < 0 ? 0 : on); }
 
-
-int inc_abi_version(void) { return 2; }  // 2: + find_params_mse, awq_repack, sq_*, w8a8_* (SmoothQuant), chol_diag_block
+// 2: + find_params_mse, awq_repack, sq_*, w8a8_* (SmoothQuant), chol_diag_block
+// 3: inc_mse_accumulate sums in fp64 in a fixed order (workspace argument); inc_debug_set_small_tiles left the library
+int inc_abi_version(void) { return 3; }
 const char* inc_target_arch(void) { return "gfx950"; }
 const char* inc_error_string(int code) {
   switch (code) {

@@ -256,13 +256,25 @@ __global__ __launch_bounds__(256) void gptq_find_params_kernel(
   }
 }
 
-// ---- sum((a-b)^2) ---------------------------------------------------------------------------------
+// ---- sum((a-b)^2), fp64, fixed summation order -----------------------------------------------------------
+// The AWQ grid searches (awq.py:336-344, 450-458) and search_clip (utility.py:468) take an argmin over such sums: the
+// reference accumulates them as Python doubles, and an order-dependent fp32 atomic sum would make the chosen grid point
+// vary from run to run.  Pass 1: every workgroup writes ONE fp64 partial (its elements visited in a fixed order, wave
+// and workgroup reductions are fixed trees); pass 2: one workgroup adds the partials in a fixed tree and accumulates
+// into *out.  Same input -> same bits, on any launch.
+constexpr int MSE_MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 template <int DT>
-__global__ __launch_bounds__(256) void mse_accumulate_kernel(const void* __restrict__ a,
-                                                             const void* __restrict__ b, int64_t n,
-                                                             float* __restrict__ out, int vec_ok) {
-  __shared__ float part[4];
-  float acc = 0.f;
+__global__ __launch_bounds__(256) void mse_partial_kernel(const void* __restrict__ a, const void* __restrict__ b, int64_t n,
+                                                          double* __restrict__ partial, int vec_ok) {
+  __shared__ double part[4];
+  double acc = 0.0;
   const int64_t nchunk = (n + 7) / 8;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk;
        c += (int64_t)gridDim.x * blockDim.x) {
@@ -271,16 +283,28 @@ __global__ __launch_bounds__(256) void mse_accumulate_kernel(const void* __restr
     const int nv = left < 8 ? (int)left : 8;
     load8<DT>(a, c * 8, nv, vec_ok != 0, va);
     load8<DT>(b, c * 8, nv, vec_ok != 0, vb);
+    float s8 = 0.f;  // 8 squares in fp32 (what `.float().pow(2)` yields per element), then widened
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float d = round_to<DT>(va[i] - vb[i]);  // the subtraction happens in the tensor dtype
-      acc += d * d;
+      s8 += d * d;
     }
+    acc += (double)s8;
   }
-  acc = wave_sum(acc);
+  acc = wave_sum_f64(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void mse_final_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+  __shared__ double part[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+  acc = wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 inline int team_lanes(int gs) {
@@ -345,15 +369,19 @@ int inc_gptq_find_params_mse(const float* w, int64_t N, int64_t K, int64_t col0,
   INC_LAUNCH_RETURN();
 }
 
-int inc_mse_accumulate(const void* a, const void* b, int dtype, int64_t n, float* out,
+int64_t inc_mse_accumulate_workspace_bytes(void) { return (int64_t)MSE_MAX_BLOCKS * 8; }
+
+int inc_mse_accumulate(const void* a, const void* b, int dtype, int64_t n, double* out, void* workspace,
                        inc_stream_t stream) {
-  INC_CHECK_ARG(a && b && out && n > 0);
+  INC_CHECK_ARG(a && b && out && workspace && n > 0);
   const int vec_ok = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
   int64_t blocks = ceil_div64(ceil_div64(n, 8), 256);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > MSE_MAX_BLOCKS) blocks = MSE_MAX_BLOCKS;
+  double* partial = (double*)workspace;
   INC_DISPATCH_DTYPE(dtype, DT, {
-    mse_accumulate_kernel<DT><<<(unsigned)blocks, 256, 0, inc_s(stream)>>>(a, b, n, out, vec_ok);
+    mse_partial_kernel<DT><<<(unsigned)blocks, 256, 0, inc_s(stream)>>>(a, b, n, partial, vec_ok);
   })
+  mse_final_kernel<<<1, 256, 0, inc_s(stream)>>>(partial, (int)blocks, out);
   INC_LAUNCH_RETURN();
 }
 

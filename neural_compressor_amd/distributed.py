@@ -16,6 +16,19 @@ forms SURVEY.md 8(e) derives from the algorithm's structure:
                 bound by one link, so large H go as reduce-scatter + all-gather (what RCCL's all_reduce does
                 internally for big messages); no activation ever crosses GPUs.
 
+  mode "sample+rows" (exact, what `bench.py --gpus N` times; SURVEY.md 8(e) (i)+(ii)+(iii)): ONE model quantised by N
+                ranks.  Samples are sharded as in mode "sample" (block forwards and Hessian accumulation scale with N, no
+                activation crosses GPUs), but the solve is distributed too instead of being repeated on every rank:
+                  * the i-th DISTINCT Hessian of a block is REDUCED to rank i % N (collective C1 as a reduce), which alone
+                    factorises it -- the four factorisations of a Llama block run on four GPUs at once -- and BROADCASTS
+                    the inverse Cholesky factor (64 / 462 MiB; same bytes on the wire as the all-reduce it replaces);
+                  * every op of the column loop is row-wise (gptq.py:1250-1304), so each rank runs the loop on its slice
+                    of the (N-stacked) weight rows and the codes / Q / scales / zeros are ALL-GATHERED (collective C2,
+                    8-22 MiB per Linear); every rank then holds the same quantised weights for the second forward over
+                    ITS samples and packs the same model.
+                With the same Hessian on every rank (`sample_sharded=False`) the result is bit-identical to the
+                single-process one; with sharded samples it differs by the fp32 summation order of the Hessian only.
+
 Nothing here does arithmetic beyond the collective bookkeeping; the kernels are the same single-GPU HIP kernels.
 """
 
@@ -90,6 +103,92 @@ def allreduce_hessian(H, nsamples, group=None):
     if total > 0:
         H.div_(float(total))
     return H, total
+
+
+def row_shard(n_rows, rank, world, align=64):
+    """Rows [r0, r1) of an [n_rows, ...] solve owned by `rank`, plus the (aligned) shard size all ranks pad to.
+    Shards are multiples of `align` rows (the column-loop kernels work on 16-row waves / 64-row workgroups); trailing
+    ranks may own fewer rows, or none."""
+    shard = -(-n_rows // world)
+    shard = -(-shard // align) * align
+    r0 = min(rank * shard, n_rows)
+    r1 = min(r0 + shard, n_rows)
+    return r0, r1, shard
+
+
+class CalibrationGroup:
+    """The collectives of mode "sample+rows" on one process group (default: the world).
+
+    backend "nccl" (= RCCL) moves HBM-resident tensors over xGMI in place; under "gloo" (CPU tests, or two test
+    processes sharing one GPU) device tensors are staged through the host, synchronously."""
+
+    def __init__(self, group=None):
+        assert dist.is_initialized(), "initialise torch.distributed first (distributed.init_from_env)"
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+
+    def _global(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def owner(self, index):
+        """Rank that factorises the index-th distinct Hessian of a block (the expensive K=11008 one is the last of a
+        Llama block and lands on its own rank for world >= 4)."""
+        return index % self.world
+
+    def _staged(self, t):
+        return self.backend == "gloo" and t.is_cuda
+
+    def all_reduce(self, t):
+        if self._staged(t):
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def reduce(self, t, dst):
+        """Sum onto rank `dst` (other ranks' buffers are left undefined)."""
+        if self._staged(t):
+            host = t.cpu()
+            dist.reduce(host, dst=self._global(dst), op=dist.ReduceOp.SUM, group=self.group)
+            if self.rank == dst:
+                t.copy_(host)
+        else:
+            dist.reduce(t, dst=self._global(dst), op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def broadcast(self, t, src, async_op=False):
+        """Returns a handle with .wait() when async_op (None when the transfer already completed)."""
+        if self._staged(t):
+            host = t.cpu() if self.rank == src else torch.empty(t.shape, dtype=t.dtype)
+            dist.broadcast(host, src=self._global(src), group=self.group)
+            if self.rank != src:
+                t.copy_(host)
+            return None
+        work = dist.broadcast(t, src=self._global(src), group=self.group, async_op=async_op)
+        return work if async_op else None
+
+    def all_gather_rows(self, local, n_rows, shard):
+        """Concatenate the ranks' row slices (`row_shard` partition) of an [n_rows, ...] tensor; `local` may be empty."""
+        tail = tuple(local.shape[1:])
+        padded = torch.zeros((shard,) + tail, dtype=local.dtype, device=local.device)
+        if local.shape[0]:
+            padded[: local.shape[0]].copy_(local)
+        out = torch.empty((self.world * shard,) + tail, dtype=local.dtype, device=local.device)
+        if self._staged(local):
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, padded.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, padded, group=self.group)
+        if self.world * shard == n_rows:
+            return out
+        # ranks own [r*shard, min((r+1)*shard, n_rows)): only the last non-empty shard is short, so the valid rows are
+        # exactly the first n_rows of the concatenation
+        return out[:n_rows].contiguous()
 
 
 def shard_samples(n_samples, rank, world):

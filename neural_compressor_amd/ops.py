@@ -279,14 +279,21 @@ def groupwise_quant(w, bits, group_size, scheme, quantile=1.0, full_range=False,
     return qdq
 
 
+_MSE_WS = {}
+
+
 def mse_accumulate(a, b, out=None):
-    """out += sum((a-b)^2) (fp32 scalar tensor on device)."""
+    """out += sum((a-b)^2): fp64 scalar tensor on device, fixed summation order (same input -> same bits)."""
     dev = _dev(a, b)
     assert a.dtype == b.dtype and a.numel() == b.numel()
     if out is None:
-        out = torch.zeros(1, dtype=torch.float32, device=dev)
+        out = torch.zeros(1, dtype=torch.float64, device=dev)
+    assert out.dtype == torch.float64
+    ws = _MSE_WS.get(dev)
+    if ws is None:  # per-workgroup partials; calls on one device are stream-ordered, so one buffer per device
+        ws = _MSE_WS[dev] = torch.empty(int(lib.inc_mse_accumulate_workspace_bytes()) // 8, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        check(lib.inc_mse_accumulate(_ptr(a), _ptr(b), dtype_code(a.dtype), a.numel(), _ptr(out), _stream()), "inc_mse_accumulate")
+        check(lib.inc_mse_accumulate(_ptr(a), _ptr(b), dtype_code(a.dtype), a.numel(), _ptr(out), _ptr(ws), _stream()), "inc_mse_accumulate")
     return out
 
 

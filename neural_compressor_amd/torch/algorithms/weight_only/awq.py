@@ -254,11 +254,12 @@ def _get_act_scale(input_val):
 
 
 class _Loss:
-    """sum over batches of mean((a-b)^2), kept on the device (reference: `.item()` per batch)."""
+    """sum over batches of mean((a-b)^2), kept on the device (reference: `.item()` per batch, added up as Python
+    doubles): fp64, fixed summation order (inc_mse_accumulate), so the argmin over a grid is reproducible."""
 
     def __init__(self, device):
-        self.sum = torch.zeros(1, dtype=torch.float32, device=device)
-        self.val = torch.zeros(1, dtype=torch.float32, device=device)
+        self.sum = torch.zeros(1, dtype=torch.float64, device=device)
+        self.val = torch.zeros(1, dtype=torch.float64, device=device)
 
     def add(self, a, b, n=1):
         """`n`: how many equally sized calibration batches `a` / `b` hold (stacked along dim 0 by the batched search):
@@ -294,6 +295,9 @@ class ActAwareWeightQuant:
         self.use_full_range = use_full_range
         self.weight_config = weight_config
         self.absorb_layer_dict = absorb_layer_dict
+        # what the two grid searches saw: {"scale": {"name|name": (loss history, chosen index)}, "clip": {name: (...)}};
+        # left on the converted model as `awq_search_log` (diagnostics / parity tests; the reference only logs them)
+        self.search_log = {"scale": {}, "clip": {}}
 
     # -- absorb bookkeeping --------------------------------------------------------------------------
     def _absorb_for_block(self, i, folding):
@@ -364,6 +368,7 @@ class ActAwareWeightQuant:
             if use_mse_search:
                 self.search_clip(block_name, module_list, input_values)
         self.apply_quantize_with_clip(return_int)
+        self.model.awq_search_log = self.search_log
         return self.model
 
     # -- scale search (reference :264-361) ---------------------------------------------------------------
@@ -411,6 +416,7 @@ class ActAwareWeightQuant:
             for i_, v in enumerate(hist):
                 if v < best:  # first strict minimum, like the reference's scan
                     best, best_i = v, i_
+            self.search_log["scale"]["|".join(module_tuple)] = (hist, best_i)
             assert best_i is not None, "Loss is infinity! Cannot find the correct scale."
             best_scales = cand[best_i].view(-1)
             assert torch.isnan(best_scales).sum() == 0, best_scales
@@ -471,6 +477,7 @@ class ActAwareWeightQuant:
                 for r_, v in zip(ratios, hist):
                     if v < best:
                         best, best_ratio = v, r_
+                self.search_log["clip"][module_name] = (hist, ratios.index(best_ratio))
                 logger.debug("The loss history of different clip range: %s", hist)
                 if module_name not in self.weight_config:
                     self.weight_config[module_name] = {"bits": cur_bits, "group_size": cur_group_size, "scheme": cur_scheme}

@@ -90,7 +90,7 @@ _EXACT_TRIO = os.environ.get("INC_MI355X_CHOLESKY_TRIO", "0") == "1"
 
 
 @torch.no_grad()
-def inverse_cholesky_upper(H):
+def inverse_cholesky_upper(H, check=True):
     """Upper Cholesky factor U of H^-1 (H^-1 = U^T U) for a symmetric positive definite fp32 H [K,K] in HBM.
 
     The reference gets it from three LAPACK factorisations (potrf -> potri -> potrf, gptq.py:1228-1230); on the GPU
@@ -103,7 +103,8 @@ def inverse_cholesky_upper(H):
       * panel solve  L[i>j, j] = A[i>j, j] @ inv(L_jj)^T  and trailing update  A[i>j, i>j] -= L_panel L_panel^T: fp32 GEMMs;
       * Lr^-1 by recursive doubling: inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]], all pairs of a level independent.
     The GEMMs are the fp32 library GEMMs torch dispatches to (plumbing, like torch.linalg was before); a non-positive
-    pivot raises like torch.linalg.cholesky does.
+    pivot raises like torch.linalg.cholesky does.  `check=False` returns (U, info) without reading `info` back (no
+    host synchronisation): the caller checks it later with `raise_if_not_spd`.
     """
     assert H.dim() == 2 and H.shape[0] == H.shape[1] and H.dtype == torch.float32
     K = H.shape[0]
@@ -140,10 +141,19 @@ def inverse_cholesky_upper(H):
         if len(segs) % 2:
             nxt.append(segs[-1])
         segs = nxt
-    if int(info.item()) != 0:
+    U = torch.flip(X[:K, :K], (0, 1)).contiguous()
+    if not check:
+        return U, info
+    raise_if_not_spd(info)
+    return U
+
+
+def raise_if_not_spd(info):
+    """Host-side check of the status word written by inc_chol_diag_block (synchronises with the device)."""
+    bad = int(info.item())
+    if bad != 0:
         raise torch.linalg.LinAlgError(
-            f"inverse_cholesky_upper: the matrix is not positive definite (pivot <= 0 in diagonal block {int(info.item())})")
-    return torch.flip(X[:K, :K], (0, 1)).contiguous()
+            f"inverse_cholesky_upper: the matrix is not positive definite (pivot <= 0 in diagonal block {bad})")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -171,6 +181,8 @@ class HessianAccumulator:
         self._stage = None    # [capacity tokens, K] staging buffer in the activation dtype
         self._fill = 0
         self.finalized = None  # (Hinv, dead, perm) cache keyed by (percdamp, act_order)
+        self._info = None      # status word of a factorisation whose check was deferred (see check())
+        self._handles = None   # pending broadcasts of a factor received from its owner rank (mode "sample+rows")
 
     @property
     def nsamples(self):
@@ -221,6 +233,10 @@ class HessianAccumulator:
         sharing the accumulator factorise once."""
         key = (float(percdamp), bool(act_order))
         if self.finalized is not None and self.finalized[0] == key:
+            if self._handles:  # the factor is arriving from its owner rank: order this stream behind the transfers
+                for h in self._handles:
+                    h.wait()
+                self._handles = None
             return self.finalized[1:]
         self.flush()
         self._stage = None
@@ -240,10 +256,51 @@ class HessianAccumulator:
             Hinv = torch.linalg.cholesky(Hi, upper=True).contiguous()
             del Hi
         else:
-            Hinv = inverse_cholesky_upper(H)
+            Hinv, self._info = inverse_cholesky_upper(H, check=False)
         self.H = None
         self.finalized = (key, Hinv, dead, perm)
         return Hinv, dead, perm
+
+    def check(self):
+        """Raise if the (deferred) factorisation met a non-positive pivot; one host synchronisation."""
+        if self._info is not None:
+            info, self._info = self._info, None
+            raise_if_not_spd(info)
+
+    # -- mode "sample+rows" (neural_compressor_amd/distributed.py) ------------------------------------------------------
+    def reduce_to_owner(self, ctx, owner, n_total):
+        """Sample-sharded calibration: sum the ranks' Hessians onto `owner` (H = sum_r (n_r / n) H_r, exact up to fp32
+        summation order); the other ranks drop theirs."""
+        self.flush()
+        self._stage = None
+        if self.H is None:  # this rank saw no batch for the layer
+            self.H = torch.zeros((self.columns, self.columns), dtype=torch.float32, device=self.device)
+        self.H.mul_(float(self._n))
+        ctx.reduce(self.H, dst=owner)
+        if ctx.rank == owner:
+            if n_total > 0:
+                self.H.div_(float(n_total))
+        else:
+            self.H = None
+        self._n = int(n_total)
+
+    def exchange_factor(self, ctx, owner, percdamp, act_order):
+        """The owner factorises; every other rank receives (Hinv, dead, perm) by broadcast (asynchronously under RCCL:
+        `inverse_factor` waits on the handles when a solve first needs the factor)."""
+        if ctx.rank == owner:
+            Hinv, dead, perm = self.inverse_factor(percdamp, act_order)
+        else:
+            self.flush()
+            self._stage, self.H = None, None
+            K = self.columns
+            Hinv = torch.empty((K, K), dtype=torch.float32, device=self.device)
+            dead = torch.empty(K, dtype=torch.uint8, device=self.device)
+            perm = torch.empty(K, dtype=torch.int64, device=self.device) if act_order else None
+            self.finalized = ((float(percdamp), bool(act_order)), Hinv, dead, perm)
+        handles = [ctx.broadcast(t, owner, async_op=True) for t in (Hinv, dead, perm) if t is not None]
+        handles = [h for h in handles if h is not None]
+        if ctx.rank != owner and handles:
+            self._handles = handles
 
 
 class GPTQ:
@@ -259,6 +316,7 @@ class GPTQ:
         self.acc = accumulator or HessianAccumulator(self.columns, device)
         self.perm = None
         self.cfg = {}
+        self.row_ctx = None  # distributed.CalibrationGroup: solve only this rank's weight rows, all-gather the results
 
     # the reference's Quantizer.configure (gptq.py:1375) copies the per-layer dict onto the quantizer
     def configure(self, weight_config_this_layer):
@@ -291,8 +349,17 @@ class GPTQ:
         if self.is_conv1d:
             W = W.t()
         W = W.contiguous()
-        N, K = W.shape
+        N_all, K = W.shape
         tick = time.time()
+        ctx = self.row_ctx
+        if ctx is not None:
+            # every op below is row-wise given Hinv (gptq.py:1250-1304): this rank solves rows [r0, r1) of the (stacked)
+            # weight; codes / Q / scale / zero of all ranks are all-gathered at the end (collective C2)
+            from ....distributed import row_shard
+
+            r0, r1, shard = row_shard(N_all, ctx.rank, ctx.world)
+            W = W[r0:r1].contiguous()
+        N = W.shape[0]
 
         Hinv, dead, perm = self.acc.inverse_factor(percdamp, act_order)
         gs = K if (groupsize == -1 or groupsize >= K) else int(groupsize)
@@ -300,13 +367,16 @@ class GPTQ:
         scale = torch.empty((N, G), dtype=torch.float32, device=W.device)
         zero = torch.empty((N, G), dtype=torch.float32, device=W.device)
 
-        if groupsize == -1:
+        if N == 0:  # this rank owns no row of a small layer: it only takes part in the all-gather below
+            w32 = torch.empty((0, K), dtype=torch.float32, device=W.device)
+        elif groupsize == -1:
             # per-channel parameters come from W before dead columns are zeroed (gptq.py:1180-1189 order)
             w32 = ops.gptq_prepare_weight(W, None)
             ops.gptq_find_params(w32, 0, K, 1, bits, sym, scale, zero, 0, mse=mse)
             del w32
-        w32 = ops.gptq_prepare_weight(W, dead)
-        if static_groups:
+        if N > 0:
+            w32 = ops.gptq_prepare_weight(W, dead)
+        if static_groups and N > 0:
             ops.gptq_find_params(w32, 0, gs, G, bits, sym, scale, zero, 0, mse=mse)
         loop_scale, loop_zero = scale, zero
         if act_order:
@@ -327,7 +397,7 @@ class GPTQ:
         if loop_scale is not scale:
             kernel_gs = 1
         blocksize = int(blocksize) if blocksize and blocksize > 0 else K
-        i1 = 0
+        i1 = 0 if N > 0 else K
         while i1 < K:
             ref_end = min((i1 // blocksize + 1) * blocksize, K)  # end of the reference's block (gptq.py:1250)
             count = min(QBLOCK, ref_end - i1)
@@ -342,6 +412,11 @@ class GPTQ:
             i1 += count
         logger.debug("fasterquant %dx%d issued in %.3fs", N, K, time.time() - tick)
 
+        if ctx is not None:
+            codes = ctx.all_gather_rows(codes, N_all, shard)
+            Q = ctx.all_gather_rows(Q, N_all, shard)
+            scale = ctx.all_gather_rows(scale, N_all, shard)
+            zero = ctx.all_gather_rows(zero, N_all, shard)
         if act_order:
             invperm = torch.argsort(perm)
             Q = Q[:, invperm].contiguous()
@@ -399,10 +474,28 @@ class RAWGPTQuantizer(object):
         # sample-sharded multi-GPU calibration: every rank feeds ITS calibration samples through prepare()/run_fn and the
         # per-layer Hessians are all-reduced before each solve; pass True (default process group) or a process group
         self.hessian_allreduce = kwargs.get("hessian_allreduce", None)
-        if self.hessian_allreduce is None and os.environ.get("INC_MI355X_GPTQ_SAMPLE_SHARDED", "0") == "1":
+        # mode "sample+rows" / "rows" (distributed.py): the i-th distinct Hessian of a block is factorised on rank
+        # i % world only and its factor broadcast, every solve is row-sharded and all-gathered.  Pass True (default
+        # process group) or a process group; together with hessian_allreduce the Hessians are REDUCED to the owner
+        # (samples sharded), without it every rank is expected to have seen all samples.
+        self.row_shard_solve = kwargs.get("row_shard_solve", None)
+        mode = os.environ.get("INC_MI355X_GPTQ_MULTI_GPU", "")
+        if os.environ.get("INC_MI355X_GPTQ_SAMPLE_SHARDED", "0") == "1" and not mode:
+            mode = "sample"
+        if mode and (self.hessian_allreduce is None and self.row_shard_solve is None):
             import torch.distributed as dist
 
-            self.hessian_allreduce = bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+            live = bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+            assert mode in ("sample", "rows", "sample+rows"), f"INC_MI355X_GPTQ_MULTI_GPU={mode!r}"
+            self.hessian_allreduce = live and mode in ("sample", "sample+rows")
+            self.row_shard_solve = live and mode in ("rows", "sample+rows")
+        self.dist_ctx = None
+        if self.row_shard_solve:
+            from ....distributed import CalibrationGroup
+
+            self.dist_ctx = CalibrationGroup(None if self.row_shard_solve is True else self.row_shard_solve)
+            if self.dist_ctx.world == 1:
+                self.dist_ctx = None
 
     # -- config handling (reference :330-398) --------------------------------------------------------
     _DEFAULTS = dict(
@@ -575,6 +668,22 @@ class RAWGPTQuantizer(object):
         self._fgroups = (batch_num, groups)
         return groups
 
+    def _exchange_factors(self, distinct):
+        """Mode "sample+rows": combine the sharded Hessians on their owner ranks, factorise there, broadcast the factors.
+        Every rank walks the accumulators in the same order (collectives match up); a rank factorises ITS Hessian right
+        before broadcasting it and has already posted the receives of the cheaper ones ahead of it."""
+        ctx = self.dist_ctx
+        if self.hessian_allreduce:
+            for acc, _, _ in distinct:
+                acc.flush()
+            counts = torch.tensor([float(acc._n) for acc, _, _ in distinct], dtype=torch.float64,
+                                  device="cpu" if ctx.backend == "gloo" else self.device)
+            counts = ctx.all_reduce(counts).tolist()  # a handful of scalars
+            for i, (acc, _, _) in enumerate(distinct):
+                acc.reduce_to_owner(ctx, ctx.owner(i), int(round(counts[i])))
+        for i, (acc, percdamp, act_order) in enumerate(distinct):
+            acc.exchange_factor(ctx, ctx.owner(i), percdamp, act_order)
+
     # -- the main loop (reference :568-887) ----------------------------------------------------------------
     @torch.no_grad()
     def execute_quantization(self, means=None, stds=None):
@@ -621,6 +730,11 @@ class RAWGPTQuantizer(object):
             else:
                 layer(self.cache_positional_arguments[0][j])
         handle.remove()
+        if self.dist_ctx is not None:
+            self._exchange_factors([(solver.acc, cfg["percdamp"], cfg["act_order"])])
+            solver.row_ctx = self.dist_ctx
+        elif self.hessian_allreduce:
+            solver.acc.allreduce(None if self.hessian_allreduce is True else self.hessian_allreduce)
         scale, _, zp, Q = solver.fasterquant(
             layer.weight.data, blocksize=cfg["block_size"], percdamp=cfg["percdamp"], groupsize=cfg["group_size"],
             act_order=cfg["act_order"], hybrid_order=cfg["hybrid_order"], fp8_aware=cfg["fp8_aware"],
@@ -636,6 +750,7 @@ class RAWGPTQuantizer(object):
             zp=zero is not None, bias=layer.bias is not None, g_idx=solver.export_perm is not None, device=self.device,
         )
         new_module.pack_codes(solver.codes, scale, zero, layer.bias, g_idx=solver.export_perm)
+        solver.acc.check()
         solver.free()
         set_module(self.model, full, new_module)
 
@@ -690,14 +805,20 @@ class RAWGPTQuantizer(object):
                     solvers[name].acc = solvers[owner].acc
                 else:  # pragma: no cover - different damping per layer: cannot share the factorisation
                     raise RuntimeError(f"{name} shares its input with {owner} but not its GPTQ settings; pass share_hessians=False")
-            if self.hessian_allreduce:
+            distinct, seen = [], set()
+            for name in layers:  # same order on every rank
+                acc = solvers[name].acc
+                if id(acc) not in seen:
+                    seen.add(id(acc))
+                    distinct.append((acc, solvers[name].cfg["percdamp"], solvers[name].cfg["act_order"]))
+            if self.dist_ctx is not None:
+                self._exchange_factors(distinct)
+                for sv in solvers.values():
+                    sv.row_ctx = self.dist_ctx
+            elif self.hessian_allreduce:
                 group = None if self.hessian_allreduce is True else self.hessian_allreduce
-                done = set()
-                for name in layers:  # same order on every rank: one all-reduce per DISTINCT accumulator
-                    acc = solvers[name].acc
-                    if id(acc) not in done:
-                        done.add(id(acc))
-                        acc.allreduce(group)
+                for acc, _, _ in distinct:  # one all-reduce per DISTINCT accumulator
+                    acc.allreduce(group)
             # Step 2.4: solve (reference :690-747).  The column loop treats every weight ROW independently, so Linears
             # that share one Hessian (q/k/v, gate/up) and one GPTQ setting are stacked along N and solved in ONE pass:
             # a third of the serial 128-column steps and three times the rows in flight per step, same results.
@@ -740,9 +861,11 @@ class RAWGPTQuantizer(object):
                                       zero=None if cfg["sym"] else (zp if one else zp[sl].contiguous()), perm=perm,
                                       codes=codes if one else codes[sl].contiguous())
                     solvers[n].perm = perm
-                for n in names:
-                    solvers[n].free()
-            del solvers
+            for acc, _, _ in distinct:
+                acc.check()  # deferred "not positive definite" checks of this group's factorisations (one sync each)
+            for n in list(solvers):
+                solvers[n].free()
+            del solvers, distinct
             # Step 2.5: outputs of the quantised block become the next block's inputs (reference :749-762)
             def replace(j, out):
                 if "hidden_states" in self.cache_key_arguments:
@@ -783,7 +906,7 @@ class GPTQuantizer(INCQuantizer):
             model, weight_config=self.quant_config, nsamples=nsamples, use_max_length=use_max_length,
             max_seq_length=max_seq_length, device=device, use_layer_wise=use_layer_wise, model_path=model_path,
             quant_lm_head=quant_lm_head, use_block_wise=use_block_wise,
-            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback", "hessian_allreduce")},
+            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback", "hessian_allreduce", "row_shard_solve")},
         )
         self.gptq_quantizer.prepare_for_calibration()
         return self.gptq_quantizer.model

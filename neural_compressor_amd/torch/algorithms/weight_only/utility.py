@@ -54,7 +54,7 @@ def search_clip(m, bits=4, group_size=32, scheme="asym", dtype="int", enable_ful
         w = w.contiguous()
     n_grid, max_shrink = 200, 0.2
     n_try = int(max_shrink * n_grid)
-    losses = torch.zeros(n_try, dtype=torch.float32, device=w.device)
+    losses = torch.zeros(n_try, dtype=torch.float64, device=w.device)
     tmp = torch.empty_like(w)
     ratios = []
     for i_s in range(n_try):
@@ -63,8 +63,9 @@ def search_clip(m, bits=4, group_size=32, scheme="asym", dtype="int", enable_ful
         tmp.copy_(w)
         ops.groupwise_quant(tmp, bits, group_size, scheme, quantile=ratio, full_range=enable_full_range, inplace=True)
         ops.mse_accumulate(w, tmp, out=losses[i_s : i_s + 1])
-    # first strict minimum, like the reference's `loss < best_error` scan; mean = sum / numel is monotone
-    vals = losses.tolist()
+    # first strict minimum, like the reference's `loss < best_error` scan over fp32 means (`.float().pow(2).mean()`):
+    # the fp64 fixed-order sums are rounded to fp32 means before they are compared
+    vals = (losses / w.numel()).float().tolist()
     best, best_ratio = float("inf"), None
     for ratio, v in zip(ratios, vals):
         if v < best:

@@ -464,6 +464,51 @@ def awq_act_scale(input_val):
     return tmp.mean(0)
 
 
+def awq_search_scale_module(weight, bias, input_val, group_size=32, scheme="asym", full_range=False):
+    """ActAwareWeightQuant.search_scale (awq.py:264-361) for a module tuple of ONE Linear (the `module_inference`
+    branch :311-313, :340-342): the 20-point alpha grid.  `input_val`: list of [.., K] activations of that Linear.
+    Returns dict(history [20 python floats], best_index, best_scales [K]).  The search quantises as 4-bit integers
+    whatever the configured width (the reference passes `num_bits=` / `data_type=`, which quant_tensor swallows)."""
+    w_max = awq_weight_scale(weight, q_group_size=group_size)
+    x_max = awq_act_scale(input_val)
+    org_out = [torch.nn.functional.linear(x, weight, bias) for x in input_val]
+    best_error, best_scales, best_i, history = float("inf"), None, None, []
+    n_grid = 20
+    for step in range(n_grid):
+        ratio = step * 1 / n_grid
+        scales = (x_max.pow(ratio) / w_max.pow(1 - ratio)).clamp(min=1e-4).view(-1)
+        scales = scales / (scales.max() * scales.min()).sqrt()
+        wq = quant_tensor(weight.mul(scales.view(1, -1)), bits=4, group_size=group_size, scheme=scheme, full_range=full_range) / scales.view(1, -1)
+        loss = 0
+        for x, o1 in zip(input_val, org_out):
+            o2 = torch.nn.functional.linear(x, wq, bias)
+            loss += (o1 - o2).float().pow(2).mean().item()
+        history.append(loss)
+        if loss < best_error:
+            best_error, best_scales, best_i = loss, scales, step
+    return dict(history=history, best_index=best_i, best_scales=best_scales.view(-1))
+
+
+def awq_search_clip_module(weight, bias, input_val, group_size=32, scheme="asym", full_range=False, input_scale=None):
+    """ActAwareWeightQuant.search_clip (awq.py:393-470) for one module: 10 clip ratios 1.00 .. 0.91, output-MSE criterion.
+    `input_scale` [K]: the module is a MulLinear (modules.py:907-949: forward = linear(x * input_scale))."""
+    xs = input_val if input_scale is None else [x * input_scale for x in input_val]
+    org_out = [torch.nn.functional.linear(x, weight, bias) for x in xs]
+    best_error, best_ratio, best_i, history = float("inf"), None, None, []
+    n_grid, max_shrink = 100, 0.1
+    for i_s in range(int(max_shrink * n_grid)):
+        ratio = 1 - i_s / n_grid
+        wq = quant_tensor(weight, bits=4, group_size=group_size, scheme=scheme, full_range=full_range, quantile=ratio)
+        loss = 0
+        for x, o1 in zip(xs, org_out):
+            o2 = torch.nn.functional.linear(x, wq, bias)
+            loss += (o1 - o2).float().pow(2).mean().item()
+        history.append(loss)
+        if loss < best_error:
+            best_error, best_ratio, best_i = loss, ratio, i_s
+    return dict(history=history, best_index=best_i, best_ratio=best_ratio)
+
+
 # =====================================================================================================
 # forward
 # =====================================================================================================

@@ -46,7 +46,27 @@ def _worker(rank, world, port, out):
     got = D.broadcast_calibration(acts, src=1, shape=(2, 3, 4), dtype=torch.float32, device="cpu")
     ok_b = torch.equal(got, torch.arange(24, dtype=torch.float32).reshape(2, 3, 4))
     t = D.barrier_max_time(float(rank + 1), device="cpu")
-    out[rank] = (ok_h, ok_b, owners, D.blocks_of_rank(5, rank, world), t)
+    # --- mode "sample+rows": reduce to the owner, factor broadcast, row-sharded solve + all-gather
+    ctx = D.CalibrationGroup()
+    assert (ctx.rank, ctx.world) == (rank, world) and [ctx.owner(i) for i in range(4)] == [0, 1, 0, 1]
+    part = torch.full((3, 3), float(rank + 1))
+    ctx.reduce(part, dst=1)
+    ok_r = rank != 1 or torch.equal(part, torch.full((3, 3), 3.0))
+    fac = torch.arange(6.0).reshape(2, 3) if rank == 1 else torch.empty(2, 3)
+    h = ctx.broadcast(fac, src=1, async_op=True)
+    if h is not None:
+        h.wait()
+    ok_r = ok_r and torch.equal(fac, torch.arange(6.0).reshape(2, 3))
+    cnt = ctx.all_reduce(torch.tensor([1.0, 2.0 + rank], dtype=torch.float64)).tolist()
+    ok_r = ok_r and cnt == [2.0, 5.0]
+    ok_g = True
+    for n_rows in (200, 128, 70, 1):  # uneven shards, an exactly divisible case, a rank that owns nothing
+        r0, r1, shard = D.row_shard(n_rows, rank, world)
+        full = torch.arange(n_rows * 2, dtype=torch.float32).reshape(n_rows, 2)
+        got_rows = ctx.all_gather_rows(full[r0:r1].contiguous(), n_rows, shard)
+        got_u8 = ctx.all_gather_rows(full[r0:r1, :1].to(torch.uint8).contiguous(), n_rows, shard)
+        ok_g = ok_g and torch.equal(got_rows, full) and torch.equal(got_u8, full[:, :1].to(torch.uint8)) and shard % 64 == 0
+    out[rank] = (ok_h, ok_b, owners, D.blocks_of_rank(5, rank, world), t, ok_r, ok_g)
     dist.destroy_process_group()
 
 
@@ -58,8 +78,8 @@ def test_gloo_world2():
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         res = dict(out)
     for rank in range(world):
-        ok_h, ok_b, owners, mine, t = res[rank]
-        assert ok_h and ok_b
+        ok_h, ok_b, owners, mine, t, ok_r, ok_g = res[rank]
+        assert ok_h and ok_b and ok_r and ok_g
         assert owners == [0, 1, 0, 1, 0]
         assert mine == ([0, 2, 4] if rank == 0 else [1, 3])
         assert t == 2.0
@@ -74,3 +94,10 @@ def test_single_process_paths_are_identity():
     assert D.shard_samples(10, 1, 4) == [3, 4, 5]
     assert sum(len(D.shard_samples(10, r, 4)) for r in range(4)) == 10
     assert D.barrier_max_time(1.5) == 1.5
+    # row partition: aligned shards that cover every row exactly once, trailing ranks may be empty
+    for n_rows, world in ((4096, 8), (22016, 8), (12288, 3), (100, 4), (1, 2)):
+        parts = [D.row_shard(n_rows, r, world) for r in range(world)]
+        assert all(p[2] == parts[0][2] and p[2] % 64 == 0 for p in parts)
+        assert parts[0][0] == 0 and parts[-1][1] == n_rows
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert all(p[0] == min(r * p[2], n_rows) for r, p in enumerate(parts))

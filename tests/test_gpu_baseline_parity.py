@@ -283,3 +283,72 @@ def test_fused_gemm_baseline_shapes_vs_oracle(hip, M, N, K):
     print(f"\n[fused gemm M={M} N={N} K={K}] vs oracle rounded to bf16 {e_round:.2e}, vs oracle fp32 {e_exact:.2e}")
     assert e_round <= 1e-3
     assert e_exact <= 4e-3  # bf16 output rounding alone is 2^-9 / sqrt(3) ~ 1.1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# (e) AWQ grid searches at a BASELINE-size layer against the oracle
+# ---------------------------------------------------------------------------------------------------
+def test_awq_scale_and_clip_search_4096_vs_oracle(hip):
+    """ActAwareWeightQuant.search_scale / apply_scale / search_clip (awq.py:264-361, 364-391, 393-470) on one
+    self-absorbed 4096x4096 Linear, g128 asym, 8 x 256 calibration tokens, fp32: all 20 + 10 losses and both chosen grid
+    points against `O.awq_search_scale_module` / `O.awq_search_clip_module` (pinned to the unmodified reference's own
+    traces by tests/test_oracle_golden.py).  At this size one flipped rounding tie moves a loss by ~1e-7, so the loss
+    curves must agree to float noise and the argmins exactly."""
+    from neural_compressor_amd.torch.algorithms.weight_only.awq import ActAwareWeightQuant
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MulLinear
+
+    N = K = 4096
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(N, K, generator=g) * 0.02
+    xs = []
+    for _ in range(8):
+        x = torch.randn(1, 256, K, generator=g)
+        x[..., ::53] *= 12.0  # salient channels: gives the alpha grid a real optimum
+        xs.append(x)
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(K, N, bias=False)
+
+        def forward(self, x):
+            return self.lin(x)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([Block()])
+
+        def forward(self, x):
+            return self.blocks[0](x)
+
+    model = Model()
+    model.blocks[0].lin.weight.data.copy_(W)
+    xd = [x.to(hip) for x in xs]
+    awq = ActAwareWeightQuant(model, bits=4, group_size=GS, scheme="asym", total_block_args=[[x] for x in xd],
+                              total_block_kwargs=[{} for _ in xd])
+    name, tup = "blocks.0.lin", ("blocks.0.lin",)
+    inputs = {"lin": {"input": xd}}
+    with torch.no_grad():
+        info = awq.search_scale(model.blocks[0], "blocks.0", [tup], inputs)
+        awq.absorb_of = {tup: name}
+        awq.apply_scale(info)
+        assert isinstance(model.blocks[0].lin, MulLinear)
+        awq.search_clip("blocks.0", [tup], inputs)
+    s_hist, s_best = awq.search_log["scale"][name]
+    c_hist, c_best = awq.search_log["clip"][name]
+
+    r = O.awq_search_scale_module(W, None, xs, group_size=GS, scheme="asym")
+    isc = 1.0 / r["best_scales"]
+    c = O.awq_search_clip_module(W / isc.view(1, -1), None, xs, group_size=GS, scheme="asym", input_scale=isc)
+    s_rel = float(np.max(np.abs(np.array(s_hist) - np.array(r["history"])) / np.array(r["history"])))
+    c_rel = float(np.max(np.abs(np.array(c_hist) - np.array(c["history"])) / np.array(c["history"])))
+    sr = np.sort(np.array(r["history"]))
+    cr = np.sort(np.array(c["history"]))
+    print(f"\n[awq 4096x4096 g128] scale search: chosen alpha index HIP {s_best} / oracle {r['best_index']}, max rel diff of the 20 losses "
+          f"{s_rel:.2e} (oracle's best-to-runner-up gap {(sr[1] - sr[0]) / sr[0]:.2e}); clip search: index HIP {c_best} / oracle "
+          f"{c['best_index']}, max rel diff of the 10 losses {c_rel:.2e} (gap {(cr[1] - cr[0]) / cr[0]:.2e})")
+    assert s_best == r["best_index"] and c_best == c["best_index"]
+    assert s_rel <= 1e-4 and c_rel <= 1e-4
+    got = info[tup].float().cpu()
+    assert float(((got - r["best_scales"]).abs() / r["best_scales"]).max()) <= 1e-5

@@ -463,12 +463,42 @@ def _run_awq(absorb, **kw):
     return convert(model), ids
 
 
+def _awq_search_parity(q, trace_tag, tau):
+    """The two AWQ grid searches against what the UNMODIFIED reference's searches saw on the same model
+    (tests/golden/awq_trace_*.npz: every loss of every grid).  Per search: the HIP path's loss curve must follow the
+    reference's, and its chosen grid point must be the reference's -- or one the reference's OWN numbers put within
+    `tau` of its minimum (an argmin near-tie: on these 64-wide toy layers ONE 4-bit code that rounds the other way
+    moves a loss by ~1/(64*64) = 2.4e-4 of itself, which is the size of the gaps between neighbouring grid points here;
+    at 4096x4096 the same flip is 6e-8 and test_awq_scale_and_clip_search_4096_vs_oracle demands identical argmins).
+    Returns (exact matches, searches, list of explained near-ties)."""
+    tr = np.load(os.path.join(ROOT, "tests", "golden", f"awq_trace_{trace_tag}.npz"))
+    log = q.awq_search_log
+    exact, total, residue = 0, 0, []
+    for kind in ("scale", "clip"):
+        names, hists, bests = tr[f"{kind}_names"], tr[f"{kind}_hist"], tr[f"{kind}_best"]
+        assert sorted(str(n) for n in names) == sorted(log[kind]), kind
+        for name, ref_hist, ref_best in zip(names, hists, bests):
+            hist, best = log[kind][str(name)]
+            hist = np.array(hist)
+            curve = float(np.max(np.abs(hist - ref_hist) / ref_hist))
+            assert curve <= 10 * tau, f"{kind} search of {name}: loss curve differs from the reference's by {curve:.2e}"
+            total += 1
+            if best == int(ref_best):
+                exact += 1
+                continue
+            gap = float((ref_hist[best] - ref_hist[ref_best]) / ref_hist[ref_best])
+            assert gap <= tau, (f"{kind} search of {name}: grid point {best} chosen, the reference chose {int(ref_best)} and its own "
+                                f"loss at {best} is {gap:.2e} above its minimum -- not a near-tie")
+            residue.append((kind, str(name), best, int(ref_best), gap))
+    return exact, total, residue
+
+
 @pytest.mark.parametrize("tag", ["fold", "self"])
 def test_awq_tiny_llama_vs_reference(tag):
-    """Same structure as the reference (which layers become MulLinear, which norms absorb), the searched per-channel
-    scales agree (the alpha grid point is an argmin over losses that differ in the last fp32 bits between the CPU
-    and the GPU, so a minority of modules may land on a neighbouring grid point), packed buffers agree where the
-    scales do, and the quantised model is as close to the float model as the reference's."""
+    """Same structure as the reference (which layers become MulLinear, which norms absorb); BOTH grid searches of EVERY
+    module land on the reference's grid point or on a documented near-tie of the reference's own loss curve
+    (_awq_search_parity); where the grid points agree the searched scales and the packed words agree; and the quantised
+    model is as close to the float model as the reference's."""
     from neural_compressor_amd.torch.algorithms.weight_only.modules import MulLinear
 
     g = np.load(os.path.join(ROOT, "tests", "golden", f"awq_tiny_llama_{tag}.npz"))
@@ -478,28 +508,26 @@ def test_awq_tiny_llama_vs_reference(tag):
     ref_mul = sorted(k[: -len(".input_scale")] for k in g.files if k.endswith(".input_scale"))
     our_mul = sorted(n for n, m in q.named_modules() if isinstance(m, MulLinear))
     assert our_mul == ref_mul
-    same_scale, total = 0, 0
-    matched = set()
-    for name in ref_mul:
-        ours = dict(q.named_modules())[name].input_scale.float().cpu().numpy()
-        rel = np.linalg.norm(ours - g[f"{name}.input_scale"]) / np.linalg.norm(g[f"{name}.input_scale"])
-        total += 1
-        if rel <= 1e-3:
-            same_scale += 1
-            matched.add(name + ".linear")
-    for k in [k for k in g.files if k.endswith("layernorm.weight")]:
-        ours = dict(q.named_modules())[k[: -len(".weight")]].weight.detach().float().cpu().numpy()
-        rel = np.linalg.norm(ours - g[k]) / np.linalg.norm(g[k])
-        total += 1
-        same_scale += rel <= 1e-3
-    assert same_scale >= 0.7 * total, f"only {same_scale}/{total} searched scales match the reference"
-    # where the scale matched, the packed integers must match almost everywhere (clip ratio is a second argmin)
-    agree = []
-    for name in matched:
-        m = mods[name]
-        agree.append(float((m.qweight.cpu().numpy() == g[f"{name}.qweight"]).mean()))
-    if agree:
-        assert np.median(agree) >= 0.9, agree
+    exact, total, residue = _awq_search_parity(q, f"tiny_llama_{tag}", tau=2e-3)
+    print(f"\n[awq tiny_llama {tag}] {exact}/{total} grid searches choose the reference's grid point; near-ties: {residue}")
+    assert exact >= 0.8 * total, (exact, total, residue)
+    off_scale = {n for k, n, *_ in residue if k == "scale"}
+    off_clip = {n for k, n, *_ in residue if k == "clip"}
+    named = dict(q.named_modules())
+    for name in ref_mul:  # self-absorbed layers: input_scale = 1 / searched scale
+        if any(name in t.split("|") for t in off_scale):
+            continue
+        ours = named[name].input_scale.float().cpu().numpy()
+        assert np.linalg.norm(ours - g[f"{name}.input_scale"]) / np.linalg.norm(g[f"{name}.input_scale"]) <= 1e-5, name
+    agree = {}
+    for name, m in mods.items():
+        base = name[: -len(".linear")] if name.endswith(".linear") else name
+        if any(base in t.split("|") for t in off_scale) or base in off_clip:
+            continue
+        agree[name] = float((m.qweight.cpu().numpy() == g[f"{name}.qweight"]).mean())
+    # same scale grid point and same clip ratio -> the packed words are the reference's except at RTN rounding ties of
+    # W * s (s comes from powf on the GPU vs pow on the CPU: last-bit differences)
+    assert agree and min(agree.values()) >= 0.97, agree
     with torch.no_grad():
         # the packed modules return fp16 for fp32 inputs (the reference's accelerator semantics, modules.py:605): run
         # the rest of the model in fp16 too, otherwise HF's eager attention mixes fp32 RoPE outputs with an fp16 V
@@ -539,7 +567,10 @@ def test_awq_tiny_gptj_default_discovery_vs_reference():
     for k in norms:  # the folded LayerNorm carries 1/scale in weight AND bias
         w = named[k].weight.detach().float().cpu().numpy()
         close += int(np.linalg.norm(w - g[f"{k}.weight"]) / np.linalg.norm(g[f"{k}.weight"]) <= 1e-3)
-    assert close >= 0.6 * (len(ref_mul) + len(norms)), close  # argmin over a 20-point grid: neighbours may swap
+    exact, total, residue = _awq_search_parity(q, "tiny_gptj_default", tau=2e-3)
+    print(f"\n[awq tiny_gptj default discovery] {exact}/{total} grid searches choose the reference's grid point; near-ties: {residue}")
+    assert exact >= 0.8 * total, (exact, total, residue)
+    assert close >= (len(ref_mul) + len(norms)) - sum(1 for k, *_ in residue if k == "scale"), (close, residue)
     with torch.no_grad():
         y = _to_half(q)(ids[0].to("cuda")).logits.float().cpu()
     ref, fp = torch.from_numpy(g["logits"]), torch.from_numpy(g["logits_fp"])
@@ -716,4 +747,105 @@ def test_gptq_sample_sharded_two_ranks_equals_single_process():
     single = {n: m.qweight.cpu() for n, m in _woq_modules(convert(model)).items()}
     first = min(_nibble_match(res[0][n].numpy(), single[n].numpy()) for n in single if ".layers.0." in n)
     worst = min(_nibble_match(res[0][n].numpy(), single[n].numpy()) for n in single)
+    assert first >= 0.99 and worst >= 0.95, (first, worst)
+
+
+def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      INC_MI355X_GPTQ_MULTI_GPU=mode)
+    import torch.distributed as dist
+
+    from neural_compressor_amd import distributed as D
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    torch.cuda.set_device(0)
+    D.init_from_env(backend="gloo")
+    ids = calib_ids()
+    mine = D.shard_samples(len(ids), rank, world) if "sample" in mode else range(len(ids))
+    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw))
+    assert model.quantizer.gptq_quantizer.dist_ctx is not None
+    for j in mine:
+        model(ids[j])
+    q = convert(model)
+    res = {}
+    for n, m in _woq_modules(q).items():
+        res[n] = (m.qweight.cpu(), m.scales.cpu(), m.qzeros.cpu(), None if m.g_idx is None else m.g_idx.cpu())
+    with torch.no_grad():
+        res["__logits__"] = q(ids[0].to("cuda")).logits.float().cpu()
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def _spawn_multi_gpu(mode, cfg_kw):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_multi_gpu_worker, args=(2, port, mode, cfg_kw, out), nprocs=2, join=True)
+        return {r: dict(v) for r, v in out.items()}
+
+
+def _single_process(cfg_kw):
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    ids = calib_ids()
+    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw))
+    for x in ids:
+        model(x)
+    q = convert(model)
+    res = {n: (m.qweight.cpu(), m.scales.cpu(), m.qzeros.cpu(), None if m.g_idx is None else m.g_idx.cpu()) for n, m in _woq_modules(q).items()}
+    with torch.no_grad():
+        res["__logits__"] = q(ids[0].to("cuda")).logits.float().cpu()
+    return res
+
+
+def _same(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return torch.equal(a, b)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("cfg_kw", [dict(use_sym=True), dict(use_sym=False, act_order=True)], ids=["sym", "asym_act_order"])
+def test_gptq_row_sharded_solve_two_ranks_is_bit_identical_to_single_process(cfg_kw):
+    """Multi-GPU mode "rows" (distributed.py; SURVEY 8(e)(ii), collective C2): every rank sees all samples, the i-th
+    distinct Hessian of a block is factorised on rank i % 2 only and its factor broadcast, each rank runs the column loop
+    on its slice of the (N-stacked) weight rows and the codes / Q / scales / zeros are all-gathered.  Nothing in that
+    changes a single bit: both ranks must pack exactly the single-process model (two processes share the one test
+    GPU, gloo between them; the production backend is RCCL)."""
+    res = _spawn_multi_gpu("rows", cfg_kw)
+    single = _single_process(cfg_kw)
+    assert res[0].keys() == res[1].keys() == single.keys() and len(single) == 15
+    for n in single:
+        if n == "__logits__":
+            assert torch.equal(res[0][n], single[n]) and torch.equal(res[1][n], single[n])
+            continue
+        for a, b, c in zip(res[0][n], res[1][n], single[n]):
+            assert _same(a, c) and _same(b, c), n
+
+
+@pytest.mark.timeout(900)
+def test_gptq_sample_and_row_sharded_two_ranks():
+    """Multi-GPU mode "sample+rows" (what bench.py --gpus N runs): samples sharded, Hessians REDUCED to their owner rank,
+    factor broadcast, row-sharded solve, all-gather.  Both ranks end with the SAME packed model; against the
+    single-process run only the fp32 summation order of the Hessian differs (rounding-tie flips)."""
+    cfg_kw = dict(use_sym=True)
+    res = _spawn_multi_gpu("sample+rows", cfg_kw)
+    single = _single_process(cfg_kw)
+    assert res[0].keys() == res[1].keys() == single.keys()
+    for n in single:
+        if n == "__logits__":
+            assert torch.equal(res[0][n], res[1][n])
+            assert float((res[0][n] - single[n]).norm() / single[n].norm()) <= 2e-2
+            continue
+        for a, b in zip(res[0][n], res[1][n]):
+            assert _same(a, b), n
+    first = min(_nibble_match(res[0][n][0].numpy(), single[n][0].numpy()) for n in single if ".layers.0." in n)
+    worst = min(_nibble_match(res[0][n][0].numpy(), single[n][0].numpy()) for n in single if n != "__logits__")
     assert first >= 0.99 and worst >= 0.95, (first, worst)

@@ -1,10 +1,14 @@
 """CPU: the oracle restatement must reproduce the outputs of the unmodified reference stored in tests/golden/."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import woq_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_kat_pack(golden):
@@ -167,3 +171,41 @@ def test_awq_stats(golden):
     assert np.array_equal(O.awq_weight_scale(w, -1).numpy(), golden["awq_wscale_pc"])
     x = torch.from_numpy(golden["awq_x"])
     assert np.array_equal(O.awq_act_scale([x[i : i + 1] for i in range(x.shape[0])]).numpy(), golden["awq_xscale"])
+
+
+def test_oracle_awq_searches_match_the_reference_trace():
+    """oracle.awq_search_scale_module / awq_search_clip_module (awq.py:264-361, 393-470) against what the UNMODIFIED
+    reference's two grid searches saw on tiny_llama with every Linear self-absorbed (tests/golden/awq_trace_*.npz,
+    made by make_golden_awq_trace.py): all 20 + 10 losses of every module, and the chosen grid points."""
+    from tests.model_zoo import calib_ids, tiny_llama
+
+    tr = np.load(os.path.join(ROOT, "tests", "golden", "awq_trace_tiny_llama_self.npz"))
+    model = tiny_llama()
+    model.config.use_cache = False
+    ids = calib_ids()
+    inputs = {}
+    hooks = []
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.Linear) and ".layers." in name:
+            hooks.append(mod.register_forward_hook(lambda m, inp, out, n=name: inputs.setdefault(n, []).append(inp[0].detach())))
+    with torch.no_grad():
+        for x in ids:
+            model(x)
+    for h in hooks:
+        h.remove()
+    mods = dict(model.named_modules())
+    clip_names = list(tr["clip_names"])
+    assert len(tr["scale_names"]) == 14 and len(clip_names) == 14
+    for i, name in enumerate(tr["scale_names"]):
+        name = str(name)
+        W = mods[name].weight.detach().clone()
+        r = O.awq_search_scale_module(W, None, inputs[name], group_size=32, scheme="asym")
+        np.testing.assert_allclose(np.array(r["history"]), tr["scale_hist"][i], rtol=2e-5, err_msg=name)
+        assert r["best_index"] == int(tr["scale_best"][i]), name
+        # apply_scale, self-absorption (awq.py:375-379): MulLinear(input_scale = 1/s), linear.weight /= input_scale
+        isc = 1.0 / r["best_scales"]
+        W2 = W / isc.view(1, -1)
+        j = clip_names.index(name)
+        c = O.awq_search_clip_module(W2, None, inputs[name], group_size=32, scheme="asym", input_scale=isc)
+        np.testing.assert_allclose(np.array(c["history"]), tr["clip_hist"][j], rtol=2e-5, err_msg=name)
+        assert c["best_index"] == int(tr["clip_best"][j]), name

@@ -17,6 +17,12 @@
 
 #include "../include/inc_mi355x.h"
 
+// A/B switch of the HARNESS build of the library (tools/libinc_mi355x_kbench.so, -DINC_KBENCH): 0 = shipped kernels;
+// 1 = first-generation kernels; 2 = second-generation 256x256 two-stage dequant-GEMM; 4 / 6 = the other instruction
+// schedules of the 3A2B dequant-GEMM; 20-30, 31-37 = timing-only ablations of its step (wrong results by construction).
+// Not part of libinc_mi355x.so.
+extern "C" void inc_debug_set_small_tiles(int on);
+
 #define HIPCHECK(x)                                                                      \
   do {                                                                                   \
     hipError_t e_ = (x);                                                                 \
