@@ -63,6 +63,7 @@ class SmoothQuantQuantizer(Quantizer):
         sq.input_maxes = {n: calib.input_maxes[n] for n in names}
         sq.same_input = {n: o for n, o in calib.same_input.items() if n in sq.input_maxes and o in sq.input_maxes}
         sq.producer = {n: p for n, p in calib.producer.items() if n in sq.input_maxes}
+        sq.example_call = calib.example_call  # folds are verified numerically on the first calibration batch
         sq.transform(alpha=first.get("alpha", 0.5), folding=first.get("folding", False), op_types=(torch.nn.Linear,),
                      scale_sharing=first.get("scale_sharing", False), absorb_to_layer=first.get("absorb_to_layer"))
         dev = next(model.parameters()).device

@@ -42,6 +42,7 @@ class Calibration:
         self.hook_handles = []
         self.same_input = {}  # layer name -> name of the first layer that saw the very same input tensor
         self.producer = {}    # layer name -> name of the norm whose output tensor IS this layer's input (folding)
+        self.example_call = None  # (args, kwargs) of the first calibration forward: replayed to VERIFY a fold numerically
 
     def _save_input_pc_hook(self, name):
         def save_input_hook(module, inputs, outputs):
@@ -79,6 +80,12 @@ class Calibration:
             self._norm_out.clear()
 
         self.hook_handles.append(root.register_forward_hook(clear))
+
+        def remember(_m, args, kwargs):
+            if self.example_call is None:
+                self.example_call = (args, dict(kwargs))
+
+        self.hook_handles.append(root.register_forward_pre_hook(remember, with_kwargs=True))
 
     def _remove_observer(self):
         for h in self.hook_handles:
@@ -247,6 +254,7 @@ class TorchSmoothQuant:
         self.scale_sharing = scale_sharing
         self.input_mins, self.input_maxes = {}, {}
         self.same_input, self.producer = {}, {}
+        self.example_call = None
         self.weight_scale_info, self.absorb_scales_info = {}, {}
         self.absorb_to_layer = {}
         self.weight_max_lb = 1e-5
@@ -310,12 +318,57 @@ class TorchSmoothQuant:
         return {n: [n] for n, m in self.model.named_modules() if isinstance(m, tuple(op_types))}
 
     def _find_foldable(self):
-        """{norm name: [Linear names whose input tensor is that norm's output]} -- observed during calibration."""
+        """{norm name: [Linear names whose input tensor is that norm's output]} -- observed during calibration, then
+        VERIFIED: the hooks only see the selected Linears, so a norm whose output also feeds something else (a Linear
+        that is not being smoothed, a residual add, any functional op) would emit x/s to a consumer that keeps unscaled
+        weights.  Like the AWQ path's discovery, every candidate fold is therefore tried with a random rescale on the
+        first calibration batch and kept only if the model output does not move; a candidate that fails is treated as
+        the reference treats a layer it cannot fold (folding=True smooths absorbable layers only)."""
         found = {}
         for layer, norm in self.producer.items():
             if norm is not None:
                 found.setdefault(norm, []).append(layer)
-        return found
+        if not found:
+            return found
+        if self.example_call is None:
+            logger.warning("SmoothQuant folding: no calibration forward was recorded, candidate folds cannot be verified and are dropped")
+            return {}
+        args, kwargs = self.example_call
+
+        def run():
+            out = self.model(*args, **kwargs)
+            out = out.logits if hasattr(out, "logits") else (out[0] if isinstance(out, (tuple, list)) else out)
+            return out.float()
+
+        base = run()
+        gen = torch.Generator().manual_seed(0)
+        verified = {}
+        for norm_name, layers in found.items():
+            norm = get_module(self.model, norm_name)
+            mods = [get_module(self.model, n) for n in layers]
+            K = mods[0].weight.shape[1]
+            s = (0.5 + 1.5 * torch.rand(K, generator=gen)).to(base.device)
+            saved = [norm.weight.data.clone(), None if getattr(norm, "bias", None) is None else norm.bias.data.clone()] + [m.weight.data.clone() for m in mods]
+            try:
+                norm.weight.data = (norm.weight.data.float() / s).to(norm.weight.dtype)
+                if saved[1] is not None:
+                    norm.bias.data = (norm.bias.data.float() / s).to(norm.bias.dtype)
+                for m in mods:
+                    m.weight.data = (m.weight.data.float() * s.view(1, -1)).to(m.weight.dtype)
+                moved = float((run() - base).norm() / base.norm().clamp_min(1e-30))
+            finally:
+                norm.weight.data = saved[0]
+                if saved[1] is not None:
+                    norm.bias.data = saved[1]
+                for m, w in zip(mods, saved[2:]):
+                    m.weight.data = w
+            # a correct fold moves the output by rounding noise only (16-bit models: ~1e-2); a missed consumer by O(1)
+            if moved <= 5e-2:
+                verified[norm_name] = layers
+            else:
+                logger.warning("SmoothQuant folding: %s also feeds something other than %s (output moved by %.3f under a "
+                               "test rescale); these layers are not smoothed", norm_name, layers, moved)
+        return verified
 
     # -- the entry (:2289-2432) ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -331,6 +384,7 @@ class TorchSmoothQuant:
             calib = Calibration(self.model, self.dataloader, self.q_func)
             self.input_mins, self.input_maxes = calib.calibrate(calib_iter, op_types)
             self.same_input, self.producer = calib.same_input, calib.producer
+            self.example_call = calib.example_call
         input_maxes_abs = {k: torch.max(self.input_mins[k].abs(), self.input_maxes[k].abs()) for k in self.input_mins}
         if absorb_to_layer is not None:
             self.absorb_to_layer = {k: list(v) for k, v in absorb_to_layer.items()}

@@ -34,7 +34,7 @@ import torch
 
 from .... import ops
 from ....common.utils import logger
-from ...utils.utility import get_accelerator, set_module
+from ...utils.utility import batch_broadcastable, get_accelerator, set_module
 from ..base_algorithm import Quantizer
 from .modules import MulLinear
 from .utility import get_block_prefix, quant_tensor
@@ -591,10 +591,19 @@ class ActAwareWeightQuant:
                 and self._same_kwargs({kk: v for kk, v in k.items() if kk != "hidden_states"},
                                       {kk: v for kk, v in kw0.items() if kk != "hidden_states"})
                 for a, k in zip(self.total_block_args, self.total_block_kwargs))
+            # every other argument must also broadcast over the batch (leading dimension 1): batch-folded arguments such
+            # as Bloom / Falcon / MPT `alibi` [batch*heads, 1, T] do not, and such models keep the reference's
+            # one-batch-per-forward loop
+            stackable = stackable and batch_broadcastable(list(args0[1:])) and batch_broadcastable(
+                {kk: v for kk, v in kw0.items() if kk != "hidden_states"})
             if stackable:
                 hs = [get(a, k) for a, k in zip(self.total_block_args, self.total_block_kwargs)]
                 chunks = [("stack", x, n) for x, n in self._stack(hs)]
-            else:
+                if not self._stacked_block_is_faithful(block, chunks[0], hidden_in_args):
+                    logger.warning("AWQ: a stacked forward of this block does not reproduce its per-batch outputs; "
+                                   "searching with one calibration batch per forward")
+                    stackable = False
+            if not stackable:
                 chunks = [("single", i, 1) for i in range(len(self.total_block_args))]
             self._block_chunks = chunks
         outs = []
@@ -612,6 +621,32 @@ class ActAwareWeightQuant:
             out = block(*args, **kwargs)
             outs.append((out[0] if isinstance(out, tuple) else out, n))
         return outs
+
+    def _stacked_block_is_faithful(self, block, chunk, hidden_in_args):
+        """The first stacked forward against the per-batch forwards of the same batches (guards against blocks that are
+        not row-independent; compared up to GEMM-shape rounding)."""
+        _, x, n = chunk
+        if n <= 1:
+            return True
+        args0, kw0 = self.total_block_args[0], self.total_block_kwargs[0]
+
+        def run(h):
+            if hidden_in_args:
+                out = block(*([h] + list(args0[1:])), **kw0)
+            else:
+                out = block(*args0, **dict(kw0, hidden_states=h))
+            return (out[0] if isinstance(out, tuple) else out).float()
+
+        try:
+            got = run(x)
+        except Exception as e:
+            logger.warning("AWQ: stacked block forward failed (%s)", e)
+            return False
+        ref = torch.cat([run(x[i : i + 1]) for i in range(n)], dim=0)
+        if got.shape != ref.shape:
+            return False
+        tol = 1e-4 if x.dtype == torch.float32 else 3e-2
+        return bool((got - ref).norm() <= tol * ref.norm().clamp_min(1e-30))
 
     def module_inference(self, model, inputs):
         total_out = []

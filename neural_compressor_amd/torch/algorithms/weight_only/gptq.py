@@ -31,7 +31,7 @@ import torch.nn as nn
 
 from .... import ops
 from ....common.utils import logger
-from ...utils.utility import get_accelerator, get_model_device, set_module
+from ...utils.utility import batch_broadcastable, get_accelerator, get_model_device, set_module
 from ..base_algorithm import Quantizer as INCQuantizer
 from .modules import MI355XWeightOnlyLinear
 
@@ -610,7 +610,7 @@ class RAWGPTQuantizer(object):
         forward runs (M = 16384 instead of 2048 at the BASELINE calibration shape) and 8x fewer elementwise launches."""
         batch_num = self.cache_key_arguments.pop("batch_num")
         in_kwargs = "hidden_states" in self.cache_key_arguments
-        for group in self._forward_groups(batch_num, in_kwargs):
+        for group in self._forward_groups(batch_num, in_kwargs, block):
             j0 = group[0]
             kw = self.gather_single_batch_from_dict(self.cache_key_arguments, j0)
             pos = self.gather_single_batch_from_list(self.cache_positional_arguments, j0)
@@ -628,8 +628,14 @@ class RAWGPTQuantizer(object):
                         on_output(j, out[i : i + 1])
         self.cache_key_arguments["batch_num"] = batch_num
 
-    def _forward_groups(self, batch_num, in_kwargs):
-        """[[batch indices sharing one forward]]; computed once (only the hidden states change from block to block)."""
+    def _forward_groups(self, batch_num, in_kwargs, block=None):
+        """[[batch indices sharing one forward]]; computed once (only the hidden states change from block to block).
+
+        Batches are stacked only when that is provably the same computation: same shapes, every other argument the same
+        values AND broadcastable over the batch (leading dimension 1 -- batch-folded arguments like `alibi`
+        [batch*heads, 1, T] are not), and the first stacked forward of `block` reproduces the per-batch outputs (guards
+        against blocks that are not row-independent, e.g. MoE routing with capacity limits).  Anything else runs one
+        batch per forward, exactly like the reference."""
         cached = getattr(self, "_fgroups", None)
         if cached is not None and cached[0] == batch_num:
             return cached[1]
@@ -652,9 +658,10 @@ class RAWGPTQuantizer(object):
             if not (isinstance(hi, torch.Tensor) and isinstance(hj, torch.Tensor)) or hi.shape != hj.shape or hi.shape[0] != 1 or hi.dim() < 2:
                 return False
             for k, v in self.cache_key_arguments.items():
-                if k != "hidden_states" and not same(v[i], v[j]):
+                if k != "hidden_states" and not (same(v[i], v[j]) and batch_broadcastable(v[i])):
                     return False
-            return all(same(lst[i], lst[j]) for lst in self.cache_positional_arguments[(0 if in_kwargs else 1):])
+            return all(same(lst[i], lst[j]) and batch_broadcastable(lst[i])
+                       for lst in self.cache_positional_arguments[(0 if in_kwargs else 1):])
 
         groups, cur = [], [0] if batch_num > 0 else []
         for j in range(1, batch_num):
@@ -665,8 +672,51 @@ class RAWGPTQuantizer(object):
                 cur = [j]
         if cur:
             groups.append(cur)
+        multi = next((g for g in groups if len(g) > 1), None)
+        if multi is not None and block is not None and not self._stacking_is_faithful(block, multi, in_kwargs):
+            logger.warning("GPTQ: a stacked forward of this block does not reproduce its per-batch outputs; "
+                           "running one calibration batch per forward")
+            groups = [[j] for j in range(batch_num)]
         self._fgroups = (batch_num, groups)
         return groups
+
+    def _stacking_is_faithful(self, block, group, in_kwargs):
+        """One stacked forward of `group` against the per-batch forwards (no hooks are installed at this point of the
+        first block; outputs are compared up to GEMM-shape rounding)."""
+        hooks = [m._forward_hooks for m in block.modules()]
+        saved = [dict(h) for h in hooks]
+        for h in hooks:
+            h.clear()  # the Hessian hooks of the caller must not see these probe forwards
+        try:
+            j0 = group[0]
+            kw = self.gather_single_batch_from_dict(self.cache_key_arguments, j0)
+            pos = self.gather_single_batch_from_list(self.cache_positional_arguments, j0)
+            src = self.cache_key_arguments["hidden_states"] if in_kwargs else self.cache_positional_arguments[0]
+            singles = []
+            for j in group:
+                if in_kwargs:
+                    kw["hidden_states"] = src[j]
+                else:
+                    pos[0] = src[j]
+                singles.append(self.track_hidden_states(block(*pos, **kw)).float())
+            stacked_in = torch.cat([src[j] for j in group], dim=0)
+            if in_kwargs:
+                kw["hidden_states"] = stacked_in
+            else:
+                pos[0] = stacked_in
+            try:
+                out = self.track_hidden_states(block(*pos, **kw)).float()
+            except Exception as e:  # shape errors of batch-folded arguments the structural test did not recognise
+                logger.warning("GPTQ: stacked block forward failed (%s)", e)
+                return False
+            ref = torch.cat(singles, dim=0)
+            if out.shape != ref.shape:
+                return False
+            tol = 1e-4 if stacked_in.dtype == torch.float32 else 3e-2
+            return bool((out - ref).norm() <= tol * ref.norm().clamp_min(1e-30))
+        finally:
+            for h, sv in zip(hooks, saved):
+                h.update(sv)
 
     def _exchange_factors(self, distinct):
         """Mode "sample+rows": combine the sharded Hessians on their owner ranks, factorise there, broadcast the factors.

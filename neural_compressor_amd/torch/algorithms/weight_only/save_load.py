@@ -72,6 +72,10 @@ def change_config_to_hf_format(config_mappings):
 def save(model, output_dir="./saved_results", format="default", **kwargs):
     """Save the quantised model and its configuration (reference save_load.py:56-108)."""
     fmt = getattr(format, "value", format)
+    for name, mod in model.named_modules():
+        if isinstance(mod, MI355XWeightOnlyLinear) and not getattr(mod, "use_optimum_format", True):
+            # both on-disk formats ARE the optimum (HF / AutoGPTQ) layout; the loader rebuilds modules in that layout only
+            raise ValueError(f"{name} was packed with use_optimum_format=False; convert with the default optimum format to save it")
     os.makedirs(output_dir, exist_ok=True)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
@@ -114,18 +118,26 @@ def _module_config(quantization_config, name, module):
 
 def _build(original_model, state, quantization_config, device):
     keys = set(state.keys())
+    try:
+        from transformers import Conv1D
+    except Exception:  # pragma: no cover
+        Conv1D = ()
     for name, module in list(original_model.named_modules()):
-        if not isinstance(module, torch.nn.Linear):
+        if not isinstance(module, (torch.nn.Linear, Conv1D) if Conv1D else torch.nn.Linear):
             continue
         if name + ".qweight" not in keys and name + ".linear.qweight" not in keys:
             continue  # not quantised
+        if isinstance(module, torch.nn.Linear):
+            in_features, out_features = module.in_features, module.out_features
+        else:  # transformers.Conv1D (GPT-2) stores [in, out]; RTN / GPTQ pack it like the transposed Linear (rtn.py)
+            in_features, out_features = module.weight.shape[0], module.weight.shape[1]
         cfg = _module_config(quantization_config, name, module)
         target = name
         if name + ".linear.qweight" in keys:  # AWQ / TEQ: a multiplier in front of the packed layer (reference :479-482)
             set_module(original_model, name, MulLinear(module))
             target = name + ".linear"
         new = MI355XWeightOnlyLinear(
-            module.in_features, module.out_features, dtype=cfg.get("dtype", "int"), bits=cfg.get("bits", 4),
+            in_features, out_features, dtype=cfg.get("dtype", "int"), bits=cfg.get("bits", 4),
             group_size=cfg.get("group_size", 32), zp=(target + ".qzeros") in keys, bias=module.bias is not None,
             g_idx=(target + ".g_idx") in keys, use_optimum_format=True, device=device,
         )
@@ -136,7 +148,7 @@ def _build(original_model, state, quantization_config, device):
                 own[k] = state.pop(full)
         own = {k: v.to(device) for k, v in own.items()}
         n_pack = 32 // new.bits
-        awq_shape = (module.in_features, module.out_features // n_pack)
+        awq_shape = (in_features, out_features // n_pack)
         if "qweight" in own and tuple(own["qweight"].shape) == awq_shape and awq_shape != tuple(new.qweight.shape):
             # an AutoAWQ "GEMM" checkpoint ([K, N/8] words, interleaved fields): shuffle to the optimum layout on the
             # device (reference repack_awq_and_load_state_dict, transformers/quantization/utils.py:655-697)
@@ -146,6 +158,9 @@ def _build(original_model, state, quantization_config, device):
         if "qweight" in missing.missing_keys or "scales" in missing.missing_keys:
             raise RuntimeError(f"checkpoint is missing packed buffers of {target}")
         set_module(original_model, target, new)
+    left = sorted(k for k in state if k.endswith(".qweight"))
+    if left:  # e.g. a module type this loader does not rebuild: never hand back a silently-float model
+        raise RuntimeError(f"checkpoint holds packed weights that no module of the model consumed: {left[:4]}{' ...' if len(left) > 4 else ''}")
     return original_model
 
 

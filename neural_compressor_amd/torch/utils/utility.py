@@ -141,3 +141,20 @@ def get_accelerator(device_name="auto"):
             "No HIP device is visible (torch.cuda.is_available() is False). neural_compressor_amd has no CPU fallback."
         )
     return _ACC
+
+
+def batch_broadcastable(obj):
+    """True when `obj` (a block-forward argument other than the hidden states: tensor / nested tuples, lists, dicts /
+    plain Python value) can be reused unchanged for a STACK of calibration batches: every tensor in it has a leading
+    dimension of 1 (or is 0-d), i.e. it broadcasts over the batch.  Batch-folded arguments such as Bloom / Falcon / MPT
+    `alibi` [batch * heads, 1, T] fail this test, and such models are then run one calibration batch per forward, as
+    the reference does."""
+    import torch
+
+    if isinstance(obj, torch.Tensor):
+        return obj.dim() == 0 or obj.shape[0] == 1
+    if isinstance(obj, (tuple, list)):
+        return all(batch_broadcastable(o) for o in obj)
+    if isinstance(obj, dict):
+        return all(batch_broadcastable(o) for o in obj.values())
+    return True

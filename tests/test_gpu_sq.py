@@ -228,3 +228,38 @@ def test_smooth_quant_save_load_roundtrip(tmp_path):
         y1 = r(ids[0].to("cuda")).logits
     assert torch.equal(y0, y1)  # same integers, same folded norms, same kernels
     assert r.sq_info["folding"] is True and abs(r.sq_info["alpha"] - 0.6) < 1e-12
+
+
+def test_smooth_quant_folding_refuses_a_norm_with_unsmoothed_consumers():
+    """folding=True must not fold 1/s into a norm whose output also feeds a consumer that is NOT rescaled: here k_proj /
+    v_proj stay fp32 while q_proj is selected, so input_layernorm would emit x/s to two Linears with unscaled weights.
+    Every candidate fold is verified with a test rescale on the first calibration batch; the failing one is dropped
+    (q_proj is quantised unsmoothed, as the reference's folding mode treats a layer it cannot fold), the gate/up fold,
+    whose consumers are all smoothed, is kept -- and the model stays a faithful W8A8 image of the float one."""
+    from neural_compressor_amd.torch.algorithms.smooth_quant import W8A8Linear
+    from neural_compressor_amd.torch.quantization import SmoothQuantConfig, convert, prepare
+
+    ids = calib_ids(n=8, seq=32)
+    fp = tiny_llama(dtype=torch.float16).to("cuda")
+    with torch.no_grad():
+        ref = fp(ids[0].to("cuda")).logits.float()
+    cfg = SmoothQuantConfig(alpha=0.5, folding=True, scale_sharing=True)
+    cfg.set_local("lm_head", SmoothQuantConfig(w_dtype="fp32"))
+    cfg.set_local(".*k_proj", SmoothQuantConfig(w_dtype="fp32"))
+    cfg.set_local(".*v_proj", SmoothQuantConfig(w_dtype="fp32"))
+    model = prepare(tiny_llama(dtype=torch.float16), cfg, example_inputs=ids[0])
+    for x in ids:
+        model(x.to("cuda"))
+    q = convert(model)
+    mods = {n: m for n, m in q.named_modules() if isinstance(m, W8A8Linear)}
+    assert len(mods) == 10 and not any(n.endswith(("k_proj", "v_proj")) for n in mods)
+    assert set(q.sq_info["absorb_to_layer"]) == {f"model.layers.{i}.post_attention_layernorm" for i in (0, 1)}
+    named, fnamed = dict(q.named_modules()), dict(fp.named_modules())
+    for i in (0, 1):
+        a, b = named[f"model.layers.{i}.input_layernorm"].weight, fnamed[f"model.layers.{i}.input_layernorm"].weight
+        assert torch.equal(a.detach().cpu(), b.detach().cpu()), "a norm with unsmoothed consumers must be left alone"
+        c, d = named[f"model.layers.{i}.post_attention_layernorm"].weight, fnamed[f"model.layers.{i}.post_attention_layernorm"].weight
+        assert not torch.equal(c.detach().cpu(), d.detach().cpu()), "gate/up are both smoothed: their norm absorbs 1/s"
+    with torch.no_grad():
+        y = q(ids[0].to("cuda")).logits.float()
+    assert rel_fro(y, ref) <= 0.08, rel_fro(y, ref)
