@@ -169,8 +169,8 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
   std::vector<uint16_t> hy = y.download(), hyo = y_old.download();
   int sched_mismatch = 0;
   if (M > 16) {
-    const int alts[2] = {4, 6};
-    for (int a = 0; a < 2; ++a) {
+    const int alts[3] = {40, 4, 6};  // 3A2B pinned / compiler-ordered / ping-pong vs the default (producer-consumer kernel)
+    for (int a = 0; a < 3; ++a) {
       inc_debug_set_small_tiles(alts[a]);
       INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y_old.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
       HIPCHECK(hipDeviceSynchronize());
@@ -223,8 +223,8 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
     // interleaved rounds (the first variant timed after an idle gap runs at lower clocks: single back-to-back timings were
     // biased by ~8 %): every round times every variant, rotating the order; the median over rounds is reported
     Timer t;
-    const int modes[3] = {0, 4, 6};
-    const char* labels[3] = {"3A2B pinned pipeline", "3A2B compiler sched", "3A2B ping-pong"};
+    const int modes[3] = {0, 40, 4};
+    const char* labels[3] = {"PC producer/consumer", "3A2B pinned pipeline", "3A2B compiler sched"};
     const int nv = 3, rounds = 5, iters = M <= 16 ? 100 : 8;
     std::vector<std::vector<float>> ms(nv);
     for (int i = 0; i < 10; ++i)  // warm the clocks
@@ -522,6 +522,8 @@ int main(int argc, char** argv) {
     fails += run_gemm_case(256, 256, 64, 32, false, true, false, 64);     // one tile, one K-step, gs=32 asym
     fails += run_gemm_case(300, 1000, 192, 64, false, true, false, 64);   // ragged M and N
     fails += run_gemm_case(1024, 768, 1024, 1024, true, false, false, 64);  // single group (g_shift = -1)
+    fails += run_gemm_case(300, 1000, 256, 64, false, true, false, 64);   // producer/consumer kernel: ragged M and N, gs=64 asym
+    fails += run_gemm_case(700, 520, 384, 128, false, true, false, 64);   // ... odd number of K-steps per slab guard, ragged tiles
     fails += run_gemm_case(4096, 4096, 4096, 128, true, false, true, 64);
     fails += run_gemm_case(4096, 11008, 4096, 128, true, false, true, 32);
     fails += run_gemm_case(4096, 4096, 11008, 128, true, false, true, 32);
@@ -644,6 +646,42 @@ int main(int argc, char** argv) {
       std::sort(ms[mi].begin(), ms[mi].end());
       const float med = ms[mi][ms[mi].size() / 2];
       printf("ABLATE %-24s median %8.4f ms  (%7.1f TFLOP/s equivalent)  best %8.4f\n", labels[mi], med, 2.0 * M * N * K / med / 1e9, ms[mi][0]);
+    }
+    inc_debug_set_small_tiles(0);
+  }
+  if (what == "pcablate") {  // timing-only ablations of the producer / consumer dequant-GEMM step (outputs are wrong by construction)
+    const int64_t M = 4096, N = 4096, K = 4096;
+    Packed W(N, K, 128, true);
+    DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
+    std::vector<uint16_t> hx(x.n);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    x.upload(hx);
+    const int nv = 24, rounds = 5, iters = 8;
+    const int modes[nv] = {0, 40, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72};
+    const char* labels[nv] = {"PC full step", "3A2B full step", "P: - dequant arithmetic", "P: - dequant - ds_write", "P: - x LDS-DMA", "P: - W loads",
+                              "P: - all global traffic", "P: idle (no loads, no dequant)", "C: - fragment reads", "MFMA + barrier only",
+                              "MFMA only", "C: - MFMA", "- barrier", "producers ALONE: full", "  alone - dequant arithmetic",
+                              "  alone - dequant - ds_write", "  alone - x LDS-DMA", "  alone - W loads", "  alone - all global traffic",
+                              "  alone: barriers only", "- epilogue stores", "consumers at s_setprio 2", "producers at s_setprio 2",
+                              "prologue + barriers, no stores"};
+    std::vector<std::vector<float>> ms(nv);
+    Timer t;
+    for (int i = 0; i < 10; ++i)
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+    for (int r = 0; r < rounds; ++r)
+      for (int vi = 0; vi < nv; ++vi) {
+        const int mi = (vi + r) % nv;
+        inc_debug_set_small_tiles(modes[mi]);
+        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+        t.start();
+        for (int i = 0; i < iters; ++i)
+          INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+        ms[mi].push_back(t.stop_ms() / iters);
+      }
+    for (int mi = 0; mi < nv; ++mi) {
+      std::sort(ms[mi].begin(), ms[mi].end());
+      const float med = ms[mi][ms[mi].size() / 2];
+      printf("PCABLATE %-32s median %8.4f ms  (%7.1f TFLOP/s equivalent)  best %8.4f\n", labels[mi], med, 2.0 * M * N * K / med / 1e9, ms[mi][0]);
     }
     inc_debug_set_small_tiles(0);
   }
