@@ -1482,14 +1482,25 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, const ui
 // Guideline 16) sums the partials in a fixed order, adds the bias, converts and stores -> one launch,
 // deterministic.  The counters live in the caller's workspace, must be zero on entry and are returned to
 // zero by the last arriver.
-constexpr int VS = 8;   // MFMA K=32 steps per wave
-template <bool IS_BF16, bool G128>
+// Hand-off of the split-K partials (MI355X_MICROARCH.md, "Valid forms besides R1/R2"): write-through (`sc1`) partial stores ->
+// every wave drains them (`s_waitcnt vmcnt(0)`) -> barrier -> ONE relaxed agent-scope ticket; the last arriver reads the slabs
+// with `sc1` loads (L1-bypassing), so neither side needs an agent-scope fence (the release / acquire pair this replaces cost
+// ~3.4 us of an 8.4 us kernel).  VSTEPS = MFMA K=32 steps per wave: 8 (a wave streams 8 KiB of weights) for large matrices,
+// 4 when that would leave CUs without a workgroup or SIMDs with a single wave (the dequantisation arithmetic of a wave is a
+// serial ~60-instruction chain per step).
+constexpr int VS = 8;   // largest VSTEPS (sizes the workspace)
+// MB = 16-row blocks of x per workgroup (M <= 16 * MB): batched decode (16 < M <= 64) streams the packed weights ONCE like the
+// M <= 16 case -- every dequantised B fragment feeds MB MFMAs -- instead of parking a 256-row tile that is mostly clamped rows.
+template <bool IS_BF16, bool G128, int VSTEPS, int MB>
 __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
     float* __restrict__ partial, unsigned* __restrict__ counters, int M, int64_t N, int64_t K, int64_t NW,
     int64_t G, int g_shift, int splitk) {
-  __shared__ float red[4 * 16 * 65];
+  constexpr int VS = VSTEPS;  // shadows the file-level maximum inside this kernel
+  constexpr int ROWS = 16 * MB;
+  constexpr int NOUT = ROWS * 64 / 256;  // outputs per thread of the strip
+  __shared__ float red[4 * ROWS * 65];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float inv_u = fp8_unit_inverse();
   const int strip = blockIdx.x, slice = blockIdx.y;
@@ -1501,17 +1512,20 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
   const int step0 = (slice * 4 + wave) * VS;
 
   // ---- issue every load of this wave up front ---------------------------------------------------
-  uint4 w[VS], a[VS];
-  const int am = jn < M ? jn : M - 1;  // A row (clamped; rows >= M are zeroed below)
+  uint4 w[VS], a[MB][VS];
 #pragma unroll
   for (int s = 0; s < VS; ++s) {
     int st = step0 + s;
     if (st > steps_total - 1) st = steps_total - 1;  // past-the-end steps re-read the last one and are zeroed via A
     w[s] = *reinterpret_cast<const uint4*>(qweight + ((int64_t)st * 4 + oct) * N + ncol);
-    a[s] = *reinterpret_cast<const uint4*>(x + (int64_t)am * K + (int64_t)st * 32 + 8 * oct);
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const int am = 16 * b + jn < M ? 16 * b + jn : M - 1;  // A row (clamped; rows >= M are zeroed below)
+      a[b][s] = *reinterpret_cast<const uint4*>(x + (int64_t)am * K + (int64_t)st * 32 + 8 * oct);
+    }
   }
-  // group parameters: G128 -> the wave's 256 k span at most the two groups of its two 128-k halves
-  constexpr int NG = G128 ? 2 : VS;
+  // group parameters: G128 -> one group per 4 steps (step0 is a multiple of 4)
+  constexpr int NG = G128 ? (VS + 3) / 4 : VS;
   uint2 sraw[NG];
   uint32_t zraw[NG];
 #pragma unroll
@@ -1523,13 +1537,13 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
     zraw[i] = qzeros[g * NW + (ncol >> 3)];
   }
   const int zsh = 4 * (int)(ncol & 7);  // ncol % 4 == 0: the 4 zero nibbles sit at bits zsh .. zsh+15
-  // this thread's 4 outputs of the strip: idx = tid + 256*i -> row idx>>6, column idx&63; bias fetched now
-  uint16_t braw[4];
+  // this thread's outputs of the strip: idx = tid + 256*i -> row idx>>6, column idx&63; bias fetched now
+  uint16_t braw[NOUT];
   const uint16_t* const bsrc = bias ? bias : scales;  // always a valid address: the loads stay unconditional
-  bool out_ok[4];
-  int64_t out_off[4];
+  bool out_ok[NOUT];
+  int64_t out_off[NOUT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NOUT; ++i) {
     const int idx = tid + 256 * i, m = idx >> 6, c = idx & 63;
     out_ok[i] = m < M && n0 + c < N;
     out_off[i] = out_ok[i] ? (int64_t)m * N + n0 + c : 0;
@@ -1537,16 +1551,22 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
   }
   __builtin_amdgcn_sched_barrier(0);  // everything above is in flight before the first use below
 
-  f32x4 acc[4];
+  f32x4 acc[MB][4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool row_ok = jn < M;
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < VS; ++s) {
     const int gi = G128 ? (s >> 2) : s;
-    const bool live = row_ok && (step0 + s < steps_total);
-    uint4 av = a[s];
-    av.x = live ? av.x : 0u; av.y = live ? av.y : 0u; av.z = live ? av.z : 0u; av.w = live ? av.w : 0u;
+    const bool in_k = step0 + s < steps_total;
+    uint4 av[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const bool live = in_k && (16 * b + jn < M);
+      av[b] = a[b][s];
+      av[b].x = live ? av[b].x : 0u; av[b].y = live ? av[b].y : 0u; av[b].z = live ? av[b].z : 0u; av[b].w = live ? av[b].w : 0u;
+    }
     const uint32_t sw[2] = {sraw[gi].x, sraw[gi].y};
     const uint32_t ww[4] = {w[s].x, w[s].y, w[s].z, w[s].w};
 #pragma unroll
@@ -1554,62 +1574,61 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
       const float sc = f16_bits_to_f32((uint16_t)(sw[c >> 1] >> (16 * (c & 1))));
       uint32_t zz = ((zraw[gi] >> (zsh + 4 * c)) & 15u) + 1u;
       zz = zz > 15u ? 0u : zz;
-      const uint4 b = dequant8<IS_BF16>(ww[c], sc * inv_u, -(float)zz * sc);
-      acc[c] = mfma16<IS_BF16>(av, b, acc[c]);
+      const uint4 bq = dequant8<IS_BF16>(ww[c], sc * inv_u, -(float)zz * sc);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) acc[b][c] = mfma16<IS_BF16>(av[b], bq, acc[b][c]);
     }
   }
-  // ---- reduce the 4 waves: D col = lane&15 -> column 4*jn + c, row m = 4*oct + r ------------------
+  // ---- reduce the 4 waves: D col = lane&15 -> column 4*jn + c, row m = 16*b + 4*oct + r ------------------
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int b = 0; b < MB; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * oct + r) * 65 + 4 * jn + c] = acc[c][r];
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * ROWS + 16 * b + 4 * oct + r) * 65 + 4 * jn + c] = acc[b][c][r];
   __syncthreads();
-  float sum[4];
+  float sum[NOUT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NOUT; ++i) {
     const int idx = tid + 256 * i, m = idx >> 6, c = idx & 63;
-    sum[i] = red[(0 * 16 + m) * 65 + c] + red[(1 * 16 + m) * 65 + c] + red[(2 * 16 + m) * 65 + c] + red[(3 * 16 + m) * 65 + c];
+    sum[i] = red[(0 * ROWS + m) * 65 + c] + red[(1 * ROWS + m) * 65 + c] + red[(2 * ROWS + m) * 65 + c] + red[(3 * ROWS + m) * 65 + c];
   }
   if (splitk > 1) {
     const int64_t slab = (int64_t)M * N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (out_ok[i]) partial[(int64_t)slice * slab + out_off[i]] = sum[i];
-    // publish: drain the stores of every wave, then one agent-scope release + ticket from lane 0
+    for (int i = 0; i < NOUT; ++i)
+      if (out_ok[i]) __hip_atomic_store(&partial[(int64_t)slice * slab + out_off[i]], sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
+    // publish: every wave drains its write-through stores, then one relaxed agent-scope ticket from lane 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned ticket = __hip_atomic_fetch_add(&counters[strip], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)(splitk - 1);
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(&counters[strip], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
-      }
+      if (last) __hip_atomic_store(&counters[strip], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
       red[0] = last ? 1.f : 0.f;
     }
     __syncthreads();
     if (red[0] == 0.f) return;
-    // last arriver: fixed-order sum over the slices, 4 slices x 4 outputs of loads in flight at a time
+    // last arriver: fixed-order sum over the slices, up to 32 partial loads of this thread in flight at a time
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sum[i] = 0.f;
-    for (int sl0 = 0; sl0 < splitk; sl0 += 4) {
-      float pv[4][4];
+    for (int i = 0; i < NOUT; ++i) sum[i] = 0.f;
+    constexpr int SB = 32 / NOUT;  // slices per batch (8 for M <= 16: one L2 round trip for up to 8 slices)
+    for (int sl0 = 0; sl0 < splitk; sl0 += SB) {
+      float pv[SB][NOUT];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
+      for (int d = 0; d < SB; ++d) {
         const int sl = sl0 + d < splitk ? sl0 + d : splitk - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pv[d][i] = partial[(int64_t)sl * slab + out_off[i]];
+        for (int i = 0; i < NOUT; ++i) pv[d][i] = __hip_atomic_load(&partial[(int64_t)sl * slab + out_off[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
       }
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < SB; ++d)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sum[i] += (sl0 + d < splitk) ? pv[d][i] : 0.f;
+        for (int i = 0; i < NOUT; ++i) sum[i] += (sl0 + d < splitk) ? pv[d][i] : 0.f;
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NOUT; ++i)
     if (out_ok[i]) {
       const float v = sum[i] + (bias ? cvt16<IS_BF16>(braw[i]) : 0.f);
       y[out_off[i]] = IS_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
@@ -1660,15 +1679,20 @@ static int big_splitk(int64_t M, int64_t N, int64_t K, int* steps_out) {
   return splits;
 }
 
+constexpr int64_t GEMV_MAX_M = 64;  // M <= 64 streams the weights once (woq_gemv_w4_kernel with 1 / 2 / 4 row blocks)
+
 int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  int64_t big = 0;
   if (M > 16) {
     int steps;
     const int splits = M > 16 && N >= 64 ? big_splitk(M, N, K, &steps) : 1;
-    return splits > 1 ? WS_COUNTER_BYTES + (int64_t)splits * M * N * 4 : 0;  // slabs start AFTER the counter block
+    big = splits > 1 ? WS_COUNTER_BYTES + (int64_t)splits * M * N * 4 : 0;  // slabs start AFTER the counter block
+    if (M > GEMV_MAX_M) return big;
   }
-  int64_t slices = ceil_div64(K, 32 * VS * 4);
+  int64_t slices = ceil_div64(K, 32 * 4 * 4);  // the streaming kernel at 4 steps per wave
   if (slices < 64) slices = 64;  // the generic split-K path uses up to 64 slices
-  return WS_COUNTER_BYTES + slices * M * N * 4;
+  const int64_t small = WS_COUNTER_BYTES + slices * M * N * 4;
+  return small > big ? small : big;
 }
 
 int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16_t* scales,
@@ -1697,7 +1721,9 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   else if (group_size >= 32 && (group_size & (group_size - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < group_size) ++g_shift; }
   // 16 < M < 128 (batched decode) runs the same 256-row tile with most rows clamped: with split-K over up to 16 slabs that is
   // 30 us at 64 x 4096 x 4096 where the 128x128 register-staged kernel needed 208 us (and 615 us at 17 x 4096 x 11008)
-  const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M > 16 && N >= 64 &&
+  const bool gemv_ok = bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && ceil_div64(N, 64) * 4 <= WS_COUNTER_BYTES &&
+                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !inc_force_small_tiles() && M <= GEMV_MAX_M && inc_small_tiles_flag(-1) != 42;
+  const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M > 16 && N >= 64 && !(gemv_ok && ceil_div64(K, 32 * 4 * 4) <= 64) &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
   const int dbg = inc_small_tiles_flag(-1);
   // weight-only INT8 (BASELINE config #1's layers): the 3A2B kernel's 8-bit instantiation, same tiling and split-K plan
@@ -1730,7 +1756,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
       if (bf) splitk_slab_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
       else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
     }
-  } else if (big_ok && (K % 128) == 0 && (g_shift == -1 || g_shift >= 6) && (dbg == 0 || (dbg >= 51 && dbg <= 72)) && INC_GEMM_DEFAULT_PC) {
+  } else if (big_ok && (K % 128) == 0 && (g_shift == -1 || g_shift >= 6) && (dbg == 0 || dbg == 42 || (dbg >= 51 && dbg <= 72)) && INC_GEMM_DEFAULT_PC) {
     // producer / consumer specialisation of the 3A2B tile (one scale per column and K-step: group_size >= 64)
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
     static std::atomic<uint64_t> pc_attr_set{0};
@@ -1858,7 +1884,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
     if (bf) woq_gemm_w4_big_kernel<true><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
     else woq_gemm_w4_big_kernel<false><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
-  } else if (M > 16) {
+  } else if (M > 16 && !(gemv_ok && ceil_div64(K, 32 * 4 * 4) <= 64)) {
     const int x_vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const size_t smem = (size_t)2 * 2 * GM * GP * sizeof(uint16_t);
     static std::atomic<uint64_t> attr_set{0};
@@ -1874,17 +1900,21 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     if (bits == 4) { if (bf) INC_TILE(4, true); else INC_TILE(4, false); }
     else { if (bf) INC_TILE(8, true); else INC_TILE(8, false); }
 #undef INC_TILE
-  } else if (bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && ceil_div64(N, 64) * 4 <= WS_COUNTER_BYTES &&
-             (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !inc_force_small_tiles()) {
-    const int splitk = (int)ceil_div64(K, 32 * VS * 4);
+  } else if (gemv_ok && (M <= 16 || ceil_div64(K, 32 * 4 * 4) <= 64)) {
+    // 8 steps per wave when that still gives every SIMD two waves (>= 512 workgroups), else 4; row-blocked (M > 16): always 4
+    const bool vs4 = M > 16 || (ceil_div64(N, 64) * ceil_div64(K, 32 * 8 * 4) < 512 && ceil_div64(K, 32 * 4 * 4) <= 64);
+    const int vsteps = vs4 ? 4 : 8;
+    const int splitk = (int)ceil_div64(K, 32 * vsteps * 4);
     if (!workspace || workspace_bytes < WS_COUNTER_BYTES + (int64_t)splitk * M * N * 4) return INC_ERR_WORKSPACE;
     unsigned* counters = (unsigned*)workspace;
     float* part = (float*)((char*)workspace + WS_COUNTER_BYTES);
     dim3 grid((unsigned)ceil_div64(N, 64), (unsigned)splitk);
     const bool g128 = g_shift == -1 || g_shift >= 7;
-#define INC_GEMV(F, GG) woq_gemv_w4_kernel<F, GG><<<grid, 256, 0, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, G, g_shift, splitk)
-    if (bf) { if (g128) INC_GEMV(true, true); else INC_GEMV(true, false); }
-    else { if (g128) INC_GEMV(false, true); else INC_GEMV(false, false); }
+#define INC_GEMV(F, GG, V, B) woq_gemv_w4_kernel<F, GG, V, B><<<grid, 256, 0, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, G, g_shift, splitk)
+#define INC_GEMV2(F, GG) { if (M > 32) INC_GEMV(F, GG, 4, 4); else if (M > 16) INC_GEMV(F, GG, 4, 2); else if (vs4) INC_GEMV(F, GG, 4, 1); else INC_GEMV(F, GG, 8, 1); }
+    if (bf) { if (g128) INC_GEMV2(true, true) else INC_GEMV2(true, false) }
+    else { if (g128) INC_GEMV2(false, true) else INC_GEMV2(false, false) }
+#undef INC_GEMV2
 #undef INC_GEMV
   } else {
     int kw_per_slice = 0;

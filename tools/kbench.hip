@@ -168,7 +168,7 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
   // (0) the alternative schedules of the 3A2B kernel keep the accumulation order: bit-identical outputs required
   std::vector<uint16_t> hy = y.download(), hyo = y_old.download();
   int sched_mismatch = 0;
-  if (M > 16) {
+  if (M > 64) {  // (M <= 64 takes the streaming kernel: another summation order)
     const int alts[3] = {40, 4, 6};  // 3A2B pinned / compiler-ordered / ping-pong vs the default (producer-consumer kernel)
     for (int a = 0; a < 3; ++a) {
       inc_debug_set_small_tiles(alts[a]);
@@ -223,8 +223,8 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
     // interleaved rounds (the first variant timed after an idle gap runs at lower clocks: single back-to-back timings were
     // biased by ~8 %): every round times every variant, rotating the order; the median over rounds is reported
     Timer t;
-    const int modes[3] = {0, 40, 4};
-    const char* labels[3] = {"PC producer/consumer", "3A2B pinned pipeline", "3A2B compiler sched"};
+    const int modes[3] = {0, M <= 64 ? 42 : 40, 4};
+    const char* labels[3] = {M <= 64 ? "streaming (default)" : "PC producer/consumer", M <= 64 ? "256-row tile + split-K" : "3A2B pinned pipeline", "3A2B compiler sched"};
     const int nv = 3, rounds = 5, iters = M <= 16 ? 100 : 8;
     std::vector<std::vector<float>> ms(nv);
     for (int i = 0; i < 10; ++i)  // warm the clocks
@@ -233,6 +233,7 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
       for (int vi = 0; vi < nv; ++vi) {
         const int mi = (vi + r) % nv, mode = modes[mi];
         if (mode != 0 && M <= 16) continue;
+        if (mode == 4 && M <= 64) continue;
         inc_debug_set_small_tiles(mode);
         INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
         t.start();
@@ -533,6 +534,9 @@ int main(int argc, char** argv) {
     fails += run_gemm_case(64, 4096, 4096, 128, true, false, true, 64);
     fails += run_gemm_case(32, 11008, 4096, 128, true, false, true, 32);
     fails += run_gemm_case(17, 4096, 11008, 128, true, false, true, 17);
+    fails += run_gemm_case(33, 1000, 416, 32, false, true, false, 33);   // streaming kernel, 3 row blocks used of 4, ragged N, gs=32
+    fails += run_gemm_case(48, 4096, 4096, 128, false, true, true, 48);
+    fails += run_gemm_case(256, 4096, 4096, 128, true, false, true, 64);
   }
   if (what == "gemv" || what == "all") {
     fails += run_gemm_case(1, 4096, 4096, 128, true, false, true, 1);
