@@ -403,6 +403,9 @@ def main():
 
     clock = KernelClock()
     clock.wrap(ops, "gptq_hessian_accum", lambda H, x, b, a: f"hessian_K{x.shape[1]}", lambda H, x, b, a: 2.0 * x.shape[0] * x.shape[1] ** 2)
+    # the driver's normal path: ALL Hessians of one stacked forward in one launch (inc_gptq_hessian_accum_multi)
+    clock.wrap(ops, "gptq_hessian_accum_multi", lambda items: "hessian_multi_K" + "+".join(str(x.shape[1]) for _, x, _, _ in items),
+               lambda items: sum(2.0 * x.shape[0] * x.shape[1] ** 2 for _, x, _, _ in items))
     clock.wrap(ops, "gptq_quant_block", lambda w, *a: "quant_block", lambda w, *a: 2.0 * w.shape[0] * w.shape[1] * 4)
     clock.wrap(ops, "gptq_lazy_update", lambda w, h, e, i1, c: "lazy_update", lambda w, h, e, i1, c: 2.0 * w.shape[0] * c * max(w.shape[1] - i1 - c, 0))
 
@@ -437,22 +440,25 @@ def main():
         dom = max(hess, key=lambda k: hess[k]["total_ms"])
         v = hess[dom]
         achieved = v["work"] / (v["total_ms"] * 1e-3) / 1e12
-        Kdom = int(dom.split("K")[-1])
-        nt = -(-Kdom // 256)
-        executed = (nt * (nt + 1) / 2) / (nt * nt)  # the kernel multiplies the upper-triangular 256x256 tiles only
+        Ks = [int(t) for t in dom.split("K")[-1].split("+")]
+        tokens = int(round(v["work"] / v["launches"] / sum(2.0 * k * k for k in Ks)))
+        # the kernel multiplies the upper-triangular 256x256 tiles only: executed / algorithmic flops of the launch
+        tiles = [(-(-k // 256)) for k in Ks]
+        executed = sum(t * (t + 1) / 2 * 256 * 256 for t in tiles) / sum(float(k) * k for k in Ks)
         all_work = sum(x["work"] for x in hess.values())
         all_ms = sum(x["total_ms"] for x in hess.values())
         traffic, traffic_src = _pmc_traffic(dom)
-        roofline = dict(kernel=f"hessian_syrk_16bit_256_kernel<bf16> ({dom}; algorithmic flops 2*T*K^2 per launch)", bound="mfma",
+        multi = dom.startswith("hessian_multi")
+        roofline = dict(kernel=("hessian_syrk_16bit_256_multi_kernel<bf16>" if multi else "hessian_syrk_16bit_256_kernel<bf16>") +
+                               f" ({dom}; algorithmic flops 2*T*K^2 per Hessian and launch)", bound="mfma",
                         achieved=round(achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
-                        avg_launch_ms=round(v["avg_ms"], 4), launches=v["launches"],
-                        tokens_per_launch=int(round(v["work"] / v["launches"] / (2.0 * Kdom * Kdom))),
+                        avg_launch_ms=round(v["avg_ms"], 4), launches=v["launches"], tokens_per_launch=tokens,
                         executed_frac=round(achieved * executed / BF16_MFMA_PEAK_TFLOPS, 4),
                         all_launches_frac=round(all_work / (all_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
-                        note="algorithmic = the full X^T X product (SURVEY 8d); the syrk kernel executes the upper-triangular tiles "
+                        note="algorithmic = the full X^T X products (SURVEY 8d); the syrk kernel executes the upper-triangular tiles "
                              f"only ({executed:.3f} of it): executed_frac is the matrix-pipe view of the same time; all_launches_frac = "
-                             "algorithmic flops of EVERY Hessian launch of the timed region (all K) / their summed time")
+                             "algorithmic flops of EVERY Hessian launch of the timed region / their summed time")
 
     result = dict(
         metric="llama2_7b_gptq_int4_g128_quantize_wall_clock", value=round(value, 3), unit="s", n_gpus=world,

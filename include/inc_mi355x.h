@@ -162,6 +162,16 @@ int inc_mse_accumulate(const void* a, const void* b, int dtype, int64_t n, doubl
 int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int64_t ldx, float* H,
                            float beta, float alpha, inc_stream_t stream);
 
+/* The same update for up to 8 Hessians in ONE launch: the distinct layer inputs of one calibration forward of a block
+ * (add_batch runs once per hooked layer per forward, gptq.py:670-688) -- xs[i] [T,Ks[i]] 16-bit with row stride
+ * ldxs[i], Hs[i] [Ks[i],Ks[i]] fp32, all with the same token count T.  Every tile is computed exactly as by
+ * inc_gptq_hessian_accum (bit-identical H); what changes is that the small Hessians no longer leave half of the CUs idle.
+ * INC_ERR_UNSUPPORTED (nothing launched) for fp32 inputs, K < 256, unaligned rows or more than 8 problems: call the
+ * single-problem entry instead.  The pointer / size arrays are HOST arrays, read before the call returns.             */
+int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64_t T, const int64_t* Ks,
+                                 const int64_t* ldxs, float* const* Hs, const float* betas, const float* alphas,
+                                 inc_stream_t stream);
+
 /* == GPTQ.fasterquant prologue (gptq.py:1186-1189, 1221-1227): mirror the upper triangle to the
  *   lower, dead[i] = (H[i,i]==0) -> H[i,i]=1, damp = percdamp*mean(diag(H)), H[i,i] += damp.
  *   dead: uint8 [K] out.  workspace: >= 16 bytes.                                               */

@@ -40,6 +40,7 @@ SIGNATURES = {
     "inc_mse_accumulate_workspace_bytes": (c_int64, []),
     "inc_mse_accumulate": (c_int, [_P, _P, c_int, c_int64, _P, _P, _P]),
     "inc_gptq_hessian_accum": (c_int, [_P, c_int, c_int64, c_int64, c_int64, _P, c_float, c_float, _P]),
+    "inc_gptq_hessian_accum_multi": (c_int, [c_int, _P, c_int, c_int64, _P, _P, _P, _P, _P, _P]),
     "inc_gptq_hessian_finalize": (c_int, [_P, c_int64, c_float, _P, _P, _P]),
     "inc_gptq_prepare_weight": (c_int, [_P, c_int, _P, _P, c_int64, c_int64, _P]),
     "inc_gptq_find_params": (

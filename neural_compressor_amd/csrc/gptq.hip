@@ -251,14 +251,14 @@ __device__ __forceinline__ void load_block8x8_fast(const uint16_t* __restrict__ 
   }
 }
 
+// one 256x256 tile of  H <- beta*H + alpha*X^T X:  `block` of `nblocks` workgroups of ONE problem
 template <bool IS_BF16, bool TAIL>
-__global__ __launch_bounds__(512) void hessian_syrk_16bit_256_kernel(const uint16_t* __restrict__ x, int64_t T,
-                                                                     int64_t K, int64_t ldx, float* __restrict__ H,
-                                                                     float beta, float alpha, int nt) {
+__device__ __forceinline__ void hessian_syrk_256_tile(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
+                                                      float* __restrict__ H, float beta, float alpha, int nt, int block, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint16_t* smem = reinterpret_cast<uint16_t*>(smem_raw);
   int ti, tj;
-  xcd_supertile_decode(blockIdx.x, gridDim.x, nt, ti, tj);
+  xcd_supertile_decode(block, nblocks, nt, ti, tj);
   const int64_t i0 = (int64_t)ti * H2, j0 = (int64_t)tj * H2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
@@ -340,6 +340,44 @@ __global__ __launch_bounds__(512) void hessian_syrk_16bit_256_kernel(const uint1
         }
       }
     }
+}
+
+template <bool IS_BF16, bool TAIL>
+__global__ __launch_bounds__(512) void hessian_syrk_16bit_256_kernel(const uint16_t* __restrict__ x, int64_t T,
+                                                                     int64_t K, int64_t ldx, float* __restrict__ H,
+                                                                     float beta, float alpha, int nt) {
+  hessian_syrk_256_tile<IS_BF16, TAIL>(x, T, K, ldx, H, beta, alpha, nt, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several Hessians of ONE calibration forward in a single launch (same token count T): the three K = 4096 Hessians of a Llama
+// block have 136 tiles each -- alone they leave 120 of the 256 CUs idle for the whole launch (0.395 of peak by the 2*T*K^2
+// convention against 0.64 at K = 11008, profiles/r1l); together with the K = 11008 one they are 1354 tiles of equal length
+// that the dispatcher spreads over the chip.  Problems occupy contiguous block ranges; inside its range a problem keeps its
+// XCD-local super-tile order (the decode only needs the block's index modulo 8 to be constant per XCD, which a shifted range
+// preserves).  Each tile is computed exactly as in the single-problem launch: bit-identical H.
+constexpr int HESSIAN_MAX_BATCH = 8;
+struct HessianBatch {
+  const uint16_t* x[HESSIAN_MAX_BATCH];
+  float* H[HESSIAN_MAX_BATCH];
+  int64_t K[HESSIAN_MAX_BATCH];
+  int64_t ldx[HESSIAN_MAX_BATCH];
+  float beta[HESSIAN_MAX_BATCH];
+  float alpha[HESSIAN_MAX_BATCH];
+  int nt[HESSIAN_MAX_BATCH];
+  int first[HESSIAN_MAX_BATCH + 1];  // first block of every problem, then the grid size
+  int n;
+};
+
+template <bool IS_BF16, bool TAIL>
+__global__ __launch_bounds__(512) void hessian_syrk_16bit_256_multi_kernel(HessianBatch args, int64_t T) {
+  const int b = (int)blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < HESSIAN_MAX_BATCH; ++i)
+    if (i < args.n && b >= args.first[i]) p = i;
+  p = __builtin_amdgcn_readfirstlane(p);
+  hessian_syrk_256_tile<IS_BF16, TAIL>(args.x[p], T, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p], args.nt[p],
+                                       b - args.first[p], args.first[p + 1] - args.first[p]);
 }
 
 // ---- fp32 inputs: exact fp32 MFMA 32x32x2 ------------------------------------------------------
@@ -932,6 +970,47 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
   } else {
     return INC_ERR_UNSUPPORTED;
   }
+  INC_LAUNCH_RETURN();
+}
+
+int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64_t T, const int64_t* Ks, const int64_t* ldxs,
+                                 float* const* Hs, const float* betas, const float* alphas, inc_stream_t stream) {
+  INC_CHECK_ARG(n > 0 && xs && Ks && ldxs && Hs && betas && alphas && T > 0);
+  if (n > HESSIAN_MAX_BATCH || !(xdtype == INC_BF16 || xdtype == INC_F16) || inc_force_small_tiles()) return INC_ERR_UNSUPPORTED;
+  HessianBatch a;
+  int first = 0;
+  for (int i = 0; i < n; ++i) {
+    INC_CHECK_ARG(xs[i] && Hs[i] && Ks[i] > 0 && ldxs[i] >= Ks[i]);
+    const bool vec_ok = (ldxs[i] % 8 == 0) && ((reinterpret_cast<uintptr_t>(xs[i]) & 15) == 0);
+    if (!(Ks[i] >= H2 && vec_ok && (Ks[i] % 8) == 0)) return INC_ERR_UNSUPPORTED;  // the caller falls back to single launches
+    a.x[i] = (const uint16_t*)xs[i];
+    a.H[i] = Hs[i];
+    a.K[i] = Ks[i];
+    a.ldx[i] = ldxs[i];
+    a.beta[i] = betas[i];
+    a.alpha[i] = alphas[i];
+    a.nt[i] = (int)ceil_div64(Ks[i], H2);
+    a.first[i] = first;
+    first += a.nt[i] * (a.nt[i] + 1) / 2;
+  }
+  for (int i = n; i <= HESSIAN_MAX_BATCH; ++i) a.first[i] = first;
+  for (int i = n; i < HESSIAN_MAX_BATCH; ++i) { a.x[i] = a.x[0]; a.H[i] = a.H[0]; a.K[i] = a.K[0]; a.ldx[i] = a.ldx[0]; a.beta[i] = 1.f; a.alpha[i] = 0.f; a.nt[i] = a.nt[0]; }
+  a.n = n;
+  const size_t smem2 = (size_t)2 * H2_STAGE * sizeof(uint16_t);  // 144 KiB
+  static std::atomic<uint64_t> attr_set{0};
+  if (inc_attr_needed(attr_set)) {
+    (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+    (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+    (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+    (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+    inc_attr_done(attr_set);
+  }
+  hipStream_t s = inc_s(stream);
+  const bool tail = (T % HK) != 0;
+#define INC_HM(B, TL) hessian_syrk_16bit_256_multi_kernel<B, TL><<<first, 512, smem2, s>>>(a, T)
+  if (xdtype == INC_BF16) { if (tail) INC_HM(true, true); else INC_HM(true, false); }
+  else { if (tail) INC_HM(false, true); else INC_HM(false, false); }
+#undef INC_HM
   INC_LAUNCH_RETURN();
 }
 

@@ -318,6 +318,36 @@ def gptq_hessian_accum(H, x2d, beta, alpha):
     return H
 
 
+def gptq_hessian_accum_multi(items):
+    """One launch for several Hessians of the same forward: items = [(H [K,K] fp32, x2d [T,K] 16-bit, beta, alpha), ...],
+    all x2d with the same dtype and token count.  Returns False (nothing launched) when the library declines the batch
+    (fp32 inputs, K < 256, more than 8 problems): the caller then uses gptq_hessian_accum per item."""
+    import ctypes
+
+    n = len(items)
+    x0 = items[0][1]
+    if n > 8 or x0.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    dev = _dev(*[t for H, x, _, _ in items for t in (H, x)])
+    T = x0.shape[0]
+    for H, x, _, _ in items:
+        assert H.dtype == torch.float32 and x.dim() == 2 and H.shape == (x.shape[1], x.shape[1])
+        if x.dtype != x0.dtype or x.shape[0] != T:
+            return False
+    xs = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x, _, _ in items])
+    Hs = (ctypes.c_void_p * n)(*[H.data_ptr() for H, _, _, _ in items])
+    Ks = (ctypes.c_int64 * n)(*[x.shape[1] for _, x, _, _ in items])
+    ld = (ctypes.c_int64 * n)(*[x.stride(0) for _, x, _, _ in items])
+    be = (ctypes.c_float * n)(*[float(b) for _, _, b, _ in items])
+    al = (ctypes.c_float * n)(*[float(a) for _, _, _, a in items])
+    with torch.cuda.device(dev):
+        rc = lib.inc_gptq_hessian_accum_multi(n, xs, dtype_code(x0.dtype), T, Ks, ld, Hs, be, al, _stream())
+    if rc == -2:  # INC_ERR_UNSUPPORTED: nothing was launched
+        return False
+    check(rc, "inc_gptq_hessian_accum_multi")
+    return True
+
+
 def gptq_hessian_finalize(H, percdamp):
     """mirror + dead-column fix + damping (gptq.py:1186-1189, 1221-1227). Returns the uint8 dead mask [K]."""
     dev = _dev(H)

@@ -171,18 +171,25 @@ class HessianAccumulator:
     """
 
     STAGE_TOKENS = int(os.environ.get("INC_MI355X_HESSIAN_STAGE_TOKENS", "16384"))
+    # an input that already holds a full stage of tokens (the driver's stacked forwards) is read in place instead of being
+    # copied into the staging buffer; INC_MI355X_HESSIAN_ZERO_COPY=0 restores the copy (needed only for a model that
+    # modifies a Linear's input in place later in the same forward -- detected at launch time, never silent)
+    ZERO_COPY = os.environ.get("INC_MI355X_HESSIAN_ZERO_COPY", "1") == "1"
 
     def __init__(self, columns, device):
         self.columns = columns
         self.device = device
         self.H = None  # allocated on the first batch: aliased layers never allocate theirs
         self._n = 0           # batches already folded into H
-        self._pending = 0     # batches staged, not yet folded
+        self._pending = 0     # batches staged (or held by reference), not yet folded
         self._stage = None    # [capacity tokens, K] staging buffer in the activation dtype
         self._fill = 0
+        self._direct = None   # (x2d, version) of an input read in place at the next launch
+        self.defer = False    # True: a full stage waits for flush_many (one launch for all Hessians of a forward)
         self.finalized = None  # (Hinv, dead, perm) cache keyed by (percdamp, act_order)
         self._info = None      # status word of a factorisation whose check was deferred (see check())
         self._handles = None   # pending broadcasts of a factor received from its owner rank (mode "sample+rows")
+        self._ready = None     # event of a factorisation that ran on a side stream (prefactor)
 
     @property
     def nsamples(self):
@@ -196,6 +203,14 @@ class HessianAccumulator:
         T = x2d.shape[0]
         if self.H is None:
             self.H = torch.zeros((self.columns, self.columns), dtype=torch.float32, device=x2d.device)
+        if self._direct is not None:
+            self.flush()
+        if self.ZERO_COPY and self._pending == 0 and T >= self.STAGE_TOKENS and x2d.is_contiguous() and x2d.data_ptr() % 16 == 0:
+            self._direct = (x2d, x2d._version)
+            self._pending = b
+            if not self.defer:
+                self.flush()
+            return
         if self._stage is not None and (self._stage.dtype != x2d.dtype or self._fill + T > self._stage.shape[0]):
             self.flush()
             if self._stage.dtype != x2d.dtype or T > self._stage.shape[0]:
@@ -205,7 +220,7 @@ class HessianAccumulator:
         self._stage[self._fill:self._fill + T].copy_(x2d)
         self._fill += T
         self._pending += b
-        if self._fill >= self.STAGE_TOKENS:
+        if self._fill >= self.STAGE_TOKENS and not self.defer:
             self.flush()
 
     def allreduce(self, group=None):
@@ -220,13 +235,49 @@ class HessianAccumulator:
             self.H = torch.zeros((self.columns, self.columns), dtype=torch.float32, device=self.device)
         self.H, self._n = allreduce_hessian(self.H, self._n, group=group)
 
-    def flush(self):
+    def _launch_item(self):
+        """(H, x2d, beta, alpha) of the pending update  H <- H*n/(n+B) + 2/(n+B) X_B^T X_B, or None."""
         if self._pending == 0:
-            return
-        beta = self._n / (self._n + self._pending)
+            return None
+        if self._direct is not None:
+            x, version = self._direct
+            if x._version != version:
+                raise RuntimeError("a Linear's input was modified in place before its Hessian update was launched; "
+                                   "set INC_MI355X_HESSIAN_ZERO_COPY=0 for this model")
+        else:
+            x = self._stage[: self._fill]
+        n = self._n + self._pending
+        return self.H, x, self._n / n, 2.0 / n
+
+    def _committed(self):
         self._n += self._pending
-        ops.gptq_hessian_accum(self.H, self._stage[: self._fill], beta, 2.0 / self._n)
-        self._fill, self._pending = 0, 0
+        self._fill, self._pending, self._direct = 0, 0, None
+
+    def flush(self):
+        item = self._launch_item()
+        if item is not None:
+            ops.gptq_hessian_accum(*item)
+            self._committed()
+
+    @staticmethod
+    def flush_many(accs):
+        """Fold the pending batches of several accumulators with ONE launch (inc_gptq_hessian_accum_multi) when the
+        library takes the batch, else one launch each; every tile is computed as in the single launch."""
+        todo, seen = [], set()
+        for acc in accs:
+            if id(acc) in seen:
+                continue
+            seen.add(id(acc))
+            item = acc._launch_item()
+            if item is not None:
+                todo.append((acc, item))
+        if not todo:
+            return
+        if not (len(todo) > 1 and ops.gptq_hessian_accum_multi([item for _, item in todo])):
+            for _, item in todo:
+                ops.gptq_hessian_accum(*item)
+        for acc, _ in todo:
+            acc._committed()
 
     def inverse_factor(self, percdamp, act_order):
         """Upper Cholesky factor of (H + damp I)^-1 (gptq.py:1186-1231); consumes H.  Cached so that layers
@@ -237,6 +288,9 @@ class HessianAccumulator:
                 for h in self._handles:
                     h.wait()
                 self._handles = None
+            if self._ready is not None:  # factorised on a side stream (prefactor): order this stream behind it
+                torch.cuda.current_stream().wait_event(self._ready)
+                self._ready = None
             return self.finalized[1:]
         self.flush()
         self._stage = None
@@ -260,6 +314,24 @@ class HessianAccumulator:
         self.H = None
         self.finalized = (key, Hinv, dead, perm)
         return Hinv, dead, perm
+
+    def prefactor(self, stream, percdamp, act_order):
+        """Run the factorisation on `stream` (a side stream): the independent Hessians of a block are factorised
+        concurrently -- each is a chain of one-workgroup diagonal-block kernels and fp32 GEMMs that leaves most of the chip
+        idle on its own -- instead of one after another.  The consumer (`inverse_factor` on the solve's stream) waits on
+        the recorded event."""
+        main = torch.cuda.current_stream()
+        self.flush()
+        H = self.H
+        stream.wait_stream(main)
+        with torch.cuda.stream(stream):
+            if H is not None:
+                H.record_stream(stream)  # allocated on `main`, read (and dropped) under `stream`
+            out = self.inverse_factor(percdamp, act_order)
+            for t in out:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)  # allocated under `stream`, consumed by the column loop on `main`
+            self._ready = stream.record_event()
 
     def check(self):
         """Raise if the (deferred) factorisation met a non-positive pivot; one host synchronisation."""
@@ -470,6 +542,9 @@ class RAWGPTQuantizer(object):
         self.max_seq_length = max_seq_length
         self.nsamples = nsamples
         self.share_hessians = kwargs.get("share_hessians", True)
+        self.factor_streams = int(os.environ.get("INC_MI355X_GPTQ_FACTOR_STREAMS", "4"))
+        self._fstreams = []
+        self._stacks = {}  # first batch index of a forward group -> (stacked hidden states, the list entries that are its slices)
         self.block_callback = kwargs.get("block_callback", None)  # used by the multi-GPU driver
         # sample-sharded multi-GPU calibration: every rank feeds ITS calibration samples through prepare()/run_fn and the
         # per-layer Hessians are all-reduced before each solve; pass True (default process group) or a process group
@@ -614,18 +689,30 @@ class RAWGPTQuantizer(object):
             j0 = group[0]
             kw = self.gather_single_batch_from_dict(self.cache_key_arguments, j0)
             pos = self.gather_single_batch_from_list(self.cache_positional_arguments, j0)
+            src = self.cache_key_arguments["hidden_states"] if in_kwargs else self.cache_positional_arguments[0]
             if len(group) > 1:
-                if in_kwargs:
-                    kw["hidden_states"] = torch.cat([self.cache_key_arguments["hidden_states"][j] for j in group], dim=0)
+                # the cached inputs of a group are normally the slices of ONE tensor -- the previous block's stacked output
+                # (recorded below): reuse it instead of concatenating 8 x 16 MiB again for every forward
+                held = self._stacks.get(j0)
+                if held is not None and len(held[1]) == len(group) and all(src[j] is v for j, v in zip(group, held[1])):
+                    stacked = held[0]
                 else:
-                    pos[0] = torch.cat([self.cache_positional_arguments[0][j] for j in group], dim=0)
+                    stacked = torch.cat([src[j] for j in group], dim=0)
+                    self._stacks[j0] = (stacked, [src[j] for j in group])  # valid while the list still holds these objects
+                if in_kwargs:
+                    kw["hidden_states"] = stacked
+                else:
+                    pos[0] = stacked
             out = self.track_hidden_states(block(*pos, **kw))
             if on_output is not None:
                 if len(group) == 1:
                     on_output(j0, out)
                 else:
-                    for i, j in enumerate(group):
-                        on_output(j, out[i : i + 1])
+                    views = [out[i : i + 1] for i in range(len(group))]
+                    for j, v in zip(group, views):
+                        on_output(j, v)
+                    if out.is_contiguous() and all(src[j] is v for j, v in zip(group, views)):
+                        self._stacks[j0] = (out, views)  # the callback stored the slices: they ARE the next stacked input
         self.cache_key_arguments["batch_num"] = batch_num
 
     def _forward_groups(self, batch_num, in_kwargs, block=None):
@@ -773,7 +860,7 @@ class RAWGPTQuantizer(object):
         layer.to(self.device)
         solver = GPTQ(layer, device=self.device)
         solver.configure(cfg)
-        handle = layer.register_forward_hook(lambda _, inp, out: solver.add_batch(inp[0].data))
+        handle = layer.register_forward_hook(lambda _, inp, out: solver.add_batch(inp[0].detach()))
         for j in range(self.cache_key_arguments["batch_num"]):
             if "hidden_states" in self.cache_key_arguments:
                 layer(self.cache_key_arguments["hidden_states"][j])
@@ -828,7 +915,7 @@ class RAWGPTQuantizer(object):
 
             def make_hook(name):
                 def hook(_, inp, out):
-                    x = inp[0].data
+                    x = inp[0].detach()  # (not `.data`: the version counter must stay shared, see HessianAccumulator.ZERO_COPY)
                     key = (x.data_ptr(), tuple(x.shape), x.dtype, x._version)
                     if share and key in live:
                         owner = live[key][0]
@@ -843,7 +930,18 @@ class RAWGPTQuantizer(object):
                 return hook
 
             handles = [layers[n].register_forward_hook(make_hook(n)) for n in layers]
-            self._run_block(block, on_output=lambda j, out: live.clear())
+            accs = [sv.acc for sv in solvers.values()]
+            for acc in accs:
+                acc.defer = True  # the Hessian updates of one forward go out as ONE launch, after that forward
+
+            def after_forward(j, out):
+                live.clear()
+                HessianAccumulator.flush_many(accs)
+
+            self._run_block(block, on_output=after_forward)
+            HessianAccumulator.flush_many(accs)
+            for acc in accs:
+                acc.defer = False
             for h in handles:
                 h.remove()
             for name, owner in alias.items():
@@ -869,6 +967,14 @@ class RAWGPTQuantizer(object):
                 group = None if self.hessian_allreduce is True else self.hessian_allreduce
                 for acc, _, _ in distinct:  # one all-reduce per DISTINCT accumulator
                     acc.allreduce(group)
+            if self.dist_ctx is None and len(distinct) > 1 and self.factor_streams > 1:
+                # the independent factorisations of the block run concurrently, the largest first (it is the critical path)
+                if len(self._fstreams) < self.factor_streams:
+                    self._fstreams = [torch.cuda.Stream(device=self.device) for _ in range(self.factor_streams)]
+                order = sorted(range(len(distinct)), key=lambda i: -distinct[i][0].columns)
+                for slot, i in enumerate(order):
+                    acc, percdamp, act_order = distinct[i]
+                    acc.prefactor(self._fstreams[slot % len(self._fstreams)], percdamp, act_order)
             # Step 2.4: solve (reference :690-747).  The column loop treats every weight ROW independently, so Linears
             # that share one Hessian (q/k/v, gate/up) and one GPTQ setting are stacked along N and solved in ONE pass:
             # a third of the serial 128-column steps and three times the rows in flight per step, same results.

@@ -139,6 +139,26 @@ def test_hessian_running_mean_and_token_tail(hip):
     assert e <= 2e-6 and t <= 4e-6
 
 
+@pytest.mark.parametrize("shapes,T", [((512, 1024, 768, 256), 1000), ((4096, 4096, 4096, 11008), 16384)])
+def test_hessian_multi_launch_is_bit_identical_to_single_launches(hip, shapes, T):
+    """inc_gptq_hessian_accum_multi (all Hessians of one forward in ONE launch -- what the driver issues after every stacked
+    calibration forward) computes every tile exactly as inc_gptq_hessian_accum does: same bits, beta != 0 included."""
+    from neural_compressor_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(T, K, generator=g).to(torch.bfloat16).to(hip) for K in shapes]
+    single = [torch.full((K, K), 0.25, device=hip) for K in shapes]
+    multi = [h.clone() for h in single]
+    for h, x in zip(single, xs):
+        ops.gptq_hessian_accum(h, x, 0.5, 0.125)
+    assert ops.gptq_hessian_accum_multi([(h, x, 0.5, 0.125) for h, x in zip(multi, xs)])
+    for a, b, K in zip(single, multi, shapes):
+        iu = torch.triu_indices(K, K, device=hip)
+        assert torch.equal(a[iu[0], iu[1]], b[iu[0], iu[1]]), K
+    # fp32 inputs are declined (nothing launched): the caller falls back to the exact-fp32 single launches
+    assert not ops.gptq_hessian_accum_multi([(multi[0], xs[0].float(), 0.5, 0.125), (multi[0], xs[0].float(), 0.5, 0.125)])
+
+
 # ---------------------------------------------------------------------------------------------------
 # (c) inverse Cholesky factor
 # ---------------------------------------------------------------------------------------------------
