@@ -94,53 +94,19 @@ def get_model_device(model):
     return torch.device("cpu")
 
 
-class HIPAccelerator:
-    """The one accelerator of this framework: an MI355X seen through PyTorch-ROCm's `cuda` device type.
-
-    Interface of the reference's Auto_Accelerator (auto_accelerator.py:115-168): name / device_name /
-    current_device_name / synchronize / empty_cache / set_device.
-    """
-
-    def name(self):
-        return "cuda"
-
-    def is_available(self):
-        return torch.cuda.is_available()
-
-    def device_name(self, index=None):
-        return "cuda" if index is None else f"cuda:{index}"
-
-    def current_device(self):
-        return torch.cuda.current_device()
-
-    def current_device_name(self):
-        return f"cuda:{torch.cuda.current_device()}"
-
-    def set_device(self, index):
-        torch.cuda.set_device(index)
-
-    def synchronize(self):
-        torch.cuda.synchronize()
-
-    def empty_cache(self):
-        torch.cuda.empty_cache()
-
-
-_ACC = HIPAccelerator()
+from .auto_accelerator import (  # noqa: E402,F401  (the reference exposes these through torch.utils too)
+    Auto_Accelerator,
+    HIPAccelerator,
+    accelerator_registry,
+    auto_detect_accelerator,
+    register_accelerator,
+)
 
 
 def get_accelerator(device_name="auto"):
-    """Reference environ.get_accelerator (environ.py:172).  INC_TARGET_DEVICE=cpu is refused: no CPU path here."""
-    want = os.environ.get("INC_TARGET_DEVICE", device_name)
-    if want not in ("auto", "cuda", None) and not str(want).startswith("cuda"):
-        raise RuntimeError(
-            f"neural_compressor_amd only drives MI355X GPUs (device type 'cuda' = HIP); requested '{want}'."
-        )
-    if not _ACC.is_available():
-        raise RuntimeError(
-            "No HIP device is visible (torch.cuda.is_available() is False). neural_compressor_amd has no CPU fallback."
-        )
-    return _ACC
+    """Reference environ.get_accelerator (environ.py:172): the selected accelerator object.  `INC_TARGET_DEVICE=cpu` /
+    `device="cpu"` raise -- there is no CPU path."""
+    return auto_detect_accelerator(device_name)
 
 
 def batch_broadcastable(obj):

@@ -251,3 +251,48 @@ def test_hf_config_export_and_device_map_checks():
     assert str(_device_of({"": "cuda:0"})) == "cuda:0" and str(_device_of("auto")) == "cuda"
     with pytest.raises(RuntimeError):
         _device_of("cpu")
+
+
+def test_accelerator_registry_selection_order(monkeypatch):
+    """Reference auto_accelerator.py:100-168, 427-456: register_accelerator(name, priority), the Auto_Accelerator interface and
+    the selection order INC_TARGET_DEVICE (case-insensitive) > device_name > priority; and what is deliberately different
+    here: no CPU class exists, so forcing the CPU path raises instead of silently running something else."""
+    from neural_compressor_amd.torch.utils import auto_accelerator as A
+
+    saved = dict(A.accelerator_registry.registered_accelerators)
+    try:
+        @A.register_accelerator(name="fakehip", priority=500)
+        class Fake(A.HIPAccelerator):
+            @classmethod
+            def is_available(cls):
+                return True
+
+            def name(self):
+                return "fakehip"
+
+        monkeypatch.setattr(A.HIPAccelerator, "is_available", classmethod(lambda cls: True))
+        monkeypatch.delenv("INC_TARGET_DEVICE", raising=False)
+        A._select.cache_clear()
+        assert A.auto_detect_accelerator().name() == "fakehip"            # highest priority wins
+        assert A.auto_detect_accelerator("cuda").name() == "cuda"         # an explicit device name beats the priority
+        assert A.auto_detect_accelerator("cuda:0").name() == "cuda"
+        monkeypatch.setenv("INC_TARGET_DEVICE", "CUDA")
+        A._select.cache_clear()
+        assert A.auto_detect_accelerator("fakehip").name() == "cuda"      # the environment variable beats both
+        monkeypatch.setenv("INC_TARGET_DEVICE", "cpu")
+        A._select.cache_clear()
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            A.auto_detect_accelerator()
+        monkeypatch.delenv("INC_TARGET_DEVICE")
+        A._select.cache_clear()
+        with pytest.raises(RuntimeError, match="no CPU implementation"):
+            A.auto_detect_accelerator("cpu")
+        acc = A.HIPAccelerator()
+        for method in ("is_available", "name", "device_name", "set_device", "current_device", "current_device_name", "device",
+                       "empty_cache", "synchronize", "get_inc_accelerator_type"):
+            assert callable(getattr(acc, method))
+        assert acc.device_name(3) == "cuda:3" and acc.device_name() == "cuda"
+    finally:
+        A.accelerator_registry.registered_accelerators.clear()
+        A.accelerator_registry.registered_accelerators.update(saved)
+        A._select.cache_clear()

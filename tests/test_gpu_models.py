@@ -652,6 +652,63 @@ def test_save_load_roundtrip_rtn(tmp_path, fmt):
     assert float((y1 - y0).norm() / y0.norm()) <= (1e-3 if fmt == "default" else 2e-2)
 
 
+def test_load_checkpoints_saved_by_the_reference():
+    """Interop fixtures (SURVEY f-1, reference save_load.py:56-108): directories written by the UNMODIFIED reference's save()
+    on CPU (tests/golden/ckpt/ref_*, made by tests/golden/make_golden_checkpoints.py) load here into packed MI355X modules
+    holding exactly the reference's tensors, and the model computes the reference's logits."""
+    from safetensors.torch import load_file
+
+    from neural_compressor_amd.torch.quantization import load
+
+    ck = os.path.join(ROOT, "tests", "golden", "ckpt")
+    ref_logits = np.load(os.path.join(ck, "ref_logits.npz"))
+    ids = calib_ids()[0].to("cuda")
+    # format "default": quantized_weight.pt + qconfig.json
+    r = load(os.path.join(ck, "ref_rtn_default"), original_model=tiny_llama(), format="default", device="cuda")
+    state = torch.load(os.path.join(ck, "ref_rtn_default", "quantized_weight.pt"), map_location="cpu", weights_only=True)
+    mods = _woq_modules(r)
+    assert len(mods) == 14
+    for n, m in mods.items():
+        for k in ("qweight", "scales", "qzeros"):
+            assert torch.equal(getattr(m, k).cpu(), state[f"{n}.{k}"]), (n, k)
+    with torch.no_grad():
+        y = _to_half(r)(ids).logits.float().cpu().numpy()
+    assert np.linalg.norm(y - ref_logits["rtn_default"]) / np.linalg.norm(ref_logits["rtn_default"]) <= 2e-2
+    # format "huggingface": safetensors + quantize_config.json (AutoGPTQ vocabulary)
+    r = load(os.path.join(ck, "ref_gptq_hf"), format="huggingface", device="cuda")
+    state = load_file(os.path.join(ck, "ref_gptq_hf", "model.safetensors"))
+    mods = _woq_modules(r)
+    assert len(mods) == 14
+    for n, m in mods.items():
+        for k in ("qweight", "scales", "qzeros"):
+            assert torch.equal(getattr(m, k).cpu(), state[f"{n}.{k}"]), (n, k)
+    with torch.no_grad():
+        y = _to_half(r)(ids).logits.float().cpu().numpy()
+    assert np.linalg.norm(y - ref_logits["gptq_hf"]) / np.linalg.norm(ref_logits["gptq_hf"]) <= 2e-2
+
+
+def test_save_load_conv1d_model_roundtrip(tmp_path):
+    """GPT-2 (transformers.Conv1D layers): a saved RTN model must come back PACKED -- the loader rebuilds Conv1D sites too and
+    refuses a checkpoint whose packed tensors it could not place (it never hands back a silently-float model)."""
+    from neural_compressor_amd.torch.quantization import RTNConfig, load, quantize
+
+    q = quantize(tiny_gpt2(), RTNConfig(bits=4, group_size=32, use_sym=False, use_layer_wise=False))
+    n_packed = len(_woq_modules(q))
+    assert n_packed > 0
+    ids = calib_ids()[0].to("cuda")
+    with torch.no_grad():
+        y0 = _to_half(q)(ids).logits.float().cpu()
+    q.save(str(tmp_path))
+    r = load(str(tmp_path), original_model=tiny_gpt2(), format="default", device="cuda")
+    b0, b1 = _buffers(q), _buffers(r)
+    assert len(_woq_modules(r)) == n_packed and b0.keys() == b1.keys()
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
+    with torch.no_grad():
+        y1 = _to_half(r)(ids).logits.float().cpu()
+    assert float((y1 - y0).norm() / y0.norm()) <= 1e-3
+
+
 def test_save_load_huggingface_gptq_desc_act(tmp_path):
     """GPTQ with act_order -> HF / AutoGPTQ-style directory (`desc_act: true`, per-element g_idx in the safetensors) -> reload:
     identical buffers, and the reloaded modules take the fused kernel on the K-sorted words."""
