@@ -143,6 +143,15 @@ int inc_groupwise_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_o
                         float* zp_out, int64_t N, int64_t K, int group_size, int bits, int scheme,
                         float quantile, int full_range, inc_stream_t stream);
 
+/* Group-wise code-book quantisation == quantize_4bit (utility.py:112-149; the NF4 / FP4 branch of quant_tensor :246-265):
+ *   scale[n,g] = max|w| * quantile / max(values);  w / scale -> nearest entry by the midpoint intervals of the reference.
+ *   values [n_entries] ascending fp32 code book and codes [n_entries] (the integers written to int_out, INT_MAPPING) are HOST
+ *   arrays read before the call returns.  Outputs (any may be NULL): qdq_out [N,K] wdtype (may alias w), int_out [N,K] int32,
+ *   scale_out [N,G] fp32.                                                                                          */
+int inc_codebook_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_out, float* scale_out, int64_t N,
+                       int64_t K, int group_size, const float* values, const int32_t* codes, int n_entries,
+                       float quantile, inc_stream_t stream);
+
 /* *out += sum((a-b)^2) over n elements, in fp64 with a FIXED summation order (same input -> same bits on every
  * launch; zero *out first).  == the loss of search_clip (utility.py:468) and AWQ's output-MSE (awq.py:336-344,
  * 450-458), which the reference accumulates in Python doubles and takes an argmin over.  `workspace`: at least

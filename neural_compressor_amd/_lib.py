@@ -37,6 +37,7 @@ SIGNATURES = {
         c_int,
         [_P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, _P],
     ),
+    "inc_codebook_quant": (c_int, [_P, c_int, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_float, _P]),
     "inc_mse_accumulate_workspace_bytes": (c_int64, []),
     "inc_mse_accumulate": (c_int, [_P, _P, c_int, c_int64, _P, _P, _P]),
     "inc_gptq_hessian_accum": (c_int, [_P, c_int, c_int64, c_int64, c_int64, _P, c_float, c_float, _P]),

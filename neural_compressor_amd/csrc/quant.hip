@@ -187,6 +187,74 @@ __global__ __launch_bounds__(256) void groupwise_quant_kernel(
   }
 }
 
+// ---- group-wise code-book quantisation: NF4 / FP4 (quantize_4bit, utility.py:112-149) ---------------------------
+// Per (row, group): scale = max|w| * quantile / max(code book)  (every op rounded to the weight dtype, like the torch ops);
+// t = w / scale; the chosen entry is the one whose interval (mid[i-1], mid[i]] holds t -- the reference's where() chain, with
+// the Python-double midpoints cast to the tensor dtype at the comparison, the entry value cast to it when accumulated into
+// q_tensor.  An all-zero group divides 0 / 0: every comparison with the NaN is false, q = 0 (restated, not "fixed").
+struct CodeBook {
+  float value[16];  // ascending code-book entries
+  float mid[15];    // (value[i] + value[i+1]) / 2, computed in double on the host like the reference's Python list
+  int code[16];     // integer written for entry i when the caller wants ints (INT_MAPPING)
+  int n;
+  float vmax;       // max(code book)
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void codebook_quant_kernel(
+    const void* __restrict__ w, void* qdq, int32_t* __restrict__ iout, float* __restrict__ scale_out, int64_t N, int64_t K,
+    int64_t G, int gs, int L, CodeBook cb, float quantile, int vec_ok) {
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & (L - 1);
+  const int team = lane / L;
+  const int teams_per_wave = 64 / L;
+  const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t pair = wave_global * teams_per_wave + team;
+  const bool active = pair < N * G;
+  if (!active) pair = N * G - 1;
+  const int64_t n = pair / G, g = pair - n * G;
+  const int64_t kbeg = g * gs;
+  const int klen = (int)((K - kbeg) < gs ? (K - kbeg) : gs);
+  const int64_t base = n * K + kbeg;
+  const bool vec = vec_ok != 0;
+
+  float amax = 0.f;
+  for (int c = tl; c * 8 < klen; c += L) {
+    float v[8];
+    const int nv = klen - c * 8;
+    load8<DT>(w, base + c * 8, nv, vec, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nv) amax = fmaxf(amax, fabsf(v[i]));
+  }
+  for (int o = L >> 1; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float scale = round_to<DT>(round_to<DT>(amax * quantile) / cb.vmax);
+  if (active && tl == 0 && scale_out) scale_out[pair] = scale;
+
+  for (int c = tl; c * 8 < klen; c += L) {
+    float v[8];
+    const int nv = klen - c * 8;
+    load8<DT>(w, base + c * 8, nv, vec, v);
+    int iv[8];
+    float dq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = round_to<DT>(v[i] / scale);
+      int pick = -1;  // NaN (0 / 0) matches no interval
+      if (t <= round_to<DT>(cb.mid[0])) pick = 0;
+      else if (t > round_to<DT>(cb.mid[cb.n - 2])) pick = cb.n - 1;
+      for (int e = 1; e < cb.n - 1; ++e)
+        if (round_to<DT>(cb.mid[e - 1]) < t && t <= round_to<DT>(cb.mid[e])) pick = e;
+      iv[i] = pick < 0 ? 0 : cb.code[pick];
+      dq[i] = round_to<DT>((pick < 0 ? 0.f : round_to<DT>(cb.value[pick])) * scale);
+    }
+    if (active) {
+      if (iout) store8_i32(iout, base + c * 8, nv, vec, iv);
+      if (qdq) store8<DT>(qdq, base + c * 8, nv, vec, dq);
+    }
+  }
+}
+
 // ---- GPTQ Quantizer.find_params (weight=True, perchannel, int, no mse) ---------------------------
 __global__ __launch_bounds__(256) void gptq_find_params_kernel(
     const float* __restrict__ w, int64_t N, int64_t K, int64_t col0,
@@ -366,6 +434,34 @@ int inc_gptq_find_params_mse(const float* w, int64_t N, int64_t K, int64_t col0,
   const int steps = (int)(maxshrink * (float)grid);  // int(self.maxshrink * self.grid)
   gptq_find_params_kernel<<<(unsigned)ceil_div64(waves, 4), 256, 0, inc_s(stream)>>>(
       w, N, K, col0, group_size, ngroups, L, bits, sym, scale, zero, G, g0, steps, grid, norm);
+  INC_LAUNCH_RETURN();
+}
+
+int inc_codebook_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_out, float* scale_out, int64_t N, int64_t K,
+                       int group_size, const float* values, const int32_t* codes, int n_entries, float quantile,
+                       inc_stream_t stream) {
+  INC_CHECK_ARG(w && values && codes && N > 0 && K > 0 && n_entries >= 2 && n_entries <= 16);
+  int gs = group_size;
+  if (gs <= 0 || gs > K) gs = (int)K;
+  const int64_t G = ceil_div64(K, gs);
+  CodeBook cb;
+  cb.n = n_entries;
+  cb.vmax = values[0];
+  for (int i = 0; i < 16; ++i) {
+    cb.value[i] = i < n_entries ? values[i] : 0.f;
+    cb.code[i] = i < n_entries ? codes[i] : 0;
+    if (i < n_entries && values[i] > cb.vmax) cb.vmax = values[i];
+  }
+  for (int i = 0; i < 15; ++i) cb.mid[i] = i + 1 < n_entries ? (float)(((double)values[i] + (double)values[i + 1]) / 2.0) : 0.f;
+  const int L = team_lanes(gs);
+  const int64_t waves = ceil_div64(N * G, 64 / L);
+  const int elt = wdtype == INC_F32 ? 4 : 2;
+  const int vec_ok = (K % 8 == 0) && (gs % 8 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0) &&
+                     (!qdq_out || (reinterpret_cast<uintptr_t>(qdq_out) & 15) == 0) && (!int_out || (reinterpret_cast<uintptr_t>(int_out) & 15) == 0) && elt > 0;
+  INC_DISPATCH_DTYPE(wdtype, DT, {
+    codebook_quant_kernel<DT><<<(unsigned)ceil_div64(waves, 4), 256, 0, inc_s(stream)>>>(w, qdq_out, int_out, scale_out, N, K, G, gs, L, cb,
+                                                                                          quantile, vec_ok);
+  })
   INC_LAUNCH_RETURN();
 }
 

@@ -279,6 +279,37 @@ def groupwise_quant(w, bits, group_size, scheme, quantile=1.0, full_range=False,
     return qdq
 
 
+def codebook_quant(w, values, codes, group_size, quantile=1.0, return_int=False, inplace=True):
+    """== quantize_4bit through quant_tensor (utility.py:112-149, 246-265): NF4 / FP4 code-book quantisation per row group.
+
+    values / codes: the ascending code book and the integers stored for its entries (FLOAT_MAPPING / INT_MAPPING).
+    return_int=False: fake-quantises `w` (in place when `inplace`) and returns it; return_int=True: (int32 codes [N,K],
+    scale [N,G] fp32, None) -- there is no zero point in these formats."""
+    import ctypes
+
+    dev = _dev(w)
+    assert w.dim() == 2
+    N, K = w.shape
+    gs = K if (group_size == -1 or K < group_size) else int(group_size)
+    G = -(-K // gs)
+    n = len(values)
+    vals = (ctypes.c_float * n)(*[float(v) for v in values])
+    cds = (ctypes.c_int32 * n)(*[int(c) for c in codes])
+    scale = torch.empty((N, G), dtype=torch.float32, device=dev)
+    if return_int:
+        iout = torch.empty((N, K), dtype=torch.int32, device=dev)
+        qdq = None
+    else:
+        iout = None
+        qdq = w if inplace else torch.empty_like(w)
+    with torch.cuda.device(dev):
+        check(lib.inc_codebook_quant(_ptr(w), dtype_code(w.dtype), _ptr(qdq), _ptr(iout), _ptr(scale), N, K, gs, vals, cds, n,
+                                     float(quantile), _stream()), "inc_codebook_quant")
+    if return_int:
+        return iout, scale, None
+    return qdq
+
+
 _MSE_WS = {}
 
 

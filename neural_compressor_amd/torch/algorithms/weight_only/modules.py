@@ -102,11 +102,21 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         **kwargs,
     ):
         super().__init__(in_features, out_features, dtype, bits, group_size, device, scale_dtype=scale_dtype, **kwargs)
-        if "int" not in self.dtype:
-            raise NotImplementedError(f"dtype={dtype}: only integer weight-only formats are in scope (SURVEY.md section 8)")
         assert bits in (2, 4, 8), f"bits={bits}: the HIP packers implement 2, 4 and 8 bits"
         dev = _hip_device(device)
         self.use_optimum_format = use_optimum_format
+        self._lut = None
+        if "int" not in self.dtype:  # nf4 / fp4 code books (reference modules.py:213-221)
+            from .utility import FLOAT_MAPPING, INT_MAPPING
+
+            if self.dtype not in FLOAT_MAPPING:
+                raise NotImplementedError(f"dtype={dtype}: integer, NF4 and FP4 weight-only formats are implemented")
+            assert bits == 4, "NF4 / FP4 are 4-bit formats"
+            self.use_optimum_format = False  # optimum_format doesn't suit symmetric nf4 / fp4 (reference :216)
+            # stored integer (-8..7) -> code-book value; unpack() applies it like the reference's int2float_mapping
+            lut = torch.zeros(16, dtype=torch.float32)
+            lut[torch.tensor(INT_MAPPING[self.dtype]) + 8] = torch.tensor(FLOAT_MAPPING[self.dtype], dtype=torch.float32)
+            self._lut = lut.to(dev)
         self.compression_dim = compression_dim
         assert compression_dtype in _CBITS, f"Only support torch.int8|16|32|64 as compressed dtype. but got {compression_dtype}"
         assert compression_dim in (0, 1), "Only support 0 or 1 as compression dimension, 0 is output channel, 1 is input channel."
@@ -223,6 +233,8 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
             if self.compression_dim == 0:
                 iw = iw.T.contiguous()
             iw = iw[:N, :K].contiguous()
+            if self._lut is not None:  # nf4 / fp4: the unpacked "weight" is the code-book value (reference :391-395)
+                iw = self._lut.to(iw.device)[(iw.to(torch.int64) + 8)]
             zp = None
             if has_zp:
                 qz = self.qzeros if self.compression_dim == 1 else self.qzeros.T.contiguous()
@@ -242,6 +254,11 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
                 self.group_size, self.bits, out_dtype=out_dtype,
             )
         p = self.unpack()
+        if self._lut is not None:  # code-book value x group scale (reference :438-441), zp is None for these formats
+            N, K, gs = self.out_features, self.in_features, self.group_size
+            gs = K if gs == -1 or gs > K else gs
+            gi = (torch.arange(K, device=p["scales"].device) // gs) if self.g_idx is None else self.g_idx.long()
+            return (p["int_weight"].float() * p["scales"].float()[:, gi]).to(out_dtype)
         return ops.dequant_ints(p["int_weight"], p["scales"], p["zp"], self.g_idx, self.group_size, out_dtype)
 
     def forward(self, input):

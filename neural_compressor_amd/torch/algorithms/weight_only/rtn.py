@@ -12,7 +12,7 @@ from ....common.utils import logger
 from ...utils.utility import WOQ_WHITE_LIST, get_accelerator, get_model_device, set_module
 from ..base_algorithm import Quantizer
 from .modules import MI355XWeightOnlyLinear
-from .utility import quant_tensor, search_clip
+from .utility import FLOAT_MAPPING, quant_tensor, search_clip
 
 try:
     import transformers
@@ -56,10 +56,16 @@ class RTNQuantizer(Quantizer):
             if dtype != "int" and "int" in dtype:
                 bits = int(dtype.lstrip("int"))
                 dtype = "int"
-            if dtype != "int":
-                raise NotImplementedError(f"RTN dtype={dtype} is outside the MI355X hot-path scope (integer formats only)")
-            if cfg.get("use_double_quant", False):
-                raise NotImplementedError("double_quant is outside the MI355X hot-path scope")
+            if dtype != "int" and dtype not in FLOAT_MAPPING:
+                # fp8_* is a plain cast in the reference (cast_fp8, rtn.py:167-171), not a weight-only format
+                raise NotImplementedError(f"RTN dtype={dtype}: integer, NF4 and FP4 formats are implemented")
+            double_quant_config = {  # reference rtn.py:184-190
+                "double_quant": cfg.get("use_double_quant", False),
+                "double_quant_dtype": cfg.get("double_quant_dtype", "int"),
+                "double_quant_bits": cfg.get("double_quant_bits", 8),
+                "double_quant_scheme": cfg.get("double_quant_scheme", "asym"),
+                "double_quant_group_size": cfg.get("double_quant_group_size", 256),
+            }
             group_size = cfg["group_size"]
             scheme = cfg["scheme"]
             quantile = cfg.get("quantile", 1.0)
@@ -77,7 +83,7 @@ class RTNQuantizer(Quantizer):
                 quantile = search_clip(m, bits, group_size, scheme, dtype, use_full_range)
             int_weight, scale, zp = quant_tensor(
                 weight, dtype=dtype, bits=bits, group_size=group_size, scheme=scheme, quantile=quantile,
-                return_int=True, full_range=use_full_range,
+                return_int=True, full_range=use_full_range, **double_quant_config,
             )
             if transpose:
                 int_weight = int_weight.t().contiguous()

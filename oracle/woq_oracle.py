@@ -157,14 +157,77 @@ def qdq_weight_asym(weight, bits=4, quantile=1.0, return_int=False):
     return weight.mul_(scale)
 
 
-def quant_tensor(weight, bits=4, group_size=-1, scheme="asym", quantile=1.0, return_int=False, full_range=False):
-    """utility.py:272-436 for dtype "int", no double quant.  NOT in place (works on a clone).
+# 4-bit float code books (utility.py:52-98) and the integers stored for their entries
+NF4 = [-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635, -0.18477343022823334,
+       -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
+       0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0]
+FP4_BNB = [-12.0, -8.0, -6.0, -4.0, -3.0, -2.0, -0.0625, 0, 0.0625, 2.0, 3.0, 4.0, 6.0, 8.0, 12.0]
+FP4_E2M1 = [-1.0, -0.6666666666666666, -0.5, -0.3333333333333333, -0.25, -0.16666666666666666, -0.010416666666666666, 0.0,
+            0.010416666666666666, 0.16666666666666666, 0.25, 0.3333333333333333, 0.5, 0.6666666666666666, 1.0]
+FLOAT_MAPPING = {"nf4": NF4, "fp4": FP4_BNB, "fp4_e2m1_bnb": FP4_BNB, "fp4_e2m1": FP4_E2M1}
+INT_MAPPING = {"nf4": [7, 1, 2, 3, 4, 5, 6, 0, -8, -7, -6, -5, -4, -3, -2, -1], "fp4": [-5, -6, -3, -4, -1, -2, -7, 0, 1, 6, 7, 4, 5, 2, 3],
+               "fp4_e2m1_bnb": [-5, -6, -3, -4, -1, -2, -7, 0, 1, 6, 7, 4, 5, 2, 3], "fp4_e2m1": [-1, -2, -3, -4, -5, -6, -7, 0, 1, 2, 3, 4, 5, 6, 7]}
+
+
+def quantize_4bit(tensor, quantile=1.0, dtype="nf4", return_int=False, keep_scale=False):
+    """utility.py:112-149 (operates in place on `tensor` [rows, group]); keep_scale = the reference's double_quant kwarg."""
+    allow_data, allow_bit = FLOAT_MAPPING[dtype], INT_MAPPING[dtype]
+    scale = tensor.abs().max(1)[0] * quantile / max(allow_data)
+    scale.unsqueeze_(dim=-1)
+    tensor.div_(scale)
+    mid = [(allow_data[i] + allow_data[i + 1]) / 2 for i in range(len(allow_data) - 1)]
+    q = torch.zeros_like(tensor)
+    for i in range(len(allow_data)):
+        data = allow_bit[i] if return_int else allow_data[i]
+        if i == 0:
+            q += torch.where(tensor <= mid[i], data, 0)
+        elif i == len(allow_data) - 1:
+            q += torch.where(tensor > mid[i - 1], data, 0)
+        else:
+            q += torch.where((mid[i - 1] < tensor) & (tensor <= mid[i]), data, 0)
+    tensor.copy_(q)
+    if return_int or keep_scale:
+        return tensor, scale, None
+    return tensor.mul_(scale)
+
+
+def quant_tensor(weight, bits=4, group_size=-1, scheme="asym", quantile=1.0, return_int=False, full_range=False, dtype="int",
+                 double_quant=False, double_quant_dtype="int", double_quant_bits=8, double_quant_scheme="asym",
+                 double_quant_group_size=256):
+    """utility.py:272-436 for dtype "int" / "nf4" / "fp4*", optionally with double quantisation of the scales (:378-436).
+    NOT in place (works on a clone).
 
     Returns the fake-quantised weight, or (int_weight, scale [N,G], zp [N,G] | None) when return_int.
     """
+    if double_quant:
+        w, scale, zp = quant_tensor(weight, bits, group_size, scheme, quantile, True, full_range, dtype)
+        shape = scale.shape
+        flat = scale.reshape(1, -1).clone()
+        mean = None
+        if double_quant_scheme == "asym":
+            mean = flat.mean()
+            flat.sub_(mean)
+        flat = quant_tensor(flat, double_quant_bits, double_quant_group_size, "sym", 1.0, False, False, double_quant_dtype)
+        if mean is not None:
+            flat.add_(mean)
+        scale = flat.reshape(shape)
+        if return_int:
+            return w, scale, zp
+        N, K = weight.shape
+        gs = K if (group_size == -1 or K < group_size) else group_size
+        vals = w.clone()
+        if dtype in FLOAT_MAPPING:  # without return_int the reference's actor leaves the code-book VALUES in the tensor (:134)
+            lut = torch.zeros(16)
+            lut[torch.tensor(INT_MAPPING[dtype]) + 8] = torch.tensor(FLOAT_MAPPING[dtype], dtype=torch.float32)
+            vals = lut[(w + 8).long()]
+        if zp is not None:
+            vals = vals - zp.repeat_interleave(gs, 1)[:, :K]
+        return vals * scale.repeat_interleave(gs, 1)[:, :K]
     weight = weight.clone()
 
     def actor(w):
+        if dtype in FLOAT_MAPPING:
+            return quantize_4bit(w, quantile, dtype, return_int)
         if scheme == "sym":
             return qdq_weight_sym(w, bits, quantile, return_int, full_range)
         return qdq_weight_asym(w, bits, quantile, return_int)

@@ -1,0 +1,97 @@
+"""-m gpu: quant_tensor's non-integer branches on the MI355X -- NF4 / FP4 code-book quantisation (inc_codebook_quant ==
+quantize_4bit, reference utility.py:112-149), double quantisation of the scales (:378-436) and RTN with dtype="nf4" through
+the packed module -- against outputs of the UNMODIFIED reference (tests/golden/nf4_golden.npz) and the oracle."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import woq_oracle as O
+from tests.model_zoo import calib_ids, tiny_llama
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "nf4_g32": dict(dtype="nf4", group_size=32), "fp4_g32": dict(dtype="fp4", group_size=32),
+    "fp4e2m1_g32": dict(dtype="fp4_e2m1", group_size=32), "nf4_tail": dict(dtype="nf4", group_size=32),
+    "nf4_pc": dict(dtype="nf4", group_size=-1), "nf4_zero": dict(dtype="nf4", group_size=32),
+    "nf4_q09": dict(dtype="nf4", group_size=32, quantile=0.9),
+}
+DQ = dict(double_quant=True, double_quant_dtype="int", double_quant_bits=8, double_quant_scheme="asym", double_quant_group_size=256)
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(ROOT, "tests", "golden", "nf4_golden.npz"))
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_codebook_quant_vs_reference_golden(hip, g, tag):
+    """Bit-exact: fake-quantised weights, stored integers and scales (tail group, per-channel, quantile, an all-zero group)."""
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    w = torch.from_numpy(g[f"{tag}_w"]).to(hip)
+    qdq = quant_tensor(w.clone(), **CASES[tag])
+    assert np.array_equal(qdq.cpu().numpy(), g[f"{tag}_qdq"])
+    iw, sc, zp = quant_tensor(w.clone(), return_int=True, **CASES[tag])
+    assert zp is None
+    assert np.array_equal(iw.cpu().numpy().astype(np.float32), g[f"{tag}_int"])
+    assert np.array_equal(sc.cpu().numpy(), g[f"{tag}_scale"])
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_codebook_quant_4096_vs_oracle(hip, dt):
+    """BASELINE-size layer, every dtype: the kernel rounds each step to the weight dtype exactly where the torch ops do."""
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    torch.manual_seed(3)
+    w = (torch.randn(1024, 4096) * 0.02).to(dt)
+    ref = O.quant_tensor(w, dtype="nf4", group_size=128)
+    got = quant_tensor(w.clone().to(hip), dtype="nf4", group_size=128)
+    assert torch.equal(got.cpu(), ref)
+    ri, rs, _ = O.quant_tensor(w, dtype="nf4", group_size=128, return_int=True)
+    gi, gs, _ = quant_tensor(w.clone().to(hip), dtype="nf4", group_size=128, return_int=True)
+    assert torch.equal(gi.cpu().float(), ri.float()) and torch.equal(gs.cpu(), rs.float())
+
+
+@pytest.mark.parametrize("tag,kw", [("dq_int4", dict(dtype="int", bits=4, group_size=32, scheme="asym")), ("dq_nf4", dict(dtype="nf4", group_size=32))])
+def test_double_quant_vs_reference_golden(hip, g, tag, kw):
+    """The [N, G] scales quantised as ONE row (int8, mean-centred "asym", groups of 256): integers / zero points bit-exact, the
+    double-quantised scales and the dequantised weight to fp32 rounding (the mean of the scales is a device reduction)."""
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    w = torch.from_numpy(g[f"{tag}_w"]).to(hip)
+    iw, sc, zp = quant_tensor(w.clone(), return_int=True, **kw, **DQ)
+    assert np.array_equal(iw.cpu().numpy().astype(np.float32), g[f"{tag}_int"])
+    np.testing.assert_allclose(sc.cpu().numpy(), g[f"{tag}_scale"], rtol=2e-6, atol=0)
+    if f"{tag}_zp" in g.files:
+        assert np.array_equal(zp.cpu().numpy(), g[f"{tag}_zp"])
+    qdq = quant_tensor(w.clone(), **kw, **DQ)
+    np.testing.assert_allclose(qdq.cpu().numpy(), g[f"{tag}_qdq"], rtol=3e-6, atol=1e-9)
+
+
+def test_rtn_nf4_tiny_llama_vs_reference(hip, g):
+    """RTNConfig(dtype="nf4"): the reference packs the stored integers in its NON-optimum layout (qweight [N, K/8] int32, scales
+    [N, G], no zero points, modules.py:213-221) -- every packed buffer bit-identical, recover() = code-book value x scale, and
+    the model computes the reference's logits."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.quantization import RTNConfig, quantize
+
+    q = quantize(tiny_llama(), RTNConfig(dtype="nf4", group_size=32, use_layer_wise=False))
+    mods = {n: m for n, m in q.named_modules() if isinstance(m, MI355XWeightOnlyLinear)}
+    assert len(mods) == int(g["rtn_nf4_n_modules"]) == 14
+    for n, m in mods.items():
+        assert not m.use_optimum_format and not hasattr(m, "qzeros")
+        assert np.array_equal(m.qweight.cpu().numpy(), g[f"rtn_nf4_{n}.qweight"]), n
+        assert np.array_equal(m.scales.cpu().numpy(), g[f"rtn_nf4_{n}.scales"]), n
+    with torch.no_grad():
+        for mod in q.modules():  # fp16 compute like the reference's accelerator semantics (see test_gpu_models._to_half)
+            for p in mod.parameters(recurse=False):
+                if p.is_floating_point():
+                    p.data = p.data.half()
+        y = q(calib_ids()[0].to(hip)).logits.float().cpu().numpy()
+    ref = g["rtn_nf4_logits"]
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) <= 2e-2

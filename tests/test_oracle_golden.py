@@ -209,3 +209,28 @@ def test_oracle_awq_searches_match_the_reference_trace():
         c = O.awq_search_clip_module(W2, None, inputs[name], group_size=32, scheme="asym", input_scale=isc)
         np.testing.assert_allclose(np.array(c["history"]), tr["clip_hist"][j], rtol=2e-5, err_msg=name)
         assert c["best_index"] == int(tr["clip_best"][j]), name
+
+
+NF4_CASES = {
+    "nf4_g32": dict(dtype="nf4", group_size=32), "fp4_g32": dict(dtype="fp4", group_size=32),
+    "fp4e2m1_g32": dict(dtype="fp4_e2m1", group_size=32), "nf4_tail": dict(dtype="nf4", group_size=32),
+    "nf4_pc": dict(dtype="nf4", group_size=-1), "nf4_zero": dict(dtype="nf4", group_size=32),
+    "nf4_q09": dict(dtype="nf4", group_size=32, quantile=0.9),
+    "dq_int4": dict(dtype="int", bits=4, group_size=32, scheme="asym", double_quant=True),
+    "dq_nf4": dict(dtype="nf4", group_size=32, double_quant=True),
+}
+
+
+@pytest.mark.parametrize("tag", list(NF4_CASES))
+def test_oracle_nf4_fp4_double_quant_vs_reference_golden(tag):
+    """quant_tensor's non-integer branches (quantize_4bit utility.py:112-149; double quantisation of the scales :378-436)
+    restated in oracle/ against outputs of the unmodified reference (tests/golden/make_golden_nf4.py): bit-exact."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "nf4_golden.npz"))
+    w = torch.from_numpy(g[f"{tag}_w"])
+    kw = NF4_CASES[tag]
+    assert np.array_equal(O.quant_tensor(w, **kw).numpy(), g[f"{tag}_qdq"])
+    iw, sc, zp = O.quant_tensor(w, return_int=True, **kw)
+    assert np.array_equal(iw.numpy(), g[f"{tag}_int"]) and np.array_equal(sc.numpy(), g[f"{tag}_scale"])
+    assert (zp is None) == (f"{tag}_zp" not in g.files)
+    if zp is not None:
+        assert np.array_equal(zp.numpy(), g[f"{tag}_zp"])
