@@ -64,8 +64,10 @@ class SmoothQuantQuantizer(Quantizer):
         sq.same_input = {n: o for n, o in calib.same_input.items() if n in sq.input_maxes and o in sq.input_maxes}
         sq.producer = {n: p for n, p in calib.producer.items() if n in sq.input_maxes}
         sq.example_call = calib.example_call  # folds are verified numerically on the first calibration batch
+        sq.calibration = calib                # alpha="auto" replays the first calibration forwards (calib.captured_calls)
         sq.transform(alpha=first.get("alpha", 0.5), folding=first.get("folding", False), op_types=(torch.nn.Linear,),
-                     scale_sharing=first.get("scale_sharing", False), absorb_to_layer=first.get("absorb_to_layer"))
+                     scale_sharing=first.get("scale_sharing", False), absorb_to_layer=first.get("absorb_to_layer"),
+                     auto_alpha_args=first.get("auto_alpha_args"))
         dev = next(model.parameters()).device
         for name in names:
             mod = get_module(model, name)
@@ -74,7 +76,7 @@ class SmoothQuantQuantizer(Quantizer):
             stat_scale = (1.0 / sq.weight_scale_info[name]) if folded else None  # the producer now emits x / s
             new = W8A8Linear.from_float(mod, calib.input_mins[name], calib.input_maxes[name], device=dev, stat_scale=stat_scale)
             set_module(model, name, new)
-        model.sq_info = {"alpha": first.get("alpha", 0.5), "folding": first.get("folding", False),
+        model.sq_info = {"alpha": sq.alpha if isinstance(sq.alpha, dict) else first.get("alpha", 0.5), "folding": first.get("folding", False),
                          "absorb_to_layer": sq.absorb_to_layer}
         logger.info("Smooth quantization done.")
         from types import MethodType

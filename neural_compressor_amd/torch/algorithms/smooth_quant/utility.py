@@ -43,6 +43,8 @@ class Calibration:
         self.same_input = {}  # layer name -> name of the first layer that saw the very same input tensor
         self.producer = {}    # layer name -> name of the norm whose output tensor IS this layer's input (folding)
         self.example_call = None  # (args, kwargs) of the first calibration forward: replayed to VERIFY a fold numerically
+        self.captured_calls = []  # the first `capture_limit` calibration forwards (args, kwargs): the alpha="auto" tuner replays them
+        self.capture_limit = 32   # AutoAlpha's default n_samples (reference :1252)
 
     def _save_input_pc_hook(self, name):
         def save_input_hook(module, inputs, outputs):
@@ -84,6 +86,8 @@ class Calibration:
         def remember(_m, args, kwargs):
             if self.example_call is None:
                 self.example_call = (args, dict(kwargs))
+            if len(self.captured_calls) < self.capture_limit:
+                self.captured_calls.append((args, dict(kwargs)))
 
         self.hook_handles.append(root.register_forward_pre_hook(remember, with_kwargs=True))
 
@@ -237,6 +241,310 @@ class W8A8Linear(torch.nn.Module):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, w8a8"
 
 
+def quant_dequant_w_v1(m, num_bits=8, scheme="sym"):
+    """Per-output-channel symmetric int8 fake quantisation of a Linear's weight (reference :652-695): the codes and scales
+    come from inc_sq_quant_weight (bit-exact against the reference's golden vectors), dequantised in fp32."""
+    assert isinstance(m, torch.nn.Linear) and num_bits == 8 and scheme == "sym", "the W8A8 cell implemented on MI355X"
+    w = m.weight.detach().float().contiguous()
+    qw, scale, _ = ops.sq_quant_weight(w)
+    return qw[:, : w.shape[1]].float() * scale.view(-1, 1)
+
+
+def quant_dequant_x_v1(x, min_x=None, max_x=None, num_bits=8):
+    """Per-tensor asymmetric uint8 fake quantisation of an activation from channel min / max statistics (reference :726-755)."""
+    eps = torch.finfo(torch.float32).eps
+    q_min, q_max = 0, 2.0**num_bits - 1.0
+    if max_x is None or min_x is None:
+        max_x, min_x = torch.max(x), torch.min(x)
+    else:
+        max_x, min_x = torch.max(max_x), torch.min(min_x)
+    scale = torch.clip((max_x - min_x) / (2**num_bits - 1), min=eps)
+    bias = torch.round((0 - min_x) / scale)
+    q_x = torch.round(x / scale + bias)
+    q_x.clamp_(q_min, q_max)
+    return scale * (q_x - bias)
+
+
+class WrapperLayer(torch.nn.Module):
+    """Fake-quant stand-in of a Linear during alpha tuning (reference :2665-2771): records its (quantised-model) input and its
+    output; `q_dq_forward` evaluates the layer for a candidate (input_scale, weight_scale) pair."""
+
+    def __init__(self, layer, input_min, input_max, save_q_input=False):
+        super().__init__()
+        self.add_module("orig_layer", layer)
+        self.quant = False
+        self.q_input = None
+        self.input_max, self.input_min = input_max, input_min
+        self.weight_scale, self.input_scale = None, None
+        self.save_q_input = save_q_input
+        self.output = None
+
+    def enable_quant(self):
+        self.quant = True
+
+    def disable_quant(self):
+        self.quant = False
+
+    def update_scale(self, input_scale, weight_scale):
+        self.input_scale, self.weight_scale = input_scale, weight_scale
+
+    def q_dq_forward(self, x, input_scale, weight_scale):
+        lin = self.orig_layer
+        w = lin.weight.detach().float()
+        if weight_scale is not None:
+            w = w * weight_scale
+        tmp = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, device=w.device)
+        tmp.weight.data = w
+        w_qdq = quant_dequant_w_v1(tmp)
+        x = x.float()
+        if input_scale is None:
+            x = quant_dequant_x_v1(x, self.input_min, self.input_max)
+        else:
+            x = input_scale * x
+            x = quant_dequant_x_v1(x, self.input_min * input_scale, self.input_max * input_scale)
+        bias = None if lin.bias is None else lin.bias.float()
+        return torch.nn.functional.linear(x, w_qdq, bias)
+
+    def forward(self, x):
+        if self.quant:
+            if self.save_q_input:
+                self.q_input = x
+            output = self.q_dq_forward(x, self.input_scale, self.weight_scale).to(x.dtype)
+        else:
+            output = self.orig_layer(x)
+        self.output = output
+        return output
+
+
+class AutoAlpha:
+    """Layer-wise alpha tuner of SmoothQuant (`alpha="auto"`; reference :1232-1892, the model-wise "version1" path).
+
+    For every calibration sample: one float forward and one fake-quant forward (every tuned Linear replaced by a WrapperLayer
+    that quantises its smoothed weight per channel and its smoothed input per tensor, and remembers the input it got), then
+    every layer is re-evaluated on that remembered input for every alpha of the grid; the loss is
+    sum(|y_fp / max|y_fp| - y_q / max|y_fp||^0.5).  Restated as written, including what looks unintended: `loss_alphas` is
+    re-initialised for every sample (:1776), so the "accumulated" table only ever holds the CURRENT sample's losses -- the
+    alphas are updated every n_samples // 4 samples from that sample alone and the final choice is made on the last sample.
+    Everything runs in HBM: forwards are torch, the fake quantisation uses inc_sq_quant_weight + elementwise torch ops.
+    do_blockwise is not implemented (it deep-copies every block per alpha and sample in the reference)."""
+
+    def __init__(self, model, dataloader, absorb_to_layer, op_types, device, q_func, example_inputs, weight_clip=True,
+                 alpha_min=0.3, alpha_max=0.7, alpha_step=0.1, shared_criterion="mean", init_alpha=0.5, folding=False,
+                 do_blockwise=False, n_samples=32, calibration=None):
+        if do_blockwise:
+            raise NotImplementedError("SmoothQuant alpha='auto' with do_blockwise=True is not implemented on MI355X")
+        self.model = model
+        self.model.eval()
+        self.dataloader = dataloader
+        self.alpha_min, self.alpha_max, self.alpha_step = alpha_min, alpha_max, alpha_step
+        self.shared_criterion = shared_criterion
+        self.init_alpha = init_alpha
+        self.loss_type = "model_wise"
+        self.calib_sample_num = n_samples if n_samples else 32
+        self.op_types = op_types
+        self.absorb_to_layer = absorb_to_layer
+        self.q_func = q_func
+        self.folding = folding
+        self.example_inputs = example_inputs
+        self.weight_clip = weight_clip[0] if isinstance(weight_clip, tuple) else weight_clip
+        self.input_maxes, self.input_mins, self.input_maxes_abs = {}, {}, {}
+        self.device = device
+        self.calibration = calibration  # statistics + captured forwards of an earlier calibration pass (prepare/convert flow)
+        self.last_loss_alphas = None    # {layer: {str(alpha): loss}} of the final decision (diagnostics / parity tests)
+
+    # -- entry (:1278-1324) ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def tune(self):
+        if self.calibration is not None:
+            calib = self.calibration
+            self.input_mins, self.input_maxes = calib.input_mins, calib.input_maxes
+        else:
+            calib = Calibration(self.model, self.dataloader, self.q_func, self.device)
+            calib.capture_limit = self.calib_sample_num
+            self.input_mins, self.input_maxes = calib.calibrate(100, self.op_types)
+        self.calls = list(calib.captured_calls)[: self.calib_sample_num]
+        assert self.calls, "alpha='auto' needs calibration forwards to replay"
+        for key in self.input_mins:
+            self.input_maxes_abs[key] = torch.max(torch.abs(self.input_mins[key]), torch.abs(self.input_maxes[key]))
+        if not self.folding:
+            for d in set(self.absorb_to_layer.keys()).difference(self.input_mins.keys()):
+                del self.absorb_to_layer[d]
+        return self._auto_tune_alpha()
+
+    # -- helpers with the reference's names -------------------------------------------------------------------------------
+    def _get_all_hook_module_names(self):
+        return [n for n, m in self.model.named_modules() if isinstance(m, tuple(self.op_types))]
+
+    def _get_sq_layer_names(self):
+        names = []
+        for key in self.absorb_to_layer:
+            names += self.absorb_to_layer[key]
+        return names
+
+    def _qdq_model_wrapper_for_auto(self, save_q_input=False):
+        self.to_unwrap_module_names = self._get_all_hook_module_names()
+        for name in self.to_unwrap_module_names:
+            if name not in self.input_mins:
+                continue
+            module = get_module(self.model, name)
+            set_module(self.model, name, WrapperLayer(module, self.input_mins[name], self.input_maxes[name], save_q_input=save_q_input))
+
+    def _qdq_model_unwrapper_for_auto(self):
+        for name in self.to_unwrap_module_names:
+            module = get_module(self.model, name)
+            if hasattr(module, "orig_layer"):
+                set_module(self.model, name, module.orig_layer)
+
+    def _change_qdq_for_auto(self, enable=True):
+        for name in self._get_all_hook_module_names():
+            name = name.split(".orig_layer")[0]
+            module = get_module(self.model, name)
+            if hasattr(module, "orig_layer"):
+                module.enable_quant() if enable else module.disable_quant()
+
+    def _cal_scales(self, absorb_to_layer, input_maxes, alpha=0.5):
+        absorb_scales_info, weight_scales_info = {}, {}
+        for key, layer_names in absorb_to_layer.items():
+            alpha_tmp = alpha[key] if isinstance(alpha, dict) else alpha
+            if alpha_tmp < 0:
+                scale = torch.ones(1, device=self.device)
+            else:
+                weights = [get_module(self.model, n).orig_layer.weight if hasattr(get_module(self.model, n), "orig_layer")
+                           else get_module(self.model, n).weight for n in layer_names]
+                scale = cal_scale(input_maxes[layer_names[0]], weights, alpha_tmp)
+            inv = 1.0 / scale
+            inv[scale == 0] = 0
+            absorb_scales_info[key] = inv
+            for n in layer_names:
+                weight_scales_info[n] = scale
+        return absorb_scales_info, weight_scales_info
+
+    def _update_scales_for_auto(self, absorb_scales, weight_scales):
+        for key, layer_names in self.absorb_to_layer.items():
+            for layer_name in layer_names:
+                layer = get_module(self.model, layer_name)
+                layer.update_scale(absorb_scales[key].view(1, -1), weight_scales[layer_name].view(1, -1))  # Linear: [1, K]
+
+    @staticmethod
+    def _get_auto_loss(output, output_q, loss_type="abs", loss_alpha=1.0):
+        output, output_q = output.float(), output_q.float()
+        if len(output.shape) <= 2:
+            max_value = torch.max(torch.abs(output))
+        else:
+            output = output.reshape(output.shape[0], -1)
+            output_q = output_q.reshape(output_q.shape[0], -1)
+            max_value = torch.clip(torch.max(torch.abs(output), dim=-1).values.unsqueeze(-1), 1e-5)
+        output = output / max_value
+        output_q = output_q / max_value
+        if loss_type == "abs":
+            return torch.sum(torch.pow(torch.abs(output - output_q), 0.5))
+        return torch.sum((output - output_q) ** 2)
+
+    @staticmethod
+    def _get_best_alpha(absorb_to_layer, loss_alphas, shared_criterion):
+        best_alpha = {}
+        for ln_name, layer_names in absorb_to_layer.items():
+            cur = "min" if len(layer_names) == 1 else shared_criterion
+            if cur == "mean":
+                loss_tmp = {}
+                for alpha in loss_alphas[layer_names[0]].keys():
+                    loss_tmp.setdefault(alpha, 0)
+                    for layer_name in layer_names:
+                        loss_tmp[alpha] += loss_alphas[layer_name][alpha]
+                res = sorted(loss_tmp.items(), key=lambda x: x[1])  # stable, like list.sort on the reference's pairs
+                best_alpha[ln_name] = float(res[0][0])
+            elif cur in ("min", "max"):
+                tmp = []
+                for layer_name in layer_names:
+                    res = sorted(loss_alphas[layer_name].items(), key=lambda x: x[1])
+                    tmp.append(float(res[0][0]))
+                best_alpha[ln_name] = min(tmp) if cur == "min" else max(tmp)
+            else:
+                raise NotImplementedError
+        return best_alpha
+
+    def _forward(self, call):
+        args, kwargs = call
+        return self.model(*args, **kwargs)
+
+    def _get_one_batch_auto_loss(self, call, alpha_space, orig_best_alpha, input_maxes):
+        self._change_qdq_for_auto(enable=False)
+        module_names = self._get_sq_layer_names()
+        self._forward(call)  # quantisation off: float outputs
+        fp32_output = {}
+        for name in module_names:
+            module = get_module(self.model, name)
+            fp32_output[name] = module.output
+            module.output = None
+        self._change_qdq_for_auto(enable=True)
+        absorb_input_scales, weight_scales = self._cal_scales(self.absorb_to_layer, input_maxes, orig_best_alpha)
+        self._update_scales_for_auto(absorb_input_scales, weight_scales)
+        self._forward(call)  # quantisation on at the current alphas: every layer remembers the input it received
+        loss_alphas = {}
+        for name in module_names:
+            module = get_module(self.model, name)
+            cur_alpha = orig_best_alpha[name] if isinstance(orig_best_alpha, dict) else orig_best_alpha
+            loss_alphas[name] = {str(cur_alpha): self._get_auto_loss(fp32_output[name], module.output)}
+        for alpha in alpha_space:
+            absorb_input_scales, weight_scales = self._cal_scales(self.absorb_to_layer, input_maxes, alpha)
+            self._update_scales_for_auto(absorb_input_scales, weight_scales)
+            for name in module_names:
+                if str(alpha) in loss_alphas[name]:
+                    continue
+                module = get_module(self.model, name)
+                output = module.q_dq_forward(module.q_input, module.input_scale, module.weight_scale)
+                loss_alphas[name][str(alpha)] = self._get_auto_loss(fp32_output[name], output)
+        # one device -> host copy per sample (the reference compares 0-d CPU tensors)
+        return {n: {a: float(v) for a, v in d.items()} for n, d in loss_alphas.items()}
+
+    def default_tune_setup(self):
+        import numpy
+
+        round_num = max(len(str(self.alpha_min).split(".")[1]), len(str(self.alpha_max).split(".")[1]), len(str(self.alpha_step).split(".")[1]))
+        self.alpha_space = numpy.round(numpy.arange(self.alpha_min, self.alpha_max + self.alpha_step, self.alpha_step), round_num).tolist()
+        self._qdq_model_wrapper_for_auto(save_q_input=True)
+        absorb_input_scales, weight_scales = self._cal_scales(self.absorb_to_layer, self.input_maxes_abs, self.init_alpha)
+        self._update_scales_for_auto(absorb_input_scales, weight_scales)
+        return absorb_input_scales, weight_scales
+
+    def _auto_tune_alpha(self):
+        logger.info("Start alpha tuning")
+        self.default_tune_setup()
+        total_cnt, tmp_cnt, alpha_update_iter, tune_cnt = 0, 0, 0, 4
+        multiply_factor = self.calib_sample_num // tune_cnt if self.calib_sample_num >= tune_cnt else self.calib_sample_num
+        best_alphas = self.init_alpha
+        loss_alphas = {}
+        for call in self.calls:
+            loss_alphas = {}  # (sic, reference :1776) -- see the class docstring
+            best_alphas_per_module = best_alphas
+            if isinstance(best_alphas, dict):
+                for key, layer_names in self.absorb_to_layer.items():
+                    for layer_name in layer_names:
+                        best_alphas_per_module[layer_name] = best_alphas_per_module[key]
+            loss_tmp = self._get_one_batch_auto_loss(call, self.alpha_space, best_alphas_per_module, self.input_maxes_abs)
+            if loss_alphas == {}:
+                loss_alphas = loss_tmp
+            total_cnt += 1
+            tmp_cnt += 1
+            if tmp_cnt // multiply_factor >= 1:
+                alpha_update_iter += 1
+                tmp_cnt = 0
+                best_alphas = self._get_best_alpha(self.absorb_to_layer, loss_alphas, self.shared_criterion)
+                for key in best_alphas:
+                    logger.info("Auto alpha update iter: %d, %s: %s", alpha_update_iter, key, best_alphas[key])
+                absorb_input_scales, weight_scales = self._cal_scales(self.absorb_to_layer, self.input_maxes_abs, best_alphas)
+                self._update_scales_for_auto(absorb_input_scales, weight_scales)
+            if total_cnt >= self.calib_sample_num:
+                break
+        best_alphas = self._get_best_alpha(self.absorb_to_layer, loss_alphas, self.shared_criterion)
+        self.last_loss_alphas = loss_alphas
+        for key in best_alphas:
+            logger.info("Final alpha %s:%s", key, best_alphas[key])
+        self._qdq_model_unwrapper_for_auto()
+        logger.info("auto tuning done")
+        return best_alphas
+
+
 class TorchSmoothQuant:
     """Calibrate, compute the smoothing scales and apply them (:1895-2557), for nn.Linear layers.
 
@@ -255,6 +563,7 @@ class TorchSmoothQuant:
         self.input_mins, self.input_maxes = {}, {}
         self.same_input, self.producer = {}, {}
         self.example_call = None
+        self.calibration = None
         self.weight_scale_info, self.absorb_scales_info = {}, {}
         self.absorb_to_layer = {}
         self.weight_max_lb = 1e-5
@@ -374,17 +683,20 @@ class TorchSmoothQuant:
     @torch.no_grad()
     def transform(self, alpha=0.5, folding=False, calib_iter=100, op_types=(torch.nn.Linear,), scale_sharing=None,
                   absorb_to_layer=None, **kwargs):
-        if alpha == "auto":
-            raise NotImplementedError("alpha='auto' (the reference's layer-wise alpha tuner) is not implemented on MI355X")
-        alpha = max(float(alpha), 0.0) if not isinstance(alpha, dict) else alpha
+        is_auto = isinstance(alpha, str) and alpha == "auto"
+        if not is_auto:
+            alpha = max(float(alpha), 0.0) if not isinstance(alpha, dict) else alpha
         self.insert_mul, self.allow_absorb = (False, True) if folding else (True, False)
         if scale_sharing is not None:
             self.scale_sharing = scale_sharing
         if not self.input_maxes:
             calib = Calibration(self.model, self.dataloader, self.q_func)
+            if is_auto:
+                calib.capture_limit = int((kwargs.get("auto_alpha_args") or {}).get("n_samples", 32) or 32)
             self.input_mins, self.input_maxes = calib.calibrate(calib_iter, op_types)
             self.same_input, self.producer = calib.same_input, calib.producer
             self.example_call = calib.example_call
+            self.calibration = calib
         input_maxes_abs = {k: torch.max(self.input_mins[k].abs(), self.input_maxes[k].abs()) for k in self.input_mins}
         if absorb_to_layer is not None:
             self.absorb_to_layer = {k: list(v) for k, v in absorb_to_layer.items()}
@@ -403,6 +715,14 @@ class TorchSmoothQuant:
         if not self.absorb_to_layer:
             logger.warning("empty absorb_to_layer, smoothquant is ignored ")
             return self.model
+        if is_auto:  # layer-wise alpha (reference transform :2377-2393)
+            args = dict(kwargs.get("auto_alpha_args") or {})
+            tuner = AutoAlpha(self.model, self.dataloader, self.absorb_to_layer, op_types=op_types, device=next(self.model.parameters()).device,
+                              q_func=self.q_func, folding=folding, example_inputs=self.example_inputs,
+                              calibration=getattr(self, "calibration", None), **args)
+            alpha = tuner.tune()
+            self.auto_alpha_tuner = tuner
+        self.alpha = alpha
         self.weight_scale_info, self.absorb_scales_info = self._adjust_parameters(self.absorb_to_layer, input_maxes_abs, alpha)
         self.model._smoothquant_optimized = True
         return self.model

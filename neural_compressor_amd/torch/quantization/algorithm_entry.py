@@ -167,7 +167,7 @@ def smooth_quant_entry(model, configs_mapping, mode=Mode.QUANTIZE, *args, **kwar
             continue
         quant_config[op_name] = {
             "w_dtype": cfg.w_dtype, "alpha": cfg.alpha, "folding": cfg.folding, "scale_sharing": cfg.scale_sharing,
-            "absorb_to_layer": getattr(cfg, "absorb_to_layer", None),
+            "absorb_to_layer": getattr(cfg, "absorb_to_layer", None), "auto_alpha_args": getattr(cfg, "auto_alpha_args", None),
         }
     run_fn = kwargs.get("run_fn", None)
     example_inputs = kwargs.get("example_inputs", None)

@@ -214,8 +214,8 @@ def get_default_awq_config() -> AWQConfig:
 @register_config(framework_name=FRAMEWORK_NAME, algo_name=SMOOTH_QUANT, priority=PRIORITY_SMOOTH_QUANT)
 class SmoothQuantConfig(TorchBaseConfig):
     """SmoothQuant W8A8 (reference config.py:1485-1612): same fields and defaults.  On MI355X the supported cell is
-    the default one -- int8 per-channel symmetric weights, uint8 per-tensor asymmetric min/max activations -- and
-    `alpha` must be a number (the layer-wise "auto" tuner is not built)."""
+    the default one -- int8 per-channel symmetric weights, uint8 per-tensor asymmetric min/max activations; `alpha` is a
+    number or "auto" (the layer-wise tuner, reference smooth_quant/utility.py:1232 AutoAlpha; `do_blockwise` is not built)."""
 
     name = SMOOTH_QUANT
     supported_configs: List = []
