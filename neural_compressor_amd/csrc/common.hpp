@@ -133,6 +133,21 @@ __device__ __forceinline__ void lds_dma_4x1k(const void* base, uint32_t lds_dst,
       : "memory", "scc");
 }
 
+// one 1 KiB LDS-DMA of this wave: LDS[lds_dst + lane*16] <- base[voff] (per-lane byte offset); M0 saved / restored
+__device__ __forceinline__ void lds_dma_1k(const void* base, uint32_t lds_dst, uint32_t voff) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_nop 4\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(base), "s"(lds_dst)
+      : "memory");
+}
+
 // logical tile index -> (tm, tn), walking the tile grid in bands of 8 tile-rows, column by column inside a band.  The W8A8
 // GEMM first gives every XCD a contiguous range of logical indices (block b runs on XCD b % 8); with this order such a
 // range is an 8 x c patch instead of a 2 x 4c strip, so the tiles an XCD runs concurrently share more operand panels in

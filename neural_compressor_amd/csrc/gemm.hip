@@ -995,21 +995,6 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
 // step t-1).  A wave's 128 fp32 accumulators + one fragment set fit the 168-register budget of three waves per SIMD.
 constexpr int PC_THREADS = 768;
 
-// one 1 KiB LDS-DMA of this wave: LDS[lds_dst + lane*16] <- base[voff]; M0 saved / restored (see lds_dma_4x1k)
-__device__ __forceinline__ void lds_dma_1k(const void* base, uint32_t lds_dst, uint32_t voff) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_nop 4\n\t"
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(base), "s"(lds_dst)
-      : "memory");
-}
-
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // Epilogue of the producer / consumer kernel for a FULL 256 x 256 tile: the accumulator layout (a lane owns 4 consecutive

@@ -342,6 +342,164 @@ __device__ __forceinline__ void hessian_syrk_256_tile(const uint16_t* __restrict
     }
 }
 
+// ---- 256x256 syrk tile, transpose-read generation (round 2) --------------------------------------------------------
+// The kernel above moves X through registers: per 64-token step every thread issues eight 16-byte loads, transposes an 8x8
+// block with 32 v_perm_b32 and writes eight 16-byte rows to LDS -- more VALU / VMEM / LDS-store issue than the 32 MFMAs they
+// feed (PMC: matrix pipe busy 0.39).  Here the X tile goes to LDS untouched and untransposed: one LDS-DMA instruction per
+// token row ([i-panel 512 B][j-panel 512 B], lanes 0-31 / 32-63 read the two panels), no VGPR, no VALU, no ds_write; the
+// fragments are read with ds_read_b64_tr_b16, which hands lane (4a + e) of a 16-lane group element e of lanes a, a+4, a+8,
+// a+12 (tools/kbench probe): with lane (a + 4b) pointing at token row b, feature block 4a, a lane receives 4 consecutive
+// tokens of ONE feature -- the K-contiguous operand of v_mfma_f32_16x16x32 -- for both operands of X^T X.  Row pitch 1056 B
+// (1024 + 32 = 8 dwords past a multiple of 64 banks): a 32-lane half of a transpose-read touches 8 token rows x 32 B, which
+// are conflict-free when the rows are CONSECUTIVE (8 different 32-byte bank slots).  The MFMA K index only has to pair the
+// same token in both operands, so group g of 16 lanes takes tokens 4g .. 4g+3 (first read) and 16+4g .. 16+4g+3 (second
+// read) of a 32-token sub-step instead of the 8g .. 8g+7 of the operand's natural order, whose two halves (rows 0-3 and
+// 8-11) share bank slots.  Stages: TOK tokens each, NST of them, the DMA runs NST-1 steps ahead with counted vmcnt waits;
+// (64, 2) is the product configuration (132 KiB; (32, 4) pays twice the barriers and measured 5 % slower).
+constexpr int TR_PITCH = 1056;
+constexpr int TR_TOK = 64;
+constexpr int TR_NST = 2;
+constexpr int TR_STAGE = TR_TOK * TR_PITCH;  // 67 584 B
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <bool IS_BF16, int TOK, int NST>
+__device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
+                                                     float* __restrict__ H, float beta, float alpha, int nt, int block, int nblocks) {
+  static_assert((NST & (NST - 1)) == 0 && NST >= 2 && NST <= 4 && TOK % 32 == 0, "stage ring");
+  constexpr int D = NST - 1;        // steps the DMA runs ahead
+  constexpr int RPW = TOK / 8;      // DMA requests (token rows) per wave and step
+  constexpr int STAGE = TOK * TR_PITCH;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int ti, tj;
+  xcd_supertile_decode(block, nblocks, nt, ti, tj);
+  const int64_t i0 = (int64_t)ti * H2, j0 = (int64_t)tj * H2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
+
+  // DMA source: this lane's 16-byte chunk (8 features) of the i panel (lanes 0..31) or the j panel (lanes 32..63)
+  int64_t f = (lane < 32 ? i0 : j0) + 8 * (lane & 31);
+  if (f > K - 8) f = K - 8;  // K % 8 == 0 on this path: a chunk past K only feeds rows / columns that are never stored
+  const uint32_t voff = (uint32_t)(f * 2);
+  const int nk = (int)((T + TOK - 1) / TOK);
+  auto issue = [&](int kt) {
+    const int stage = kt & (NST - 1);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave * RPW + i;
+      int64_t t = (int64_t)kt * TOK + r;
+      if (t > T - 1) t = T - 1;  // rows past T are zeroed in LDS before they are multiplied (below)
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + r * TR_PITCH);
+      lds_dma_1k(x + t * ldx, dst, voff);
+    }
+  };
+  // step `next` has landed when at most the steps after it (up to `last_issued`) are still in this wave's queue
+  auto wait_landed = [&](int next, int last_issued) {
+    const int younger = last_issued - next;
+    if (D >= 3 && younger >= 2) wait_vmcnt<2 * RPW>();
+    else if (D >= 2 && younger >= 1) wait_vmcnt<RPW>();
+    else wait_vmcnt<0>();
+  };
+
+  f32x4_t acc[8][4];  // [i fragment of 16 rows][j fragment of 16 columns]
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read address: lane (a + 4b) of 16-lane group g -> token row 4g + b (second read: 16 + 4g + b), feature block 4a
+  const int s16 = lane & 15, fa = s16 & 3, fb = s16 >> 2, fg = lane >> 4;
+  const uint32_t rbase = (uint32_t)((4 * fg + fb) * TR_PITCH + (wm * 128 + 4 * fa) * 2);        // + mt * 32
+  const uint32_t cbase = (uint32_t)((4 * fg + fb) * TR_PITCH + 512 + (wn * 64 + 4 * fa) * 2);  // + nt * 32
+  typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+  auto frag = [&](uint32_t byte_off) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(byte_off));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(uintptr_t)(byte_off + 16 * TR_PITCH));
+    uint4 v;
+    __builtin_memcpy(&v, &lo, 8);
+    __builtin_memcpy(reinterpret_cast<char*>(&v) + 8, &hi, 8);
+    return v;
+  };
+
+  const int pro = nk < D ? nk : D;
+  for (int d = 0; d < pro; ++d) issue(d);
+  wait_landed(0, pro - 1);
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & (NST - 1);
+    if (kt + D < nk) issue(kt + D);  // its stage was last read in step kt - 1 (barrier passed)
+    if (kt == nk - 1 && (T % TOK) != 0) {
+      // token tail: zero the rows past T of this (last) stage; its DMA has landed (counted wait + barrier of the previous step)
+      const int first = (int)(T - (int64_t)kt * TOK);
+      for (int idx = tid; idx < (TOK - first) * 64; idx += 512) {
+        const int r = first + idx / 64, c = idx % 64;
+        *reinterpret_cast<uint4*>(smem_raw + cur * STAGE + r * TR_PITCH + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int kk = 0; kk < TOK / 32; ++kk) {
+      const uint32_t st = lds0 + cur * STAGE + kk * 32 * TR_PITCH;
+      uint4 a[8], b[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = frag(st + cbase + n * 32);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) a[m] = frag(st + rbase + m * 32);
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if constexpr (IS_BF16) {
+            bf16x8 fa8, fb8;
+            __builtin_memcpy(&fa8, &a[m], 16);
+            __builtin_memcpy(&fb8, &b[n], 16);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa8, fb8, acc[m][n], 0, 0, 0);
+          } else {
+            f16x8 fa8, fb8;
+            __builtin_memcpy(&fa8, &a[m], 16);
+            __builtin_memcpy(&fb8, &b[n], 16);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa8, fb8, acc[m][n], 0, 0, 0);
+          }
+        }
+    }
+    // every fragment read of this step has returned (the compiler sinks the last MFMAs below the barrier, so this is not
+    // implied by program order) and step kt + 1 has landed (younger steps stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int last_issued = kt + D < nk ? kt + D : nk - 1;
+    wait_landed(kt + 1, last_issued > kt + 1 ? last_issued : kt + 1);
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // epilogue: D[row i][col j] of a 16x16 fragment: col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int64_t col = j0 + wn * 64 + n * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = i0 + wm * 128 + m * 16 + 4 * (lane >> 4) + r;
+        if (row < K && col < K) {
+          float* p = H + row * K + col;
+          *p = beta * (*p) + alpha * acc[m][n][r];
+        }
+      }
+    }
+}
+
+template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST>
+__global__ __launch_bounds__(512) void hessian_syrk_tr_256_kernel(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
+                                                                  float* __restrict__ H, float beta, float alpha, int nt) {
+  hessian_syrk_tr_tile<IS_BF16, TOK, NST>(x, T, K, ldx, H, beta, alpha, nt, (int)blockIdx.x, (int)gridDim.x);
+}
+
 template <bool IS_BF16, bool TAIL>
 __global__ __launch_bounds__(512) void hessian_syrk_16bit_256_kernel(const uint16_t* __restrict__ x, int64_t T,
                                                                      int64_t K, int64_t ldx, float* __restrict__ H,
@@ -367,6 +525,18 @@ struct HessianBatch {
   int first[HESSIAN_MAX_BATCH + 1];  // first block of every problem, then the grid size
   int n;
 };
+
+template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST>
+__global__ __launch_bounds__(512) void hessian_syrk_tr_256_multi_kernel(HessianBatch args, int64_t T) {
+  const int b = (int)blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < HESSIAN_MAX_BATCH; ++i)
+    if (i < args.n && b >= args.first[i]) p = i;
+  p = __builtin_amdgcn_readfirstlane(p);
+  hessian_syrk_tr_tile<IS_BF16, TOK, NST>(args.x[p], T, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p], args.nt[p],
+                                b - args.first[p], args.first[p + 1] - args.first[p]);
+}
 
 template <bool IS_BF16, bool TAIL>
 __global__ __launch_bounds__(512) void hessian_syrk_16bit_256_multi_kernel(HessianBatch args, int64_t T) {
@@ -959,6 +1129,25 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
       }
       const uint16_t* xp = (const uint16_t*)x;
       const bool tail = (T % HK) != 0;
+      if (inc_small_tiles_flag(-1) != 45) {  // transpose-read generation (harness flag 45: the register-transposing kernel)
+        const size_t smem3 = (size_t)TR_NST * TR_STAGE;  // 132 KiB
+        static std::atomic<uint64_t> attr3_set{0};
+        if (inc_attr_needed(attr3_set)) {
+          (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+          (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+          inc_attr_done(attr3_set);
+        }
+#ifdef INC_KBENCH
+        if (inc_small_tiles_flag(-1) == 46 && xdtype == INC_BF16) {  // timing A/B: four 32-token stages
+          (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_kernel<true, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+          hessian_syrk_tr_256_kernel<true, 32, 4><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);
+          INC_LAUNCH_RETURN();
+        }
+#endif
+        if (xdtype == INC_BF16) hessian_syrk_tr_256_kernel<true><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);
+        else hessian_syrk_tr_256_kernel<false><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);
+        INC_LAUNCH_RETURN();
+      }
 #define INC_H2(B, TL) hessian_syrk_16bit_256_kernel<B, TL><<<ntiles2, 512, smem2, s>>>(xp, T, K, ldx, H, beta, alpha, nt2)
       if (xdtype == INC_BF16) { if (tail) INC_H2(true, true); else INC_H2(true, false); }
       else { if (tail) INC_H2(false, true); else INC_H2(false, false); }
@@ -1007,6 +1196,25 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
   }
   hipStream_t s = inc_s(stream);
   const bool tail = (T % HK) != 0;
+  if (inc_small_tiles_flag(-1) != 45) {  // transpose-read generation
+    const size_t smem3 = (size_t)TR_NST * TR_STAGE;
+    static std::atomic<uint64_t> attr3_set{0};
+    if (inc_attr_needed(attr3_set)) {
+      (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+      (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+      inc_attr_done(attr3_set);
+    }
+#ifdef INC_KBENCH
+    if (inc_small_tiles_flag(-1) == 46 && xdtype == INC_BF16) {  // timing A/B: four 32-token stages
+      (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_multi_kernel<true, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+      hessian_syrk_tr_256_multi_kernel<true, 32, 4><<<first, 512, smem3, s>>>(a, T);
+      INC_LAUNCH_RETURN();
+    }
+#endif
+    if (xdtype == INC_BF16) hessian_syrk_tr_256_multi_kernel<true><<<first, 512, smem3, s>>>(a, T);
+    else hessian_syrk_tr_256_multi_kernel<false><<<first, 512, smem3, s>>>(a, T);
+    INC_LAUNCH_RETURN();
+  }
 #define INC_HM(B, TL) hessian_syrk_16bit_256_multi_kernel<B, TL><<<first, 512, smem2, s>>>(a, T)
   if (xdtype == INC_BF16) { if (tail) INC_HM(true, true); else INC_HM(true, false); }
   else { if (tail) INC_HM(false, true); else INC_HM(false, false); }

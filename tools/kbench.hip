@@ -363,7 +363,7 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
   DevBuf<float> H((size_t)K * K), Hold((size_t)K * K);
   H.zero();
   Hold.zero();
-  inc_debug_set_small_tiles(0);
+  inc_debug_set_small_tiles(0);  // default: the transpose-read generation
   INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.f, 1.f, nullptr));
   INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.25f, nullptr));  // exercises beta/alpha
   inc_debug_set_small_tiles(1);
@@ -409,18 +409,59 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
          (long)K, rel, (long)differ, ns, maxrel, ok ? "OK" : "FAIL");
   if (time_it) {
     Timer t;
-    for (int mode = 0; mode < 2; ++mode) {
-      inc_debug_set_small_tiles(mode);
+    const int modes[4] = {0, 46, 45, 1};
+    const char* labels[4] = {"256x256 transpose-read 2x64", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles"};
+    for (int mi = 0; mi < 4; ++mi) {
+      inc_debug_set_small_tiles(modes[mi]);
       for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
       const int iters = 10;
       t.start();
       for (int i = 0; i < iters; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
       const float ms = t.stop_ms() / iters;
-      printf("  %-22s %9.4f ms  %8.1f TFLOP/s (2*T*K^2 convention)\n", mode ? "128x128 tiles" : "256x256 tiles", ms, 2.0 * T * K * K / ms / 1e9);
+      printf("  %-28s %9.4f ms  %8.1f TFLOP/s (2*T*K^2 convention)\n", labels[mi], ms, 2.0 * T * K * K / ms / 1e9);
     }
     inc_debug_set_small_tiles(0);
   }
   return ok ? 0 : 1;
+}
+
+// the Llama-block launch of the bench: three K = 4096 Hessians and one K = 11008 Hessian of one forward in ONE launch
+static int run_hessian_multi_case(int64_t T) {
+  const int64_t Ks[4] = {4096, 4096, 4096, 11008};
+  std::vector<DevBuf<uint16_t>*> xs;
+  std::vector<DevBuf<float>*> Hs;
+  const void* xp[4];
+  float* hp[4];
+  int64_t ld[4];
+  float betas[4], alphas[4];
+  double flops = 0;
+  for (int i = 0; i < 4; ++i) {
+    xs.push_back(new DevBuf<uint16_t>((size_t)T * Ks[i]));
+    Hs.push_back(new DevBuf<float>((size_t)Ks[i] * Ks[i]));
+    std::vector<uint16_t> hx((size_t)T * Ks[i]);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    xs[i]->upload(hx);
+    Hs[i]->zero();
+    xp[i] = xs[i]->p; hp[i] = Hs[i]->p; ld[i] = Ks[i]; betas[i] = 0.5f; alphas[i] = 0.5f;
+    flops += 2.0 * T * Ks[i] * Ks[i];
+  }
+  printf("HESSIAN multi T=%ld K=4096+4096+4096+11008 (one launch)\n", (long)T);
+  Timer t;
+  const int modes[3] = {0, 46, 45};
+  const char* labels[3] = {"transpose-read 2x64", "transpose-read 4x32", "register transpose"};
+  for (int mi = 0; mi < 3; ++mi) {
+    inc_debug_set_small_tiles(modes[mi]);
+    for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, nullptr));
+    const int iters = 10;
+    t.start();
+    for (int i = 0; i < iters; ++i) INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, nullptr));
+    const float ms = t.stop_ms() / iters;
+    printf("  %-28s %9.4f ms  %8.1f TFLOP/s (2*T*K^2 convention)\n", labels[mi], ms, flops / ms / 1e9);
+  }
+  inc_debug_set_small_tiles(0);
+  for (auto* b : xs) delete b;
+  for (auto* b : Hs) delete b;
+  return 0;
 }
 
 // ---- GPTQ column loop: quad-per-row quant block + register-resident lazy update vs the first generation --------
@@ -563,6 +604,9 @@ int main(int argc, char** argv) {
     fails += run_hessian_case(2048, 4096, true);
     fails += run_hessian_case(2048, 11008, true);
     fails += run_hessian_case(16384, 4096, true);
+    fails += run_hessian_case(16384, 11008, true);
+    fails += run_hessian_case(1000, 520, false);      // 40-token tail, feature chunks clamped at K
+    fails += run_hessian_multi_case(16384);
   }
   if (what == "colloop" || what == "all") {
     fails += run_colloop_case(200, 512, 32, 4, false);      // ragged rows, 4 groups per block
