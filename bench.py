@@ -449,7 +449,7 @@ def main():
         all_ms = sum(x["total_ms"] for x in hess.values())
         traffic, traffic_src = _pmc_traffic(dom)
         multi = dom.startswith("hessian_multi")
-        roofline = dict(kernel=("hessian_syrk_16bit_256_multi_kernel<bf16>" if multi else "hessian_syrk_16bit_256_kernel<bf16>") +
+        roofline = dict(kernel=("hessian_syrk_tr_256_multi_kernel<bf16>" if multi else "hessian_syrk_tr_256_kernel<bf16>") +
                                f" ({dom}; algorithmic flops 2*T*K^2 per Hessian and launch)", bound="mfma",
                         achieved=round(achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,

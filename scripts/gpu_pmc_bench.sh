@@ -16,7 +16,12 @@ root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in glob.glob(os.path.join(root, "gpurun_out/pmc_bench/*/pmc_counter_collection.csv")):
     for r in csv.DictReader(open(d)):
-        if "hessian_syrk_16bit_256" in r["Kernel_Name"]:
+        name = r["Kernel_Name"]
+        if "hessian_syrk_tr_256_multi" in name or "hessian_syrk_16bit_256_multi" in name:
+            # the bench's Llama block launch: 3 x 136 + 946 = 1354 tiles of 512 threads
+            key = "hessian_multi_K4096+4096+4096+11008" if int(r["Grid_Size"]) == 512 * 1354 else "hessian_multi_other"
+            agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        elif "hessian_syrk_tr_256" in name or "hessian_syrk_16bit_256" in name:
             key = "hessian_K11008" if int(r["Grid_Size"]) > 512 * 200 else "hessian_K4096"
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
