@@ -996,6 +996,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
 constexpr int PC_THREADS = 768;
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 // Epilogue of the producer / consumer kernel for a FULL 256 x 256 tile: the accumulator layout (a lane owns 4 consecutive
 // columns of 32 different rows) would leave as 8-byte pieces scattered over 32 rows per store instruction -- 1024 partial-line
@@ -1620,6 +1621,287 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
     }
 }
 
+// =============================================================================================
+// mid-M strip kernel (round 2): 64 < M <= STRIP_MAX_M
+// =============================================================================================
+// The 256 x 256 tile needs split-K over 8-16 fp32 slabs to put such a problem on 256 CUs (M = 512, 4096^2: 32 tiles, 134 MB of
+// slab traffic, 62 us; M = 128: 30 us).  This kernel extends the streaming kernel instead: a workgroup owns 64 rows x 128
+// columns for the WHOLE of K (or 1/splitk of it when rows x columns alone leave CUs idle), its eight waves take an eighth of
+// the K-steps each, and a wave's packed-weight loads ARE its MFMA B fragments (a lane's uint4 = 8 consecutive k of 4 adjacent
+// columns), dequantised in registers and fed to four 16x16x32 MFMAs each; the waves' accumulators meet in LDS at the end (64 x 64
+// outputs per pass).  Split-K (only when needed, <= 4 slices) hands over like the streaming kernel: write-through partials, one
+// relaxed ticket, the last arriver sums in slice order -> deterministic.
+constexpr int64_t STRIP_MAX_M = 1024;
+constexpr int STRIP_WAVES = 8;                                          // waves per workgroup: eighths of the K range
+constexpr int STRIP_RING = 3;                                           // operand slots (K-steps in flight) per wave
+constexpr int STRIP_SMEM_BYTES = STRIP_WAVES * STRIP_RING * 6 * 1024;   // 144 KiB: the operand rings; the epilogue reuses them
+static_assert(STRIP_SMEM_BYTES >= STRIP_WAVES * 64 * 65 * 4, "the reduction buffer (8 x 64 x 65 fp32) aliases the rings");
+
+template <bool IS_BF16, int WAVES, int RING>
+__global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
+    const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
+    float* __restrict__ partial, unsigned* __restrict__ counters, int M, int64_t N, int64_t K, int64_t NW, int g_shift, int splitk) {
+  constexpr int MB = 4, NB = 2;  // 16-row blocks and 64-column groups of a wave: the operand requests below are written out for these
+  constexpr int ROWS = 16 * MB, COLS = 64 * NB, NT = 64 * WAVES;
+  extern __shared__ __attribute__((aligned(16))) char strip_smem[];
+  float* const red = reinterpret_cast<float*>(strip_smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jn = lane & 15, oct = lane >> 4;
+  const float inv_u = fp8_unit_inverse();
+  const int64_t n0 = (int64_t)blockIdx.x * COLS;
+  const int m0 = (int)blockIdx.y * ROWS;
+  const int slice = blockIdx.z;
+
+  int64_t ncol[NB];
+  int zsh[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    ncol[nb] = n0 + 64 * nb + 4 * jn;
+    if (ncol[nb] > N - 4) ncol[nb] = N - 4;  // clamped lanes recompute valid columns; their results are not stored
+    zsh[nb] = 4 * (int)(ncol[nb] & 7);
+  }
+  // this wave's K-steps (32 k each): an even share of the slice-and-wave grid
+  const int steps_total = (int)(K / 32);
+  const int Q = WAVES * splitk, q = slice * WAVES + wave;
+  const int lo = (int)((int64_t)steps_total * q / Q), hi = (int)((int64_t)steps_total * (q + 1) / Q);
+
+  // Operand pipeline.  hipcc sinks plain loads to their first use, and a wave then pays the full memory latency in every step
+  // (measured: 1.4 us per step); pinned register prefetch one step ahead is all the register file allows next to 128
+  // accumulators at two waves per SIMD, and was still latency-bound (a third of the wave time issuing).  So the fragments travel
+  // through LDS without touching a register: every wave owns a ring of RING slots of 6 KiB; a step's four x fragments and two
+  // weight fragments arrive by six LDS-DMA requests (lane-linear image = the fragment layout), RING steps ahead of the MFMAs, and
+  // are picked up with six conflict-free ds_read_b128.  The raw group parameters (4 small requests per step) stay register
+  // loads in the same in-order queue: one step = 10 requests.
+  struct Step {  // x and weight fragments of one K-step
+    uint4 a[4];
+    uint4 w[2];
+  };
+  struct Par {  // raw scales / zero-point words of the step's group
+    u32x2 s[2];
+    uint32_t z[2];
+  };
+  constexpr int SLOT = 6 * 1024;
+  const uint32_t ring0 = (uint32_t)(uintptr_t)strip_smem + (uint32_t)wave * (RING * SLOT);
+  uint32_t xoff[4], woff[2], soff[2], zoff[2];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    int am = m0 + 16 * b + jn;
+    if (am > M - 1) am = M - 1;  // rows past M are computed from a valid row and never stored
+    xoff[b] = (uint32_t)(((int64_t)am * K + 8 * oct) * 2);
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    woff[nb] = (uint32_t)(((int64_t)oct * N + ncol[nb]) * 4);
+    soff[nb] = (uint32_t)(ncol[nb] * 2);
+    zoff[nb] = (uint32_t)((ncol[nb] >> 3) * 4);
+  }
+  auto issue = [&](int slot, Par& p, int st) {
+    st = st > hi - 1 ? hi - 1 : st;  // the prefetch past the end re-reads the last step
+    const int64_t g = g_shift >= 0 ? (((int64_t)st * 32) >> g_shift) : 0;
+    const uint16_t* xb = x + (int64_t)st * 32;
+    const uint32_t* wb = qweight + (int64_t)st * 4 * N;
+    const uint16_t* sb = scales + g * N;
+    const uint32_t* zb = qzeros + g * NW;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)slot * SLOT);
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_nop 4\n\t"
+        "s_mov_b32 m0, %19\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %15\n\t"
+        "s_add_u32 m0, %19, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, %15\n\t"
+        "s_add_u32 m0, %19, 0x800\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, %15\n\t"
+        "s_add_u32 m0, %19, 0xc00\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, %15\n\t"
+        "s_add_u32 m0, %19, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %9, %16\n\t"
+        "s_add_u32 m0, %19, 0x1400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %10, %16\n\t"
+        "global_load_dwordx2 %1, %11, %17\n\t"
+        "global_load_dwordx2 %2, %12, %17\n\t"
+        "global_load_dword %3, %13, %18\n\t"
+        "global_load_dword %4, %14, %18\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&v"(p.s[0]), "=&v"(p.s[1]), "=&v"(p.z[0]), "=&v"(p.z[1])
+        : "v"(xoff[0]), "v"(xoff[1]), "v"(xoff[2]), "v"(xoff[3]), "v"(woff[0]), "v"(woff[1]), "v"(soff[0]), "v"(soff[1]), "v"(zoff[0]),
+          "v"(zoff[1]), "s"(xb), "s"(wb), "s"(sb), "s"(zb), "s"(dst)
+        : "memory", "scc");
+  };
+  // the oldest of RING steps in flight has landed in its slot / its parameter registers (the younger ones stay in flight)
+  auto landed = [&](Par& p) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(p.s[0]), "+v"(p.s[1]), "+v"(p.z[0]), "+v"(p.z[1]) : "i"(10 * (RING - 1)) : "memory");
+  };
+  auto fetch = [&](Step& t, int slot) {
+    const char* base = strip_smem + wave * (RING * SLOT) + slot * SLOT + lane * 16;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) t.a[b] = *reinterpret_cast<const uint4*>(base + b * 1024);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) t.w[nb] = *reinterpret_cast<const uint4*>(base + 4096 + nb * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is free for the next DMA once these have returned
+  };
+
+  f32x4 acc[MB][4 * NB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int c = 0; c < 4 * NB; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // scale / zero point of this lane's 8 columns, refreshed when the K-step enters a new group (every 2^(g_shift-5) steps)
+  float scu[4 * NB], nzs[4 * NB];
+  const int gmask = g_shift < 0 ? 0x7fffffff : ((1 << (g_shift - 5)) - 1);
+  auto refresh = [&](const Par& p, int st) {
+    if (st == lo || (st & gmask) == 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float sc = f16_bits_to_f32((uint16_t)(p.s[nb][c >> 1] >> (16 * (c & 1))));
+          uint32_t zz = ((p.z[nb] >> (zsh[nb] + 4 * c)) & 15u) + 1u;  // modules.py:407-410 (stored zp - 1; wraps above 15)
+          zz = zz > 15u ? 0u : zz;
+          scu[4 * nb + c] = sc * inv_u;
+          nzs[4 * nb + c] = -(float)zz * sc;
+        }
+    }
+  };
+  auto compute = [&](const Step& t) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const uint32_t ww[4] = {t.w[nb].x, t.w[nb].y, t.w[nb].z, t.w[nb].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 bq = dequant8<IS_BF16>(ww[c], scu[4 * nb + c], nzs[4 * nb + c]);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[b][4 * nb + c] = mfma16<IS_BF16>(t.a[b], bq, acc[b][4 * nb + c]);
+      }
+    }
+  };
+
+  static_assert(RING == 3, "the loop below is unrolled over three parameter sets");
+  if (lo < hi) {
+    Par p0, p1, p2;
+    Step t;
+    issue(0, p0, lo);
+    issue(1, p1, lo + 1);
+    issue(2, p2, lo + 2);
+#define INC_STRIP_STEP(ST, SLOTI, P) \
+  {                                  \
+    landed(P);                       \
+    fetch(t, SLOTI);                 \
+    refresh(P, ST);                  \
+    issue(SLOTI, P, (ST) + 3);       \
+    compute(t);                      \
+  }
+    for (int st = lo; st < hi; st += 3) {
+      INC_STRIP_STEP(st, 0, p0)
+      if (st + 1 < hi) INC_STRIP_STEP(st + 1, 1, p1)
+      if (st + 2 < hi) INC_STRIP_STEP(st + 2, 2, p2)
+    }
+#undef INC_STRIP_STEP
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped prefetches past the end
+  __syncthreads();                                   // every wave's ring is dead: the reduction buffer takes their place
+
+  // ---- the waves' accumulators meet in LDS, 64 rows x 64 columns per pass ---------------------------------------------
+  // D of an MFMA: column = lane & 15 -> tile column 4*jn + c, row = 4*oct + r
+  const int64_t slab = (int64_t)M * N;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    if (nb > 0) __syncthreads();  // the previous pass has been read
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 64 + 16 * b + 4 * oct + r) * 65 + 4 * jn + c] = acc[b][4 * nb + c][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64 * 64 / NT; ++i) {
+      const int idx = tid + NT * i, rr = idx >> 6, cc = idx & 63;
+      float v = red[rr * 65 + cc];
+#pragma unroll
+      for (int wv = 1; wv < WAVES; ++wv) v += red[(wv * 64 + rr) * 65 + cc];  // fixed order
+      const int m = m0 + rr;
+      const int64_t n = n0 + 64 * nb + cc;
+      if (m < M && n < N) {
+        if (splitk > 1) {
+          __hip_atomic_store(&partial[(int64_t)slice * slab + (int64_t)m * N + n], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
+        } else {
+          const float o = v + (bias ? cvt16<IS_BF16>(bias[n]) : 0.f);
+          y[(int64_t)m * N + n] = IS_BF16 ? f32_to_bf16_bits(o) : f32_to_f16_bits(o);
+        }
+      }
+    }
+  }
+  if (splitk <= 1) return;
+  // publish: every wave drains its write-through stores, then one relaxed agent-scope ticket from thread 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned* const counter = counters + (blockIdx.y * gridDim.x + blockIdx.x);
+  if (tid == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == (unsigned)(splitk - 1);
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
+    red[0] = last ? 1.f : 0.f;
+  }
+  __syncthreads();
+  if (red[0] == 0.f) return;
+  // last arriver: fixed-order sum over the slices (sc1 loads: L1-bypassing, the partials were written through); 8 outputs x up
+  // to 4 slices of a thread are in flight together
+  constexpr int OUTS = ROWS * COLS / NT;
+  for (int i0 = 0; i0 < OUTS; i0 += 8) {
+    float pv[4][8];
+    int64_t off[8];
+    bool ok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + NT * (i0 + i), rr = idx / COLS, cc = idx % COLS;
+      const int m = m0 + rr;
+      const int64_t n = n0 + cc;
+      ok[i] = m < M && n < N;
+      off[i] = ok[i] ? (int64_t)m * N + n : 0;
+    }
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int64_t base = (int64_t)(sl < splitk ? sl : splitk - 1) * slab;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pv[sl][i] = __hip_atomic_load(&partial[base + off[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = pv[0][i];
+#pragma unroll
+      for (int sl = 1; sl < 4; ++sl) v += sl < splitk ? pv[sl][i] : 0.f;
+      if (ok[i]) {
+        const int64_t n = n0 + (tid + NT * (i0 + i)) % COLS;
+        v += bias ? cvt16<IS_BF16>(bias[n]) : 0.f;
+        y[off[i]] = IS_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+      }
+    }
+  }
+}
+
+// K-slices of the strip kernel for (M, N, K): split-K only to fill the chip (one workgroup = two waves per SIMD per CU)
+static int strip_splitk(int64_t M, int64_t N, int64_t K) {
+  const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);
+  int sk = 1;
+  if (wgs < 192) {
+    sk = (int)(256 / wgs);
+    if (sk > 4) sk = 4;                                                   // the last arriver sums <= 4 slabs
+    while (sk > 1 && (K / 32) / (STRIP_WAVES * sk) < 4) --sk;            // >= 4 steps per wave
+  }
+  return sk;
+}
+
 // choose the number of K-slices for the small-M kernel: enough workgroups to cover the chip, each
 // slice a multiple of 4 waves x one MFMA K=32 step
 inline int small_slices(int64_t N, int64_t K, int bits, int* kw_per_slice_out) {
@@ -1672,7 +1954,10 @@ int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     int steps;
     const int splits = M > 16 && N >= 64 ? big_splitk(M, N, K, &steps) : 1;
     big = splits > 1 ? WS_COUNTER_BYTES + (int64_t)splits * M * N * 4 : 0;  // slabs start AFTER the counter block
-    if (M > GEMV_MAX_M) return big;
+    if (M > GEMV_MAX_M) {
+      const int64_t strip = M <= STRIP_MAX_M ? WS_COUNTER_BYTES + 4 * M * N * 4 : 0;  // the strip kernel: <= 4 K-slices
+      return strip > big ? strip : big;
+    }
   }
   int64_t slices = ceil_div64(K, 32 * 4 * 4);  // the streaming kernel at 4 steps per wave
   if (slices < 64) slices = 64;  // the generic split-K path uses up to 64 slices
@@ -1714,6 +1999,26 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   // weight-only INT8 (BASELINE config #1's layers): the 3A2B kernel's 8-bit instantiation, same tiling and split-K plan
   const bool big8_ok = bits == 8 && (K % 128) == 0 && g_shift != -2 && M > 16 && N >= 64 && dbg == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 4) < (int64_t)1 << 31;
+  // 64 < M <= 1024: the strip kernel (no 256-row tiles, no slab passes); harness flags 42 / 40 / 4 / 6: the tile paths
+  const bool strip_ok = bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && M > GEMV_MAX_M && M <= STRIP_MAX_M &&
+                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && dbg == 0;
+  if (strip_ok) {
+    int splitk = strip_splitk(M, N, K);
+    const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);
+    if (splitk > 1 && (!workspace || workspace_bytes < WS_COUNTER_BYTES + (int64_t)splitk * M * N * 4 || wgs * 4 > WS_COUNTER_BYTES)) splitk = 1;
+    static std::atomic<uint64_t> strip_attr_set{0};
+    if (inc_attr_needed(strip_attr_set)) {
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_strip_kernel<true, STRIP_WAVES, STRIP_RING>, hipFuncAttributeMaxDynamicSharedMemorySize, STRIP_SMEM_BYTES);
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_strip_kernel<false, STRIP_WAVES, STRIP_RING>, hipFuncAttributeMaxDynamicSharedMemorySize, STRIP_SMEM_BYTES);
+      inc_attr_done(strip_attr_set);
+    }
+    unsigned* counters = (unsigned*)workspace;
+    float* part = splitk > 1 ? (float*)((char*)workspace + WS_COUNTER_BYTES) : nullptr;
+    dim3 grid((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)splitk);
+    if (bf) woq_gemm_w4_strip_kernel<true, STRIP_WAVES, STRIP_RING><<<grid, 64 * STRIP_WAVES, STRIP_SMEM_BYTES, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, g_shift, splitk);
+    else woq_gemm_w4_strip_kernel<false, STRIP_WAVES, STRIP_RING><<<grid, 64 * STRIP_WAVES, STRIP_SMEM_BYTES, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, g_shift, splitk);
+    INC_LAUNCH_RETURN();
+  }
   if (big8_ok) {
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;
     static std::atomic<uint64_t> a8_attr_set{0};

@@ -5,10 +5,12 @@ set -u
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
+MODE="${1:-prof}"   # tools/kbench mode to profile: prof (default) | profstrip
+rm -rf "$ROOT/gpurun_out/pmc"; mkdir -p "$ROOT/gpurun_out/pmc"
 cd /tmp
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY"; do
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS"; do
   tag=$(echo "$pass" | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$ROOT/gpurun_out/pmc/$tag" -o pmc -- "$ROOT/tools/kbench" prof > "$ROOT/gpurun_out/pmc/$tag.log" 2>&1
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$ROOT/gpurun_out/pmc/$tag" -o pmc -- "$ROOT/tools/kbench" $MODE > "$ROOT/gpurun_out/pmc/$tag.log" 2>&1
   echo "pass [$pass] exit $?"
 done
 find "$ROOT/gpurun_out/pmc" -name "*.csv" | head -20

@@ -255,6 +255,88 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
   return ok ? 0 : 1;
 }
 
+// ---- mid-M strip kernel vs the 256-row tile + split-K path: checked against the fp32 reference rows, then timed --------
+static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool with_bias, bool time_it) {
+  Packed W(N, K, gs, sym);
+  DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N), dense((size_t)N * K), bias((size_t)N);
+  {
+    std::vector<uint16_t> hx(x.n), hb(N);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    for (auto& v : hb) v = f2bf(rnd_normal());
+    x.upload(hx);
+    bias.upload(hb);
+  }
+  const int64_t wsb = inc_woq_gemm_workspace_bytes(M, N, K);
+  DevBuf<char> ws((size_t)(wsb > 0 ? wsb : 16));
+  ws.zero();
+  const void* bp = with_bias ? bias.p : nullptr;
+  INCCHECK(inc_woq_dequant(W.qweight.p, W.scales.p, W.qzeros.p, nullptr, dense.p, INC_BF16, N, K, W.G, gs, 4, nullptr));
+  const int check_rows = (int)(M < 96 ? M : 96);
+  std::vector<int> rows;
+  for (int r = 0; r < check_rows; ++r) rows.push_back((int)(((int64_t)r * 7919) % M));
+  rows[0] = 0;
+  rows[check_rows - 1] = (int)(M - 1);
+  DevBuf<int> drows(rows.size());
+  drows.upload(rows);
+  DevBuf<float> ref((size_t)check_rows * N);
+  ref_gemm_rows<<<dim3((unsigned)((N + 255) / 256), (unsigned)check_rows), 256>>>(x.p, dense.p, drows.p, check_rows, N, K, ref.p);
+  HIPCHECK(hipDeviceSynchronize());
+  std::vector<float> href = ref.download();
+  std::vector<uint16_t> hb = bias.download();
+  const int modes[3] = {0, 42, 40};
+  const char* labels[3] = {"strip (LDS-DMA rings)", "PC 256-row tile + split-K", "3A2B 256-row tile + split-K"};
+  int fails = 0;
+  std::vector<uint16_t> first;
+  for (int mi = 0; mi < 3; ++mi) {
+    inc_debug_set_small_tiles(modes[mi]);
+    y.zero();
+    for (int rep = 0; rep < 2; ++rep)  // twice: the arrival counters must have been re-armed
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<uint16_t> hy = y.download();
+    double num = 0, den = 0, maxabs = 0;
+    for (int r = 0; r < check_rows; ++r)
+      for (int64_t n = 0; n < N; ++n) {
+        const double b = href[(size_t)r * N + n] + (with_bias ? bf2f(hb[n]) : 0.f);
+        const double a = bf2f(hy[(size_t)rows[r] * N + n]);
+        num += (a - b) * (a - b);
+        den += b * b;
+        if (fabs(a - b) > maxabs) maxabs = fabs(a - b);
+      }
+    const double rel = sqrt(num / (den + 1e-30));
+    const bool ok = rel < 3e-3;
+    if (!ok) ++fails;
+    printf("STRIP M=%ld N=%ld K=%ld gs=%d %s%s [%s]: rel vs fp32 ref (%d rows)=%.2e maxabs=%.3g %s\n", (long)M, (long)N, (long)K, gs,
+           sym ? "sym" : "asym", with_bias ? "+bias" : "", labels[mi], check_rows, rel, maxabs, ok ? "OK" : "FAIL");
+  }
+  inc_debug_set_small_tiles(0);
+  if (time_it) {
+    Timer t;
+    const int rounds = 5, iters = 20;
+    std::vector<std::vector<float>> ms(3);
+    for (int i = 0; i < 10; ++i)
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+    for (int r = 0; r < rounds; ++r)
+      for (int vi = 0; vi < 3; ++vi) {
+        const int mi = (vi + r) % 3;
+        inc_debug_set_small_tiles(modes[mi]);
+        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+        t.start();
+        for (int i = 0; i < iters; ++i)
+          INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+        ms[mi].push_back(t.stop_ms() / iters);
+      }
+    const double flops = 2.0 * M * N * K;
+    for (int mi = 0; mi < 3; ++mi) {
+      std::sort(ms[mi].begin(), ms[mi].end());
+      const float med = ms[mi][ms[mi].size() / 2];
+      printf("  %-24s median %9.4f ms %8.1f TFLOP/s\n", labels[mi], med, flops / med / 1e9);
+    }
+    inc_debug_set_small_tiles(0);
+  }
+  return fails;
+}
+
 static int run_gemv_repeat(int64_t N, int64_t K, int M) {
   // the arrival counters must re-arm: 50 back-to-back calls on one workspace give bit-identical outputs
   Packed W(N, K, 128, true);
@@ -560,6 +642,18 @@ int main(int argc, char** argv) {
   HIPCHECK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s, %d CUs, %s, ABI %d\n", prop.name, prop.multiProcessorCount, prop.gcnArchName, inc_abi_version());
   int fails = 0;
+  if (what == "strip" || what == "all") {
+    fails += run_strip_case(65, 200, 96, 32, false, true, false);       // ragged everything, gs=32 asym, 3 steps
+    fails += run_strip_case(100, 1000, 416, 32, false, true, false);    // 13 steps over 4 waves (uneven), ragged N
+    fails += run_strip_case(130, 520, 2048, 2048, true, false, false);  // single group, split-K
+    fails += run_strip_case(128, 4096, 4096, 128, true, false, true);
+    fails += run_strip_case(256, 4096, 4096, 128, true, false, true);
+    fails += run_strip_case(512, 4096, 4096, 128, false, true, true);
+    fails += run_strip_case(1024, 4096, 4096, 128, true, false, true);
+    fails += run_strip_case(128, 11008, 4096, 128, true, false, true);
+    fails += run_strip_case(512, 11008, 4096, 128, true, false, true);
+    fails += run_strip_case(512, 4096, 11008, 128, true, false, true);
+  }
   if (what == "gemm" || what == "all") {
     fails += run_gemm_case(256, 256, 64, 32, false, true, false, 64);     // one tile, one K-step, gs=32 asym
     fails += run_gemm_case(300, 1000, 192, 64, false, true, false, 64);   // ragged M and N
@@ -613,6 +707,21 @@ int main(int argc, char** argv) {
     fails += run_colloop_case(4096, 4096, 128, 32, true);
     fails += run_colloop_case(11008, 4096, 128, 8, true);
     fails += run_colloop_case(4096, 11008, 128, 8, true);
+  }
+  if (what == "profstrip") {  // mid-M strip kernel alone, for rocprofv3 --pmc passes
+    const int64_t M = 512, N = 4096, K = 4096;
+    Packed W(N, K, 128, true);
+    DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
+    std::vector<uint16_t> hx(x.n);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    x.upload(hx);
+    const int64_t wsb = inc_woq_gemm_workspace_bytes(M, N, K);
+    DevBuf<char> ws((size_t)wsb);
+    ws.zero();
+    for (int i = 0; i < 5; ++i)
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, ws.p, wsb, nullptr));
+    HIPCHECK(hipDeviceSynchronize());
+    return 0;
   }
   if (what == "prof") {  // short, kernel-only workload for rocprofv3 --pmc passes (no reference kernels)
     {
