@@ -1635,7 +1635,7 @@ constexpr int64_t STRIP_MAX_M = 1024;
 constexpr int STRIP_WAVES = 8;                                          // waves per workgroup: eighths of the K range
 constexpr int STRIP_RING = 3;                                           // operand slots (K-steps in flight) per wave
 constexpr int STRIP_SMEM_BYTES = STRIP_WAVES * STRIP_RING * 6 * 1024;   // 144 KiB: the operand rings; the epilogue reuses them
-static_assert(STRIP_SMEM_BYTES >= STRIP_WAVES * 64 * 65 * 4, "the reduction buffer (8 x 64 x 65 fp32) aliases the rings");
+static_assert(STRIP_SMEM_BYTES >= STRIP_WAVES * 64 * 68 * 4, "the reduction buffer (8 x 64 x 68 fp32) aliases the rings");
 
 template <bool IS_BF16, int WAVES, int RING>
 __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
@@ -1685,11 +1685,17 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
   constexpr int SLOT = 6 * 1024;
   const uint32_t ring0 = (uint32_t)(uintptr_t)strip_smem + (uint32_t)wave * (RING * SLOT);
   uint32_t xoff[4], woff[2], soff[2], zoff[2];
+  // x fragments: FOUR ADJACENT LANES fetch the 64 contiguous bytes (32 k) of one row -- the memory pipeline coalesces adjacent
+  // lanes only; with the MFMA operand's own lane order (adjacent lanes = adjacent rows, 8 KiB apart) every lane is its own
+  // 16-byte request and the workgroup gets ~11 bytes per clock (measured).  Lane l lands at byte 16 l of the slot and carries row
+  // l >> 2, 16-byte chunk (l & 3) ^ (row >> 2): the XOR makes the pick-up below (lane (jn, oct) reads row jn, chunk oct)
+  // conflict-free.
+  const int xr = lane >> 2, xc = (lane & 3) ^ (xr >> 2);
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    int am = m0 + 16 * b + jn;
+    int am = m0 + 16 * b + xr;
     if (am > M - 1) am = M - 1;  // rows past M are computed from a valid row and never stored
-    xoff[b] = (uint32_t)(((int64_t)am * K + 8 * oct) * 2);
+    xoff[b] = (uint32_t)(((int64_t)am * K + 8 * xc) * 2);
   }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
@@ -1742,11 +1748,12 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(p.s[0]), "+v"(p.s[1]), "+v"(p.z[0]), "+v"(p.z[1]) : "i"(10 * (RING - 1)) : "memory");
   };
   auto fetch = [&](Step& t, int slot) {
-    const char* base = strip_smem + wave * (RING * SLOT) + slot * SLOT + lane * 16;
+    const char* base = strip_smem + wave * (RING * SLOT) + slot * SLOT;
+    const int apos = (4 * jn + (oct ^ (jn >> 2))) * 16;  // where row jn, chunk oct of an x fragment landed
 #pragma unroll
-    for (int b = 0; b < 4; ++b) t.a[b] = *reinterpret_cast<const uint4*>(base + b * 1024);
+    for (int b = 0; b < 4; ++b) t.a[b] = *reinterpret_cast<const uint4*>(base + b * 1024 + apos);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) t.w[nb] = *reinterpret_cast<const uint4*>(base + 4096 + nb * 1024);
+    for (int nb = 0; nb < 2; ++nb) t.w[nb] = *reinterpret_cast<const uint4*>(base + 4096 + nb * 1024 + lane * 16);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is free for the next DMA once these have returned
   };
 
@@ -1814,22 +1821,23 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
   // ---- the waves' accumulators meet in LDS, 64 rows x 64 columns per pass ---------------------------------------------
   // D of an MFMA: column = lane & 15 -> tile column 4*jn + c, row = 4*oct + r
   const int64_t slab = (int64_t)M * N;
+  constexpr int RP = 68;  // row pitch of the reduction buffer in floats
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     if (nb > 0) __syncthreads();  // the previous pass has been read
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave * 64 + 16 * b + 4 * oct + r) * 65 + 4 * jn + c] = acc[b][4 * nb + c][r];
+      for (int r = 0; r < 4; ++r)  // the lane's 4 adjacent columns of one row: one 16-byte store (row pitch 68 floats = 17 x 16 B)
+        *reinterpret_cast<float4*>(red + (wave * 64 + 16 * b + 4 * oct + r) * RP + 4 * jn) =
+            make_float4(acc[b][4 * nb + 0][r], acc[b][4 * nb + 1][r], acc[b][4 * nb + 2][r], acc[b][4 * nb + 3][r]);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 64 * 64 / NT; ++i) {
       const int idx = tid + NT * i, rr = idx >> 6, cc = idx & 63;
-      float v = red[rr * 65 + cc];
+      float v = red[rr * RP + cc];
 #pragma unroll
-      for (int wv = 1; wv < WAVES; ++wv) v += red[(wv * 64 + rr) * 65 + cc];  // fixed order
+      for (int wv = 1; wv < WAVES; ++wv) v += red[(wv * 64 + rr) * RP + cc];  // fixed order
       const int m = m0 + rr;
       const int64_t n = n0 + 64 * nb + cc;
       if (m < M && n < N) {
@@ -1999,9 +2007,11 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   // weight-only INT8 (BASELINE config #1's layers): the 3A2B kernel's 8-bit instantiation, same tiling and split-K plan
   const bool big8_ok = bits == 8 && (K % 128) == 0 && g_shift != -2 && M > 16 && N >= 64 && dbg == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 4) < (int64_t)1 << 31;
-  // 64 < M <= 1024: the strip kernel (no 256-row tiles, no slab passes); harness flags 42 / 40 / 4 / 6: the tile paths
+  // 64 < M <= 1024 with at most 64 tiles of 256 x 256: the strip kernel (no 256-row tiles, no slab passes).  With more tiles the
+  // producer / consumer kernel fills the chip with <= 2 slabs and wins (M = 512, N = 11008: 71 vs 81 us; tools/kbench strip).
+  // Harness flags 42 / 40 / 4 / 6 select the tile paths.
   const bool strip_ok = bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && M > GEMV_MAX_M && M <= STRIP_MAX_M &&
-                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && dbg == 0;
+                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && dbg == 0;
   if (strip_ok) {
     int splitk = strip_splitk(M, N, K);
     const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);

@@ -505,6 +505,10 @@ def _packed_layer(hip, N, K, gs, bits, sym, seed, bias=True):
 @pytest.mark.parametrize("M,N,K,gs,bits,sym", [
     (1, 512, 1024, 128, 4, True), (16, 320, 640, 64, 4, False), (7, 256, 512, 128, 8, False),
     (200, 384, 512, 128, 4, True), (512, 1000, 1576, 128, 4, False), (130, 256, 320, 32, 8, True),
+    # the mid-M strip kernel (64 < M <= 1024): ragged M and N with 3 K-steps for 8 waves, 13 uneven steps, one group + split-K,
+    # group size 64, and a 4-slice split-K shape
+    (65, 200, 96, 32, 4, False), (100, 1000, 416, 32, 4, False), (130, 520, 2048, 2048, 4, True), (257, 640, 1024, 64, 4, False),
+    (96, 2048, 2048, 128, 4, True),
 ])
 def test_fused_gemm_vs_oracle(hip, dtype, M, N, K, gs, bits, sym):
     m = _packed_layer(hip, N, K, gs, bits, sym, seed=M + N)
