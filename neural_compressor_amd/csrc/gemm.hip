@@ -1962,10 +1962,9 @@ int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     int steps;
     const int splits = M > 16 && N >= 64 ? big_splitk(M, N, K, &steps) : 1;
     big = splits > 1 ? WS_COUNTER_BYTES + (int64_t)splits * M * N * 4 : 0;  // slabs start AFTER the counter block
-    if (M > GEMV_MAX_M) {
-      const int64_t strip = M <= STRIP_MAX_M ? WS_COUNTER_BYTES + 4 * M * N * 4 : 0;  // the strip kernel: <= 4 K-slices
-      return strip > big ? strip : big;
-    }
+    const int64_t strip = M <= STRIP_MAX_M ? WS_COUNTER_BYTES + 4 * M * N * 4 : 0;  // the strip kernel: <= 4 K-slices
+    if (strip > big) big = strip;
+    if (M > GEMV_MAX_M) return big;
   }
   int64_t slices = ceil_div64(K, 32 * 4 * 4);  // the streaming kernel at 4 steps per wave
   if (slices < 64) slices = 64;  // the generic split-K path uses up to 64 slices
@@ -2009,9 +2008,10 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 4) < (int64_t)1 << 31;
   // 64 < M <= 1024 with at most 64 tiles of 256 x 256: the strip kernel (no 256-row tiles, no slab passes).  With more tiles the
   // producer / consumer kernel fills the chip with <= 2 slabs and wins (M = 512, N = 11008: 71 vs 81 us; tools/kbench strip).
-  // Harness flags 42 / 40 / 4 / 6 select the tile paths.
-  const bool strip_ok = bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && M > GEMV_MAX_M && M <= STRIP_MAX_M &&
-                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && dbg == 0;
+  // 32 < M <= 64 on the larger layers too (M = 64, 11008 x 4096: 21 vs 29 us for the streaming kernel, whose x fragments are
+  // per-lane 16-byte gathers; at 4096^2 the streaming kernel keeps a 1 us lead).  Harness flags 42 / 40 / 4 / 6 select the tile paths, 83 this kernel for any M > 16.
+  const bool strip_ok = bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
+                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || dbg == 83);
   if (strip_ok) {
     int splitk = strip_splitk(M, N, K);
     const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);

@@ -283,8 +283,8 @@ static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, boo
   HIPCHECK(hipDeviceSynchronize());
   std::vector<float> href = ref.download();
   std::vector<uint16_t> hb = bias.download();
-  const int modes[3] = {0, 42, 40};
-  const char* labels[3] = {"strip (LDS-DMA rings)", "PC 256-row tile + split-K", "3A2B 256-row tile + split-K"};
+  const int modes[3] = {M <= 64 ? 83 : 0, 42, M <= 64 ? 0 : 40};
+  const char* labels[3] = {"strip (LDS-DMA rings)", "PC 256-row tile + split-K", M <= 64 ? "streaming kernel (default)" : "3A2B 256-row tile + split-K"};
   int fails = 0;
   std::vector<uint16_t> first;
   for (int mi = 0; mi < 3; ++mi) {
@@ -646,6 +646,11 @@ int main(int argc, char** argv) {
     fails += run_strip_case(65, 200, 96, 32, false, true, false);       // ragged everything, gs=32 asym, 3 steps
     fails += run_strip_case(100, 1000, 416, 32, false, true, false);    // 13 steps over 4 waves (uneven), ragged N
     fails += run_strip_case(130, 520, 2048, 2048, true, false, false);  // single group, split-K
+    fails += run_strip_case(32, 4096, 4096, 128, true, false, true);
+    fails += run_strip_case(48, 4096, 4096, 128, true, false, true);
+    fails += run_strip_case(64, 4096, 4096, 128, true, false, true);
+    fails += run_strip_case(64, 11008, 4096, 128, true, false, true);
+    fails += run_strip_case(64, 4096, 11008, 128, true, false, true);
     fails += run_strip_case(128, 4096, 4096, 128, true, false, true);
     fails += run_strip_case(256, 4096, 4096, 128, true, false, true);
     fails += run_strip_case(512, 4096, 4096, 128, false, true, true);
