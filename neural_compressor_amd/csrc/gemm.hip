@@ -1910,6 +1910,83 @@ static int strip_splitk(int64_t M, int64_t N, int64_t K) {
   return sk;
 }
 
+// =============================================================================================
+// decode kernel without split-K (round 2): M <= 16, K <= GEMV16_MAX_K
+// =============================================================================================
+// The streaming kernel above splits K over workgroups to put 512+ of them on the chip, and pays for it after the last MFMA:
+// write-through partials, a drain, a ticket, and the last arriver's reload -- about 2 us of a 4.5 us kernel.  Here a workgroup
+// owns only 16 columns but ALL of K: sixteen waves take a sixteenth of the K-steps each, a lane's packed word (8 k of one
+// column) is the B operand of v_mfma_f32_16x16x32 once dequantised, and the sixteen accumulators meet in LDS -- one hop, inside
+// the workgroup.  N / 16 workgroups (256 at N = 4096), every byte of W requested before the first use.
+constexpr int GEMV16_WAVES = 16;
+constexpr int GEMV16_CH = 12;                                              // K-steps per wave and pass whose loads are issued up front
+constexpr int64_t GEMV16_MAX_K = (int64_t)32 * GEMV16_WAVES * 2 * GEMV16_CH;  // two passes: K <= 12288
+
+template <bool IS_BF16>
+__global__ __launch_bounds__(64 * GEMV16_WAVES) void woq_gemv16_w4_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
+    const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int M, int64_t N, int64_t K,
+    int64_t NW, int g_shift) {
+  constexpr int WAVES = GEMV16_WAVES, CH = GEMV16_CH;
+  __shared__ float red[WAVES * 16 * 17];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jn = lane & 15, kg = lane >> 4;
+  const float inv_u = fp8_unit_inverse();
+  const int64_t n0 = (int64_t)blockIdx.x * 16;
+  int64_t ncol = n0 + jn;
+  if (ncol > N - 1) ncol = N - 1;  // clamped lanes recompute a valid column; their results are not stored
+  const int zsh = 4 * (int)(ncol & 7);
+  const int am = jn < M ? jn : M - 1;  // A row (clamped; rows >= M only feed outputs that are never stored)
+  const uint16_t* const xrow = x + (int64_t)am * K + 8 * kg;
+  const uint32_t* const wcol = qweight + (int64_t)kg * N + ncol;
+  const int steps_total = (int)(K / 32);
+  const int lo = (int)((int64_t)steps_total * wave / WAVES), hi = (int)((int64_t)steps_total * (wave + 1) / WAVES);
+
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c0 = lo; c0 < hi; c0 += CH) {
+    uint32_t w[CH], zraw[CH];
+    uint16_t sraw[CH];
+    uint4 a[CH];
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      int st = c0 + s;
+      if (st > hi - 1) st = hi - 1;  // steps past the end re-read the last one and are skipped below
+      const int64_t g = g_shift >= 0 ? (((int64_t)st * 32) >> g_shift) : 0;
+      w[s] = wcol[(int64_t)st * 4 * N];
+      sraw[s] = scales[g * N + ncol];
+      zraw[s] = qzeros[g * NW + (ncol >> 3)];
+      a[s] = *reinterpret_cast<const uint4*>(xrow + (int64_t)st * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // everything above is in flight before the first use below
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      if (c0 + s < hi) {
+        const float sc = f16_bits_to_f32(sraw[s]);
+        uint32_t zz = ((zraw[s] >> zsh) & 15u) + 1u;  // modules.py:407-410 (stored zp - 1; wraps above 15)
+        zz = zz > 15u ? 0u : zz;
+        const uint4 bq = dequant8<IS_BF16>(w[s], sc * inv_u, -(float)zz * sc);
+        acc = mfma16<IS_BF16>(a[s], bq, acc);
+      }
+    }
+  }
+  // D of the MFMA: column = lane & 15 (= jn), row = 4 * kg + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * kg + r) * 17 + jn] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int m = tid >> 4, c = tid & 15;
+    float v = red[m * 17 + c];
+#pragma unroll
+    for (int wv = 1; wv < WAVES; ++wv) v += red[(wv * 16 + m) * 17 + c];  // fixed order
+    const int64_t n = n0 + c;
+    if (m < M && n < N) {
+      v += bias ? cvt16<IS_BF16>(bias[n]) : 0.f;
+      y[(int64_t)m * N + n] = IS_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+    }
+  }
+}
+
 // choose the number of K-slices for the small-M kernel: enough workgroups to cover the chip, each
 // slice a multiple of 4 waves x one MFMA K=32 step
 inline int small_slices(int64_t N, int64_t K, int bits, int* kw_per_slice_out) {
@@ -2200,6 +2277,13 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     if (bits == 4) { if (bf) INC_TILE(4, true); else INC_TILE(4, false); }
     else { if (bf) INC_TILE(8, true); else INC_TILE(8, false); }
 #undef INC_TILE
+  } else if (gemv_ok && M <= 16 && K <= GEMV16_MAX_K && (dbg == 85 || (dbg == 0 && M <= 4 && N <= 4096 && K <= 4096))) {
+    // decode without split-K: one workgroup of 16 waves per 16 columns, the whole of K.  Wins where its N / 16 workgroups are a
+    // single round on the chip and x is <= 4 rows (M = 1, 4096^2: 5.9 vs 6.8 us); elsewhere the streaming kernel's 64-column
+    // requests and K-slices use the HBM better (M = 1, 11008 x 4096: 8.5 vs 15.9 us; tools/kbench decode; harness flag 85 forces it)
+    const unsigned grid = (unsigned)ceil_div64(N, 16);
+    if (bf) woq_gemv16_w4_kernel<true><<<grid, 64 * GEMV16_WAVES, 0, s>>>(xp, qw, scales, qz, bp, yp, (int)M, N, K, NW, g_shift);
+    else woq_gemv16_w4_kernel<false><<<grid, 64 * GEMV16_WAVES, 0, s>>>(xp, qw, scales, qz, bp, yp, (int)M, N, K, NW, g_shift);
   } else if (gemv_ok && (M <= 16 || ceil_div64(K, 32 * 4 * 4) <= 64)) {
     // 8 steps per wave when that still gives every SIMD two waves (>= 512 workgroups), else 4; row-blocked (M > 16): always 4
     const bool vs4 = M > 16 || (ceil_div64(N, 64) * ceil_div64(K, 32 * 8 * 4) < 512 && ceil_div64(K, 32 * 4 * 4) <= 64);

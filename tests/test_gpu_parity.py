@@ -509,6 +509,8 @@ def _packed_layer(hip, N, K, gs, bits, sym, seed, bias=True):
     # group size 64, and a 4-slice split-K shape
     (65, 200, 96, 32, 4, False), (100, 1000, 416, 32, 4, False), (130, 520, 2048, 2048, 4, True), (257, 640, 1024, 64, 4, False),
     (96, 2048, 2048, 128, 4, True),
+    # decode without split-K (M <= 4, N and K <= 4096): ragged N, 13 K-steps over 16 waves; one group
+    (3, 1000, 416, 32, 4, False), (4, 200, 2048, 2048, 4, True), (2, 4096, 4096, 128, 4, True),
 ])
 def test_fused_gemm_vs_oracle(hip, dtype, M, N, K, gs, bits, sym):
     m = _packed_layer(hip, N, K, gs, bits, sym, seed=M + N)

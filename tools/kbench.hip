@@ -337,6 +337,83 @@ static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, boo
   return fails;
 }
 
+// ---- decode (M <= 16): streaming split-K kernel vs the no-split kernel, each checked against the fp32 reference ------------
+static int run_decode_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool with_bias, bool time_it) {
+  Packed W(N, K, gs, sym);
+  DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N), dense((size_t)N * K), bias((size_t)N);
+  {
+    std::vector<uint16_t> hx(x.n), hb(N);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    for (auto& v : hb) v = f2bf(rnd_normal());
+    x.upload(hx);
+    bias.upload(hb);
+  }
+  const int64_t wsb = inc_woq_gemm_workspace_bytes(M, N, K);
+  DevBuf<char> ws((size_t)(wsb > 0 ? wsb : 16));
+  ws.zero();
+  const void* bp = with_bias ? bias.p : nullptr;
+  INCCHECK(inc_woq_dequant(W.qweight.p, W.scales.p, W.qzeros.p, nullptr, dense.p, INC_BF16, N, K, W.G, gs, 4, nullptr));
+  const int check_rows = (int)M;
+  std::vector<int> rows;
+  for (int r = 0; r < check_rows; ++r) rows.push_back(r);
+  DevBuf<int> drows(rows.size());
+  drows.upload(rows);
+  DevBuf<float> ref((size_t)check_rows * N);
+  ref_gemm_rows<<<dim3((unsigned)((N + 255) / 256), (unsigned)check_rows), 256>>>(x.p, dense.p, drows.p, check_rows, N, K, ref.p);
+  HIPCHECK(hipDeviceSynchronize());
+  std::vector<float> href = ref.download();
+  std::vector<uint16_t> hb = bias.download();
+  const int modes[2] = {0, 85};
+  const char* labels[2] = {"default dispatch", "16 columns x whole K (no split-K)"};
+  int fails = 0;
+  for (int mi = 0; mi < 2; ++mi) {
+    inc_debug_set_small_tiles(modes[mi]);
+    y.zero();
+    INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<uint16_t> hy = y.download();
+    double num = 0, den = 0;
+    for (int r = 0; r < check_rows; ++r)
+      for (int64_t n = 0; n < N; ++n) {
+        const double b = href[(size_t)r * N + n] + (with_bias ? bf2f(hb[n]) : 0.f);
+        const double a = bf2f(hy[(size_t)r * N + n]);
+        num += (a - b) * (a - b);
+        den += b * b;
+      }
+    const double rel = sqrt(num / (den + 1e-30));
+    const bool ok = rel < 3e-3;
+    if (!ok) ++fails;
+    printf("DECODE M=%ld N=%ld K=%ld gs=%d %s%s [%s]: rel vs fp32 ref=%.2e %s\n", (long)M, (long)N, (long)K, gs, sym ? "sym" : "asym",
+           with_bias ? "+bias" : "", labels[mi], rel, ok ? "OK" : "FAIL");
+  }
+  inc_debug_set_small_tiles(0);
+  if (time_it) {
+    Timer t;
+    const int rounds = 5, iters = 200;
+    std::vector<std::vector<float>> ms(2);
+    for (int i = 0; i < 50; ++i)
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+    for (int r = 0; r < rounds; ++r)
+      for (int vi = 0; vi < 2; ++vi) {
+        const int mi = (vi + r) % 2;
+        inc_debug_set_small_tiles(modes[mi]);
+        INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+        t.start();
+        for (int i = 0; i < iters; ++i)
+          INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+        ms[mi].push_back(t.stop_ms() / iters);
+      }
+    const double bytes = (double)N * K / 2 + (double)W.G * N * 2 + (double)W.G * (N / 8) * 4 + (double)M * K * 2 + (double)M * N * 2;
+    for (int mi = 0; mi < 2; ++mi) {
+      std::sort(ms[mi].begin(), ms[mi].end());
+      const float med = ms[mi][ms[mi].size() / 2];
+      printf("  %-36s median %8.2f us %8.1f GB/s\n", labels[mi], med * 1e3, bytes / med / 1e6);
+    }
+    inc_debug_set_small_tiles(0);
+  }
+  return fails;
+}
+
 static int run_gemv_repeat(int64_t N, int64_t K, int M) {
   // the arrival counters must re-arm: 50 back-to-back calls on one workspace give bit-identical outputs
   Packed W(N, K, 128, true);
@@ -677,6 +754,18 @@ int main(int argc, char** argv) {
     fails += run_gemm_case(33, 1000, 416, 32, false, true, false, 33);   // streaming kernel, 3 row blocks used of 4, ragged N, gs=32
     fails += run_gemm_case(48, 4096, 4096, 128, false, true, true, 48);
     fails += run_gemm_case(256, 4096, 4096, 128, true, false, true, 64);
+  }
+  if (what == "decode" || what == "all") {
+    fails += run_decode_case(3, 1000, 416, 32, false, true, false);   // ragged N, 13 K-steps over 16 waves, gs=32 asym
+    fails += run_decode_case(16, 200, 2048, 2048, true, true, false);  // one group
+    fails += run_decode_case(1, 4096, 4096, 128, true, false, true);
+    fails += run_decode_case(4, 4096, 4096, 128, true, false, true);
+    fails += run_decode_case(16, 4096, 4096, 128, false, true, true);
+    fails += run_decode_case(1, 11008, 4096, 128, true, false, true);
+    fails += run_decode_case(1, 4096, 11008, 128, true, false, true);
+    fails += run_decode_case(8, 4096, 11008, 128, true, true, true);
+    fails += run_decode_case(1, 8192, 8192, 128, true, false, true);
+    fails += run_decode_case(1, 5120, 5120, 128, true, false, true);
   }
   if (what == "gemv" || what == "all") {
     fails += run_gemm_case(1, 4096, 4096, 128, true, false, true, 1);
