@@ -56,14 +56,18 @@ __global__ __launch_bounds__(256) void chol_diag_block_kernel(float* __restrict_
   for (int kb = 0; kb < CB / 8; ++kb) {
     // (a) the owner of diagonal tile kb factors it (8x8 Cholesky in registers) and inverts the factor
     if (ti == kb && tj == kb) {
+      // one division per pivot (its reciprocal); the 28 column scalings and the 36 rows of the inverse multiply by it -- this
+      // thread is the serial part of every panel step, and an fp32 division is a ~10-instruction dependent sequence
+      float rd[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float p = a[k][k];
         if (!(p > 0.f)) bad = true;
         const float d = sqrtf(p);
         a[k][k] = d;
+        rd[k] = 1.0f / d;
 #pragma unroll
-        for (int i = k + 1; i < 8; ++i) a[i][k] = a[i][k] / d;
+        for (int i = k + 1; i < 8; ++i) a[i][k] = a[i][k] * rd[k];
 #pragma unroll
         for (int j = k + 1; j < 8; ++j)
 #pragma unroll
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void chol_diag_block_kernel(float* __restrict_
           float sum = (i == c) ? 1.f : 0.f;
 #pragma unroll
           for (int k = c; k < i; ++k) sum = fmaf(-a[i][k], iv[k][c], sum);
-          iv[i][c] = sum / a[i][i];
+          iv[i][c] = sum * rd[i];
         }
 #pragma unroll
       for (int i = 0; i < 8; ++i)

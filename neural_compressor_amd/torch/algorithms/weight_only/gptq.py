@@ -86,6 +86,7 @@ def find_layers(module, layers=SUPPORTED_LAYERS, name=""):
 # Hinv = cholesky(cholesky_inverse(cholesky(H)), upper=True)  (reference gptq.py:1228-1230), restructured
 # ---------------------------------------------------------------------------------------------------
 CHOL_NB = 128
+CHOL_OUTER = int(os.environ.get("INC_MI355X_CHOL_OUTER", "1024"))  # outer block of the two-level factorisation (columns)
 _EXACT_TRIO = os.environ.get("INC_MI355X_CHOLESKY_TRIO", "0") == "1"
 
 
@@ -100,7 +101,8 @@ def inverse_cholesky_upper(H, check=True):
     So ONE blocked Cholesky and ONE blocked triangular inverse replace the trio (half the flops, one rounding pass
     instead of three):
       * diagonal blocks (128x128): inc_chol_diag_block factors the block AND inverts its factor in one workgroup;
-      * panel solve  L[i>j, j] = A[i>j, j] @ inv(L_jj)^T  and trailing update  A[i>j, i>j] -= L_panel L_panel^T: fp32 GEMMs;
+      * panel solve  L[i>j, j] = A[i>j, j] @ inv(L_jj)^T  and trailing update  A[i>j, i>j] -= L_panel L_panel^T: fp32 GEMMs,
+        two-level (128 inside an outer block of CHOL_OUTER columns, one deep update per outer block, lower triangle only);
       * Lr^-1 by recursive doubling: inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]], all pairs of a level independent.
     The GEMMs are the fp32 library GEMMs torch dispatches to (plumbing, like torch.linalg was before); a non-positive
     pivot raises like torch.linalg.cholesky does.  `check=False` returns (U, info) without reading `info` back (no
@@ -119,28 +121,53 @@ def inverse_cholesky_upper(H, check=True):
         A.diagonal()[K:] = 1.0
     X = torch.zeros((Kp, Kp), dtype=torch.float32, device=dev)
     info = torch.zeros(1, dtype=torch.int32, device=dev)
-    nblk = Kp // nb
-    for b in range(nblk):
-        j = b * nb
-        ops.chol_diag_block(A[j:j + nb, j:j + nb], X[j:j + nb, j:j + nb], info, b + 1)
-        if b + 1 < nblk:
-            panel = A[j + nb:, j:j + nb]                      # [M, nb] strided view
-            lp = torch.mm(panel, X[j:j + nb, j:j + nb].t())   # L_panel = A_panel @ inv(L_jj)^T
+
+    def invert_by_doubling(segs):
+        # Lr^-1 of the span covered by `segs` = [(start, size), ...], whose diagonal blocks of X already hold the inverses
+        while len(segs) > 1:
+            nxt = []
+            for p in range(0, len(segs) - 1, 2):
+                (s1, n1), (s2, n2) = segs[p], segs[p + 1]
+                C = A[s2:s2 + n2, s1:s1 + n1]
+                T = torch.mm(C, X[s1:s1 + n1, s1:s1 + n1])
+                X[s2:s2 + n2, s1:s1 + n1] = -torch.mm(X[s2:s2 + n2, s2:s2 + n2], T)
+                nxt.append((s1, n1 + n2))
+            if len(segs) % 2:
+                nxt.append(segs[-1])
+            segs = nxt
+        return segs[0]
+
+    # Two-level blocking (only the LOWER triangle of A is read or kept up to date): an outer block of CHOL_OUTER columns is
+    # factored with 128-wide steps confined to its own diagonal block, its factor is inverted by doubling, and then ONE panel
+    # solve and ONE trailing update of depth CHOL_OUTER serve the rest of the matrix -- 11 deep GEMMs at K = 11008 instead of 86
+    # rank-128 updates of the whole trailing matrix (which ran at a third of the library's fp32 GEMM rate and made the K = 11008
+    # factorisation the critical path of a block: 46 ms, profiles/r2d).
+    outer = max(nb, (CHOL_OUTER // nb) * nb)
+    tag = 0
+    top = []
+    for B in range(0, Kp, outer):
+        n2 = min(outer, Kp - B)
+        D = A[B:B + n2, B:B + n2]
+        XD = X[B:B + n2, B:B + n2]
+        for j in range(0, n2, nb):
+            tag += 1
+            ops.chol_diag_block(D[j:j + nb, j:j + nb], XD[j:j + nb, j:j + nb], info, tag)
+            if j + nb < n2:
+                panel = D[j + nb:, j:j + nb]                       # [m, nb] strided view
+                lp = torch.mm(panel, XD[j:j + nb, j:j + nb].t())   # L_panel = A_panel @ inv(L_jj)^T
+                panel.copy_(lp)
+                D[j + nb:, j + nb:].addmm_(lp, lp.t(), alpha=-1.0)
+        top.append(invert_by_doubling([(B + j, nb) for j in range(0, n2, nb)]))
+        if B + n2 < Kp:
+            panel = A[B + n2:, B:B + n2]                            # [M, n2]
+            lp = torch.mm(panel, XD.t())                            # L_panel = A_panel @ inv(L_DD)^T
             panel.copy_(lp)
-            A[j + nb:, j + nb:].addmm_(lp, lp.t(), alpha=-1.0)  # symmetric trailing update (both triangles kept valid)
-    # Lr^-1 by doubling: segments (start, size) whose diagonal blocks of X already hold the inverse
-    segs = [(b * nb, nb) for b in range(nblk)]
-    while len(segs) > 1:
-        nxt = []
-        for p in range(0, len(segs) - 1, 2):
-            (s1, n1), (s2, n2) = segs[p], segs[p + 1]
-            C = A[s2:s2 + n2, s1:s1 + n1]
-            T = torch.mm(C, X[s1:s1 + n1, s1:s1 + n1])
-            X[s2:s2 + n2, s1:s1 + n1] = -torch.mm(X[s2:s2 + n2, s2:s2 + n2], T)
-            nxt.append((s1, n1 + n2))
-        if len(segs) % 2:
-            nxt.append(segs[-1])
-        segs = nxt
+            M = Kp - (B + n2)
+            chunk = max(outer, -(-M // 4 // nb) * nb)                # lower triangle only: <= 4 column chunks, each from its diagonal down
+            for c0 in range(0, M, chunk):
+                c1 = min(c0 + chunk, M)
+                A[B + n2 + c0:, B + n2 + c0:B + n2 + c1].addmm_(lp[c0:], lp[c0:c1].t(), alpha=-1.0)
+    invert_by_doubling(top)
     U = torch.flip(X[:K, :K], (0, 1)).contiguous()
     if not check:
         return U, info

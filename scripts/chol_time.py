@@ -1,0 +1,39 @@
+"""Time inverse_cholesky_upper (GPTQ's Hinv factor) alone on the GPU for several outer block sizes.
+usage: python scripts/chol_time.py [K ...]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import neural_compressor_amd.torch.algorithms.weight_only.gptq as G  # noqa: E402
+
+
+def main():
+    Ks = [int(a) for a in sys.argv[1:]] or [4096, 11008]
+    dev = torch.device("cuda")
+    for K in Ks:
+        torch.manual_seed(K)
+        X = torch.randn(4 * K if K <= 4096 else 2 * K, K, device=dev)
+        H = (X.t() @ X) / X.shape[0]
+        H.diagonal().add_(0.01 * H.diagonal().mean())
+        ref = None
+        for outer in (128, 512, 1024, 2048, 4096):
+            G.CHOL_OUTER = outer
+            U = G.inverse_cholesky_upper(H)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                U = G.inverse_cholesky_upper(H, check=False)[0]
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            if ref is None:
+                ref = U
+            # residual of the definition: U H U^T = I
+            R = U @ H @ U.t()
+            res = float((R - torch.eye(K, device=dev)).norm() / K ** 0.5)
+            print(f"K={K} outer={outer}: {ms:8.2f} ms  |U H U^T - I|_F/sqrt(K)={res:.2e}  rel diff to outer=128: {float((U - ref).norm() / ref.norm()):.2e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
