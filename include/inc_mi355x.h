@@ -228,6 +228,14 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
 int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t N, int64_t K,
                          int64_t i1, int count, inc_stream_t stream);
 
+/* == the same update (gptq.py:1304) for the columns [col_begin, col_end) only; col_begin - (i1 + count) a multiple
+ *   of 128, col_end == K or a multiple of 128 columns past col_begin.  Lets the caller apply the next block's 128
+ *   columns first and the remainder on a second stream while the next block's column loop runs; W is bit-identical
+ *   to the one-call form.  INC_ERR_UNSUPPORTED when count != 128 (callers then use inc_gptq_lazy_update).       */
+int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int64_t N, int64_t K,
+                              int64_t i1, int count, int64_t col_begin, int64_t col_end,
+                              inc_stream_t stream);
+
 /* ---- K6': diagonal block of the blocked inverse-Cholesky factor -------------------------------- *
  * The reference builds Hinv = cholesky(cholesky_inverse(cholesky(H)), upper) (gptq.py:1228-1230) with
  * three LAPACK factorisations.  Here U = J Lr^-1 J with J H J = Lr Lr^T (see gptq.py: inverse_cholesky_upper):

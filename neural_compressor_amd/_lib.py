@@ -65,6 +65,7 @@ SIGNATURES = {
         [_P, _P, _P, _P, _P, _P, c_int, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P],
     ),
     "inc_gptq_lazy_update": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P]),
+    "inc_gptq_lazy_update_cols": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int64, c_int64, _P]),
     "inc_chol_diag_block": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, c_int, _P]),
     "inc_awq_act_abs_sum": (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),
     "inc_awq_weight_scale_workspace_bytes": (c_int64, [c_int64, c_int64, c_int]),

@@ -1322,4 +1322,29 @@ int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t 
   INC_LAUNCH_RETURN();
 }
 
+// The same update restricted to the columns [col_begin, col_end) of the trailing matrix, col_begin on the 128-column tile grid
+// that starts at i2: the tiles, and therefore every sum, are those of the one-launch form (bit-identical W).
+int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int64_t N, int64_t K, int64_t i1, int count,
+                              int64_t col_begin, int64_t col_end, inc_stream_t stream) {
+  INC_CHECK_ARG(w && Hinv && err && N > 0 && K > 0 && i1 >= 0 && count > 0 && count <= QB);
+  const int64_t i2 = i1 + count;
+  INC_CHECK_ARG(col_begin >= i2 && col_end <= K && col_begin <= col_end && ((col_begin - i2) % L2T) == 0 &&
+                (col_end == K || ((col_end - col_begin) % L2T) == 0));
+  if (col_begin == col_end) return INC_OK;
+  if (!(count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32))) return INC_ERR_UNSUPPORTED;
+  const int ncol_tiles = (int)ceil_div64(col_end - col_begin, L2T);
+  const int row_tiles = (int)ceil_div64(N, L2T);
+  int nchunks = (int)ceil_div64(512, row_tiles);
+  if (nchunks > ncol_tiles) nchunks = ncol_tiles;
+  const size_t smem2 = (size_t)2 * L2T * L2T * 4;  // 128 KiB
+  static std::atomic<uint64_t> attr2_set{0};
+  if (inc_attr_needed(attr2_set)) {
+    (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+    inc_attr_done(attr2_set);
+  }
+  gptq_lazy_update_v2_kernel<true><<<dim3((unsigned)nchunks, (unsigned)row_tiles), 256, smem2, inc_s(stream)>>>(
+      w, Hinv, err, N, K, i1, col_begin, nchunks, ncol_tiles);
+  INC_LAUNCH_RETURN();
+}
+
 }  // extern "C"

@@ -443,6 +443,19 @@ def gptq_lazy_update(w32, hinv, err, i1, count):
         check(lib.inc_gptq_lazy_update(_ptr(w32), _ptr(hinv), _ptr(err), N, K, i1, count, _stream()), "inc_gptq_lazy_update")
 
 
+def gptq_lazy_update_cols(w32, hinv, err, i1, count, col_begin, col_end):
+    """`gptq_lazy_update` for the trailing columns [col_begin, col_end) only (see include/inc_mi355x.h); launches on the
+    CURRENT stream.  Returns False when the library has no column-range form for this block shape."""
+    dev = _dev(w32, hinv, err)
+    N, K = w32.shape
+    with torch.cuda.device(dev):
+        rc = lib.inc_gptq_lazy_update_cols(_ptr(w32), _ptr(hinv), _ptr(err), N, K, i1, count, col_begin, col_end, _stream())
+    if rc == -2:  # INC_ERR_UNSUPPORTED
+        return False
+    check(rc, "inc_gptq_lazy_update_cols")
+    return True
+
+
 def chol_diag_block(A_view, Linv_view, info, tag):
     """In-place Cholesky of one <=128x128 diagonal block (a strided view into a larger fp32 matrix) + inverse of its
     factor into `Linv_view` (also a strided view).  See include/inc_mi355x.h: inc_chol_diag_block."""

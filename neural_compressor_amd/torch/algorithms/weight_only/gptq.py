@@ -86,6 +86,19 @@ def find_layers(module, layers=SUPPORTED_LAYERS, name=""):
 # Hinv = cholesky(cholesky_inverse(cholesky(H)), upper=True)  (reference gptq.py:1228-1230), restructured
 # ---------------------------------------------------------------------------------------------------
 CHOL_NB = 128
+LOOKAHEAD = os.environ.get("INC_MI355X_GPTQ_LOOKAHEAD", "1") == "1"
+_LOOKAHEAD_STREAMS = {}
+
+
+def _lookahead_stream(device):
+    """Second stream of the column loop (one per device, created on first use)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _LOOKAHEAD_STREAMS.get(key)
+    if st is None:
+        st = _LOOKAHEAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 CHOL_OUTER = int(os.environ.get("INC_MI355X_CHOL_OUTER", "1024"))  # outer block of the two-level factorisation (columns)
 _EXACT_TRIO = os.environ.get("INC_MI355X_CHOLESKY_TRIO", "0") == "1"
 
@@ -497,6 +510,18 @@ class GPTQ:
             kernel_gs = 1
         blocksize = int(blocksize) if blocksize and blocksize > 0 else K
         i1 = 0 if N > 0 else K
+        # Look-ahead (INC_MI355X_GPTQ_LOOKAHEAD=0 disables): the 128-step quantisation chain of block b+1 only needs the NEXT 128
+        # columns of block b's lazy update; the rest of that update (the bulk of the trailing matrix) runs on a second stream
+        # underneath it.  Every column still receives its updates in block order (rest(b-1) is awaited before next(b)), from
+        # the same 128-column tiles: W, the codes and Q are bit-identical to the one-stream loop.
+        lookahead = (LOOKAHEAD and N > 0 and K % QBLOCK == 0 and blocksize % QBLOCK == 0 and K >= 3 * QBLOCK and W.is_cuda)
+        if lookahead:
+            main = torch.cuda.current_stream(W.device)
+            side = _lookahead_stream(W.device)
+            errs = (err, torch.empty_like(err))
+            side.wait_stream(main)  # w32 / Hinv / scales were produced on the main stream
+            rest_done = None
+            blk = 0
         while i1 < K:
             ref_end = min((i1 // blocksize + 1) * blocksize, K)  # end of the reference's block (gptq.py:1250)
             count = min(QBLOCK, ref_end - i1)
@@ -506,9 +531,32 @@ class GPTQ:
                 g_last = (ref_end - 1) // gs
                 if g_last >= g_first:
                     ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first, mse=mse)
-            ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, err, i1, count, kernel_gs, bits)
-            ops.gptq_lazy_update(w32, Hinv, err, i1, count)
+            if not lookahead:
+                ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, err, i1, count, kernel_gs, bits)
+                ops.gptq_lazy_update(w32, Hinv, err, i1, count)
+                i1 += count
+                continue
+            e = errs[blk & 1]
+            ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, e, i1, count, kernel_gs, bits)
+            i2 = i1 + count
+            if i2 < K:
+                if rest_done is not None:
+                    main.wait_event(rest_done)  # rest(b-1) wrote the columns next(b) is about to update (and read Err of b-1)
+                nxt_end = min(i2 + QBLOCK, K)
+                if not ops.gptq_lazy_update_cols(w32, Hinv, e, i1, count, i2, nxt_end):
+                    raise RuntimeError("inc_gptq_lazy_update_cols refused a full 128-column block")
+                if nxt_end < K:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        ops.gptq_lazy_update_cols(w32, Hinv, e, i1, count, nxt_end, K)
+                        rest_done = torch.cuda.Event()
+                        rest_done.record(side)
             i1 += count
+            blk += 1
+        if lookahead:
+            main.wait_stream(side)  # w32 and both Err buffers are free again
         logger.debug("fasterquant %dx%d issued in %.3fs", N, K, time.time() - tick)
 
         if ctx is not None:
@@ -997,6 +1045,7 @@ class RAWGPTQuantizer(object):
             if self.dist_ctx is None and len(distinct) > 1 and self.factor_streams > 1:
                 # the independent factorisations of the block run concurrently, the largest first (it is the critical path)
                 if len(self._fstreams) < self.factor_streams:
+                    # (default priority: high-priority HIP streams made the whole step 20 % SLOWER, 346 -> 424 ms)
                     self._fstreams = [torch.cuda.Stream(device=self.device) for _ in range(self.factor_streams)]
                 order = sorted(range(len(distinct)), key=lambda i: -distinct[i][0].columns)
                 for slot, i in enumerate(order):
