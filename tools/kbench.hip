@@ -169,15 +169,21 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
   std::vector<uint16_t> hy = y.download(), hyo = y_old.download();
   int sched_mismatch = 0;
   if (M > 64) {  // (M <= 64 takes the streaming kernel: another summation order)
-    const int alts[3] = {40, 4, 6};  // 3A2B pinned / compiler-ordered / ping-pong vs the default (producer-consumer kernel)
+    // reference for the bitwise check: the producer / consumer tile kernel (flag 42; the DEFAULT route of a mid-M shape is the strip
+    // kernel, which sums in another order)
+    inc_debug_set_small_tiles(42);
+    INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y_old.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+    HIPCHECK(hipDeviceSynchronize());
+    const std::vector<uint16_t> hpc = y_old.download();
+    const int alts[3] = {40, 4, 6};  // 3A2B pinned / compiler-ordered / ping-pong vs the producer-consumer kernel
     for (int a = 0; a < 3; ++a) {
       inc_debug_set_small_tiles(alts[a]);
       INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y_old.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
       HIPCHECK(hipDeviceSynchronize());
       std::vector<uint16_t> ha = y_old.download();
-      if (memcmp(ha.data(), hy.data(), hy.size() * 2) != 0) {
+      if (memcmp(ha.data(), hpc.data(), hpc.size() * 2) != 0) {
         ++sched_mismatch;
-        printf("  schedule flag %d: output differs from the default schedule\n", alts[a]);
+        printf("  schedule flag %d: output differs from the producer / consumer kernel\n", alts[a]);
       }
     }
     inc_debug_set_small_tiles(0);
@@ -935,6 +941,46 @@ int main(int argc, char** argv) {
       printf("PCABLATE %-32s median %8.4f ms  (%7.1f TFLOP/s equivalent)  best %8.4f\n", labels[mi], med, 2.0 * M * N * K / med / 1e9, ms[mi][0]);
     }
     inc_debug_set_small_tiles(0);
+  }
+  if (what == "pcfma") {  // producer / consumer kernel: v_pk_fma_f32 vs scalar v_fma_f32 in the dequantisation (same outputs required)
+    const int64_t shapes[3][3] = {{4096, 4096, 4096}, {4096, 11008, 4096}, {4096, 4096, 11008}};
+    for (int si = 0; si < 3; ++si) {
+      const int64_t M = shapes[si][0], N = shapes[si][1], K = shapes[si][2];
+      Packed W(N, K, 128, true);
+      DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N), y2((size_t)M * N);
+      std::vector<uint16_t> hx(x.n);
+      for (auto& v : hx) v = f2bf(rnd_normal());
+      x.upload(hx);
+      inc_debug_set_small_tiles(0);
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+      inc_debug_set_small_tiles(73);
+      INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y2.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+      HIPCHECK(hipDeviceSynchronize());
+      std::vector<uint16_t> h1 = y.download(), h2 = y2.download();
+      const bool same = memcmp(h1.data(), h2.data(), h1.size() * 2) == 0;
+      if (!same) ++fails;
+      const int modes[3] = {0, 73, 74};
+      const char* labels[3] = {"v_fma_f32 x 8 (default)", "v_pk_fma_f32 x 4", "v_cvt_f32_fp8 x 8 + v_fma x 8"};
+      std::vector<std::vector<float>> ms(3);
+      Timer t;
+      for (int r = 0; r < 7; ++r)
+        for (int vi = 0; vi < 3; ++vi) {
+          const int mi = (vi + r) % 3;
+          inc_debug_set_small_tiles(modes[mi]);
+          INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+          t.start();
+          for (int i = 0; i < 8; ++i)
+            INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+          ms[mi].push_back(t.stop_ms() / 8);
+        }
+      printf("PCFMA M=%ld N=%ld K=%ld outputs %s\n", (long)M, (long)N, (long)K, same ? "bit-identical" : "DIFFER (FAIL)");
+      for (int mi = 0; mi < 3; ++mi) {
+        std::sort(ms[mi].begin(), ms[mi].end());
+        const float med = ms[mi][ms[mi].size() / 2];
+        printf("  %-30s median %8.4f ms %8.1f TFLOP/s\n", labels[mi], med, 2.0 * M * N * K / med / 1e9);
+      }
+      inc_debug_set_small_tiles(0);
+    }
   }
   if (what == "probe") run_probe();
   printf("kbench: %d failing case(s)\n", fails);
