@@ -47,12 +47,16 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # INC_MI355X_DIST_BACKEND=gloo: the collectives' host-staged test form (CalibrationGroup) -- lets the N-rank driver
+            # be exercised by N processes that share one GPU (RCCL refuses two ranks on one device)
+            backend = os.environ.get("INC_MI355X_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+    if torch.cuda.is_available() and local_rank >= torch.cuda.device_count():
+        local_rank %= torch.cuda.device_count()  # more ranks than GPUs (tests only): share devices round-robin
     return rank, world, local_rank
 
 
@@ -203,6 +207,8 @@ def barrier_max_time(seconds, device=None):
     """max over ranks of a local wall-clock measurement (bench.py contract)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([seconds], dtype=torch.float64, device=device or ("cuda" if torch.cuda.is_available() else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
