@@ -213,32 +213,54 @@ def bench_w8a8_gemm(device, shapes, iters=20):
 
 
 def _cpu_baseline_worker(threads):
-    """Runs in a child process: times the oracle (CPU restatement of the reference) on a bounded sample."""
+    """Runs in a child process: times the oracle (CPU restatement of the reference) on a bounded sample of the workload:
+    every distinct kernel shape of one transformer block ONCE (nothing is scaled between shapes)."""
     from oracle import woq_oracle as O
 
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
-    K = 4096
-    x = torch.randn(1, 2048, K, generator=g)
-    H, n = torch.zeros(K, K), 0
-    H, n = O.gptq_add_batch(H, n, x)  # untimed warm-up (thread pool, page faults)
-    t0 = time.time()
-    reps = 3
-    for _ in range(reps):
-        H, n = O.gptq_add_batch(H, n, x)
-    t_add = (time.time() - t0) / reps
-    W = torch.randn(4096, K, generator=g) * 0.02
-    t0 = time.time()
-    O.gptq_fasterquant(W, H, bits=4, sym=True, blocksize=128, percdamp=0.01, groupsize=128)
-    t_fq = time.time() - t0
-    print(json.dumps(dict(t_add=t_add, t_fq=t_fq)), flush=True)
+    out = {}
+    hess = {}
+    for K in (4096, 11008):
+        x = torch.randn(1, 2048, K, generator=g)
+        H, n = torch.zeros(K, K), 0
+        H, n = O.gptq_add_batch(H, n, x)  # untimed warm-up (thread pool, page faults)
+        reps = 3 if K == 4096 else 2
+        t0 = time.time()
+        for _ in range(reps):
+            H, n = O.gptq_add_batch(H, n, x)
+        out[f"t_add_{K}"] = (time.time() - t0) / reps
+        hess[K] = H
+    for N, K in ((4096, 4096), (11008, 4096), (4096, 11008)):
+        W = torch.randn(N, K, generator=g) * 0.02
+        t0 = time.time()
+        O.gptq_fasterquant(W, hess[K], bits=4, sym=True, blocksize=128, percdamp=0.01, groupsize=128)
+        out[f"t_fq_{N}x{K}"] = time.time() - t0
+    # one fp32 block forward of one 2048-token sample (the reference runs the float block twice per sample, gptq.py:660-760)
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaDecoderLayer, LlamaRotaryEmbedding
+
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=32,
+                      vocab_size=32000, max_position_embeddings=4096)
+    layer = LlamaDecoderLayer(cfg, 0).float().eval()
+    rot = LlamaRotaryEmbedding(config=cfg)
+    h = torch.randn(1, 2048, 4096, generator=g) * 0.1
+    pos = torch.arange(2048).unsqueeze(0)
+    with torch.no_grad():
+        pe = rot(h, pos)
+        layer(h, position_embeddings=pe, position_ids=pos)  # warm-up
+        t0 = time.time()
+        layer(h, position_embeddings=pe, position_ids=pos)
+        out["t_fwd"] = time.time() - t0
+    print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(timeout_s=240):
-    """The oracle (a restatement of the reference's CPU arithmetic) timed on this host's cores: a bounded sample of the
-    same workload (one [1,2048,4096] add_batch, one 4096x4096 fasterquant), extrapolated to the 32-block job (the full
-    CPU run is ~8 h).  Runs in a child process under a hard timeout so that a host with an
-    unusual CPU quota can never stall the bench line."""
+def cpu_baseline(timeout_s=420):
+    """The oracle (a restatement of the reference's CPU arithmetic) timed on this host's cores on a bounded sample of the same
+    workload -- one call of every distinct shape of a Llama-2-7B block: add_batch [1,2048,4096] and [1,2048,11008], fasterquant
+    4096x4096, 11008x4096 and 4096x11008, one fp32 block forward of one sample -- multiplied out to the 32-block job (the full
+    CPU run is ~2 h).  Runs in a child process under a hard timeout so that a host with an unusual CPU
+    quota can never stall the bench line."""
     import subprocess
 
     try:
@@ -254,19 +276,20 @@ def cpu_baseline(timeout_s=240):
         m = json.loads(line)
     except Exception as e:  # timeout / crash: report it, never fake a number
         return dict(value=None, unit="s", cores=threads, kind="port", sample=f"CPU baseline failed or timed out after {timeout_s}s: {type(e).__name__}")
-    t_add, t_fq = m["t_add"], m["t_fq"]
-    # per block as the reference does it (7 separate Hessians, gptq.py:670-688): 6 inputs of K=4096, 1 of K=11008
-    r = (11008 / 4096) ** 2
-    hess = 128 * (6 * t_add + r * t_add)
-    # fasterquant cost ~ serial columns (K) x row work (N) + Cholesky (K^3): scale the 4096x4096 measurement
-    solve = 4 * t_fq + 2 * t_fq * (11008 / 4096) + t_fq * (11008 / 4096) ** 2
-    per_block = hess + solve
+    # per block as the reference does it (7 separate Hessians, gptq.py:670-688: 6 inputs of K=4096, 1 of K=11008; 7 solves;
+    # the block forward twice per sample): counts only, every term measured
+    hess = 128 * (6 * m["t_add_4096"] + m["t_add_11008"])
+    solve = 4 * m["t_fq_4096x4096"] + 2 * m["t_fq_11008x4096"] + m["t_fq_4096x11008"]
+    fwd = 2 * 128 * m["t_fwd"]
+    per_block = hess + solve + fwd
     return dict(
         value=round(32 * per_block, 1), unit="s", cores=threads, kind="port",
-        sample=(f"oracle (CPU restatement of the reference) on this host, {threads} threads: GPTQ.add_batch [1,2048,4096] fp32 = "
-                f"{t_add:.3f} s, GPTQ.fasterquant 4096x4096 g128 = {t_fq:.2f} s; extrapolated to 32 blocks x (128 samples x 7 "
-                f"Hessians + 7 solves), block forwards excluded"),
-        add_batch_s=round(t_add, 4), fasterquant_s=round(t_fq, 3),
+        sample=(f"oracle (CPU restatement of the reference) on this host, {threads} threads, one call per distinct shape: GPTQ.add_batch "
+                f"[1,2048,4096] = {m['t_add_4096']:.3f} s, [1,2048,11008] = {m['t_add_11008']:.3f} s; GPTQ.fasterquant g128 4096x4096 = "
+                f"{m['t_fq_4096x4096']:.2f} s, 11008x4096 = {m['t_fq_11008x4096']:.2f} s, 4096x11008 = {m['t_fq_4096x11008']:.2f} s; fp32 block "
+                f"forward of one 2048-token sample = {m['t_fwd']:.2f} s; x (128 samples x 7 Hessians + 7 solves + 2 x 128 forwards) x 32 blocks"),
+        per_block_s=dict(hessians=round(hess, 2), solves=round(solve, 2), forwards=round(fwd, 2)),
+        **{k: round(v, 4) for k, v in m.items()},
     )
 
 
