@@ -368,7 +368,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <bool IS_BF16, int TOK, int NST>
+// ABL (harness build only, timing-only, WRONG results): bit 0 no LDS-DMA, bit 1 no fragment reads and no MFMA
+template <bool IS_BF16, int TOK, int NST, int ABL = 0>
 __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
                                                      float* __restrict__ H, float beta, float alpha, int nt, int block, int nblocks) {
   static_assert((NST & (NST - 1)) == 0 && NST >= 2 && NST <= 4 && TOK % 32 == 0, "stage ring");
@@ -397,7 +398,7 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
       int64_t t = (int64_t)kt * TOK + r;
       if (t > T - 1) t = T - 1;  // rows past T are zeroed in LDS before they are multiplied (below)
       const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + r * TR_PITCH);
-      lds_dma_1k(x + t * ldx, dst, voff);
+      if constexpr ((ABL & 1) == 0) lds_dma_1k(x + t * ldx, dst, voff);
     }
   };
   // step `next` has landed when at most the steps after it (up to `last_issued`) are still in this wave's queue
@@ -445,7 +446,7 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
       __syncthreads();
     }
 #pragma unroll
-    for (int kk = 0; kk < TOK / 32; ++kk) {
+    for (int kk = 0; kk < ((ABL & 2) ? 0 : TOK / 32); ++kk) {
       const uint32_t st = lds0 + cur * STAGE + kk * 32 * TR_PITCH;
       uint4 a[8], b[4];
 #pragma unroll
@@ -494,10 +495,10 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
     }
 }
 
-template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST>
+template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST, int ABL = 0>
 __global__ __launch_bounds__(512) void hessian_syrk_tr_256_kernel(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
                                                                   float* __restrict__ H, float beta, float alpha, int nt) {
-  hessian_syrk_tr_tile<IS_BF16, TOK, NST>(x, T, K, ldx, H, beta, alpha, nt, (int)blockIdx.x, (int)gridDim.x);
+  hessian_syrk_tr_tile<IS_BF16, TOK, NST, ABL>(x, T, K, ldx, H, beta, alpha, nt, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <bool IS_BF16, bool TAIL>
@@ -1141,6 +1142,14 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
         if (inc_small_tiles_flag(-1) == 46 && xdtype == INC_BF16) {  // timing A/B: four 32-token stages
           (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_kernel<true, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
           hessian_syrk_tr_256_kernel<true, 32, 4><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);
+          INC_LAUNCH_RETURN();
+        }
+        const int habl = inc_small_tiles_flag(-1) - 46;  // 47 / 48 / 49: timing-only, no LDS-DMA / no MFMA + fragment reads / neither
+        if (habl >= 1 && habl <= 3 && xdtype == INC_BF16) {
+#define INC_HABL(A) { (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_kernel<true, TR_TOK, TR_NST, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); \
+                      hessian_syrk_tr_256_kernel<true, TR_TOK, TR_NST, A><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2); }
+          if (habl == 1) INC_HABL(1) else if (habl == 2) INC_HABL(2) else INC_HABL(3)
+#undef INC_HABL
           INC_LAUNCH_RETURN();
         }
 #endif

@@ -574,9 +574,10 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
          (long)K, rel, (long)differ, ns, maxrel, ok ? "OK" : "FAIL");
   if (time_it) {
     Timer t;
-    const int modes[4] = {0, 46, 45, 1};
-    const char* labels[4] = {"256x256 transpose-read 2x64", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles"};
-    for (int mi = 0; mi < 4; ++mi) {
+    const int modes[7] = {0, 46, 45, 1, 47, 48, 49};
+    const char* labels[7] = {"256x256 transpose-read 2x64", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles",
+                             "  TR timing-only: no LDS-DMA", "  TR timing-only: no MFMA / frag reads", "  TR timing-only: barriers + epilogue"};
+    for (int mi = 0; mi < 7; ++mi) {
       inc_debug_set_small_tiles(modes[mi]);
       for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
       const int iters = 10;
