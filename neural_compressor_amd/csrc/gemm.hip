@@ -2067,19 +2067,27 @@ static int big_splitk(int64_t M, int64_t N, int64_t K, int* steps_out) {
 constexpr int64_t GEMV_MAX_M = 64;  // M <= 64 streams the weights once (woq_gemv_w4_kernel with 1 / 2 / 4 row blocks)
 
 int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  int64_t big = 0;
+  // an upper bound over the routes inc_woq_gemm can take for (M, N, K) (it does not know bits / group size here)
+  int64_t need = 0;
+  auto at_least = [&](int64_t v) { if (v > need) need = v; };
   if (M > 16) {
-    int steps;
-    const int splits = M > 16 && N >= 64 ? big_splitk(M, N, K, &steps) : 1;
-    big = splits > 1 ? WS_COUNTER_BYTES + (int64_t)splits * M * N * 4 : 0;  // slabs start AFTER the counter block
-    const int64_t strip = M <= STRIP_MAX_M ? WS_COUNTER_BYTES + 4 * M * N * 4 : 0;  // the strip kernel: <= 4 K-slices
-    if (strip > big) big = strip;
-    if (M > GEMV_MAX_M) return big;
+    if (N >= 64) {  // 256-row tiles (producer / consumer, 3A2B incl. its 8-bit form): split-K slabs behind the counter block
+      int steps;
+      const int splits = big_splitk(M, N, K, &steps);
+      if (splits > 1) at_least(WS_COUNTER_BYTES + (int64_t)splits * M * N * 4);
+    }
+    // the strip kernel, where inc_woq_gemm routes to it, with the K-slices it would use
+    const bool strip_m = M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20));
+    if (strip_m && M <= STRIP_MAX_M && N >= 64 && (K % 32) == 0 && ceil_div64(M, TM) * ceil_div64(N, TN) <= 64) {
+      const int sk = strip_splitk(M, N, K);
+      if (sk > 1) at_least(WS_COUNTER_BYTES + (int64_t)sk * M * N * 4);
+    }
+    if (M <= GEMV_MAX_M) at_least(WS_COUNTER_BYTES + ceil_div64(K, 32 * 4 * 4) * M * N * 4);  // streaming kernel, 4 steps per wave
+    return need;
   }
   int64_t slices = ceil_div64(K, 32 * 4 * 4);  // the streaming kernel at 4 steps per wave
-  if (slices < 64) slices = 64;  // the generic split-K path uses up to 64 slices
-  const int64_t small = WS_COUNTER_BYTES + slices * M * N * 4;
-  return small > big ? small : big;
+  if (slices < 64) slices = 64;                 // the generic split-K path uses up to 64 slices
+  return WS_COUNTER_BYTES + slices * M * N * 4;
 }
 
 int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16_t* scales,
