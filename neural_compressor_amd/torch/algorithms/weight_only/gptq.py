@@ -560,6 +560,10 @@ class GPTQ:
                 g_first = -(-i1 // gs)
                 g_last = (ref_end - 1) // gs
                 if g_last >= g_first:
+                    if lookahead and rest_done is not None and (g_last + 1) * gs > i1 + QBLOCK:
+                        # the groups read here reach past this 128-column block (group_size or block_size > 128): those columns
+                        # are still being updated by the previous block's remainder on the second stream
+                        main.wait_event(rest_done)
                     ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first, mse=mse)
             if not lookahead:
                 ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, err, i1, count, kernel_gs, bits)

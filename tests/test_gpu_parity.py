@@ -641,3 +641,52 @@ def test_inverse_cholesky_upper_rejects_non_spd(hip):
     H[200, 200] = -1.0
     with pytest.raises(torch.linalg.LinAlgError):
         inverse_cholesky_upper(H.to(hip))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groupsize,blocksize,sym", [(128, 128, True), (32, 128, False), (256, 128, True), (128, 256, False), (-1, 128, True)])
+def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize, blocksize, sym):
+    """The look-ahead column loop (next block's 128 columns first, the rest of the lazy update on a second stream) against the
+    one-stream loop on the same Hessian: identical codes, scales, zeros and Q -- including group / block sizes above 128, where
+    find_params reads columns that the previous block's remainder is still updating (gptq.py:1266-1272 reads "W as it is now")
+    -- and against the oracle's fasterquant with the same inverse factor injected."""
+    import neural_compressor_amd.torch.algorithms.weight_only.gptq as G
+
+    N, K = 320, 1024
+    g = torch.Generator().manual_seed(groupsize * 7 + blocksize)
+    W = torch.randn(N, K, generator=g) * 0.05
+    X = torch.randn(6, 96, K, generator=g)
+    outs = []
+    for look in (True, False):
+        monkeypatch.setattr(G, "LOOKAHEAD", look)
+        layer = torch.nn.Linear(K, N, bias=False).to(hip)
+        layer.weight.data.copy_(W)
+        gq = G.GPTQ(layer, device=hip)
+        gq.configure(dict(bits=4, sym=sym, dtype="int", mse=False))
+        for j in range(X.shape[0]):
+            gq.add_batch(X[j : j + 1].to(hip))
+        scale, _, zero, Q = gq.fasterquant(layer.weight.data, blocksize=blocksize, percdamp=0.01, groupsize=groupsize)
+        torch.cuda.synchronize()
+        outs.append((gq.codes.clone(), scale.clone(), None if zero is None else zero.clone(), Q.clone(), gq.acc.finalized))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    if a[2] is not None:
+        assert torch.equal(a[2], b[2])
+    # oracle with the HIP factor injected: rows may differ only where the oracle itself sits on a rounding tie
+    fin = a[4]
+    assert fin is not None and isinstance(fin[1], torch.Tensor) and fin[1].shape == (K, K)
+    H = torch.zeros(K, K)
+    n = 0
+    for j in range(X.shape[0]):
+        H, n = O.gptq_add_batch(H, n, X[j : j + 1])
+    ref = O.gptq_fasterquant(W.clone(), H, bits=4, sym=sym, blocksize=blocksize, percdamp=0.01, groupsize=groupsize, Hinv=fin[1].cpu())
+    # codes of the oracle from its Q (it returns no integers).  With block_size > 128 the lazy update of a reference block is two
+    # 128-column GEMMs here and one 256-term sum in the reference: the scales of later groups can differ in the last bit (and Q
+    # with them), the integer codes cannot, outside exact ties
+    G_ = ref["scale"].shape[1]
+    sc = ref["scale"].repeat_interleave(K // G_, dim=1)
+    zp = ref["zero"].repeat_interleave(K // G_, dim=1) if ref.get("zero") is not None else torch.full_like(sc, 8.0)
+    ref_codes = torch.round(ref["Q"] / sc + zp).to(torch.int32)
+    same_rows = (a[0].cpu().to(torch.int32) == ref_codes).all(dim=1).float().mean()
+    assert float(same_rows) >= 0.97, float(same_rows)
+    assert rel_fro(a[1].cpu(), ref["scale"]) <= 1e-6
