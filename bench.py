@@ -498,6 +498,9 @@ def main():
         config=dict(workload="Llama-2-7B GPTQ INT4 group_size=128 sym, 128 calib samples x 2048 tokens; step = one transformer block "
                              "(7 Linears: 4x[4096,4096], 2x[11008,4096], 1x[4096,11008]); value = 32 blocks",
                     samples=args.samples, seq_len=args.seq, block_size=128, percdamp=0.01,
+                    capture_pass=("first forward of a block ends at its last hooked Linear (that Linear's own product and the residual add "
+                                  "behind it only feed the output the reference computes and discards, gptq.py:690-702); "
+                                  "INC_MI355X_GPTQ_CAPTURE_EARLY_STOP=0 runs it in full; the quantised model is bit-identical either way"),
                     arithmetic="bf16 activations/weights (MFMA, fp32 accumulate), fp32 Hessian + Cholesky + column loop, int4 codes",
                     parallelism=("single GPU" if world == 1 else
                                  f"ONE model on {world} ranks: samples sharded {world}-way, Hessians reduced to owner ranks + factor broadcast "

@@ -87,6 +87,15 @@ def find_layers(module, layers=SUPPORTED_LAYERS, name=""):
 # ---------------------------------------------------------------------------------------------------
 CHOL_NB = 128
 LOOKAHEAD = os.environ.get("INC_MI355X_GPTQ_LOOKAHEAD", "1") == "1"
+# the capture pass of a block (forward with the Hessian hooks; its OUTPUT is discarded, reference gptq.py:690-702) stops at the
+# last hooked Linear instead of also running that Linear and whatever follows it
+CAPTURE_EARLY_STOP = os.environ.get("INC_MI355X_GPTQ_CAPTURE_EARLY_STOP", "1") == "1"
+
+
+class _CaptureDone(Exception):
+    """Raised by the Hessian pre-hook of the last hooked module of a capture pass: every input has been seen."""
+
+
 _LOOKAHEAD_STREAMS = {}
 
 
@@ -783,7 +792,7 @@ class RAWGPTQuantizer(object):
         return [qkv] + [[layer] for layer in post]
 
     # -- block forward over every calibration batch ----------------------------------------------------
-    def _run_block(self, block, on_output=None):
+    def _run_block(self, block, on_output=None, capture=False):
         """One forward of `block` over every cached calibration batch (reference :690-702 / :749-762).
 
         Cached batches that differ only in their hidden states (same shape, leading dimension 1, every other argument
@@ -812,9 +821,16 @@ class RAWGPTQuantizer(object):
                     kw["hidden_states"] = stacked
                 else:
                     pos[0] = stacked
-            out = self.track_hidden_states(block(*pos, **kw))
+            try:
+                out = self.track_hidden_states(block(*pos, **kw))
+            except _CaptureDone:
+                if not capture:
+                    raise
+                out = None  # a capture pass that ended at its last hooked module: there is no output, and none is wanted
             if on_output is not None:
-                if len(group) == 1:
+                if out is None:
+                    on_output(j0, None)
+                elif len(group) == 1:
                     on_output(j0, out)
                 else:
                     views = [out[i : i + 1] for i in range(len(group))]
@@ -879,7 +895,7 @@ class RAWGPTQuantizer(object):
     def _stacking_is_faithful(self, block, group, in_kwargs):
         """One stacked forward of `group` against the per-batch forwards (no hooks are installed at this point of the
         first block; outputs are compared up to GEMM-shape rounding)."""
-        hooks = [m._forward_hooks for m in block.modules()]
+        hooks = [m._forward_hooks for m in block.modules()] + [m._forward_pre_hooks for m in block.modules()]
         saved = [dict(h) for h in hooks]
         for h in hooks:
             h.clear()  # the Hessian hooks of the caller must not see these probe forwards
@@ -1022,8 +1038,10 @@ class RAWGPTQuantizer(object):
             live, alias = {}, {}
             share = self.share_hessians
 
+            fired, capture = [], {"probe": True, "stop": None}
+
             def make_hook(name):
-                def hook(_, inp, out):
+                def body(inp):
                     x = inp[0].detach()  # (not `.data`: the version counter must stay shared, see HessianAccumulator.ZERO_COPY)
                     key = (x.data_ptr(), tuple(x.shape), x.dtype, x._version)
                     if share and key in live:
@@ -1036,9 +1054,16 @@ class RAWGPTQuantizer(object):
                     live[key] = (name, x)  # keeps x alive so its address cannot be recycled inside this forward
                     solvers[name].add_batch(x)
 
+                def hook(_, inp):  # a forward PRE-hook: the input is all the Hessian needs (the reference hooks the output side)
+                    if capture["probe"]:
+                        fired.append(name)
+                    body(inp)
+                    if capture["stop"] == name:
+                        raise _CaptureDone
+
                 return hook
 
-            handles = [layers[n].register_forward_hook(make_hook(n)) for n in layers]
+            handles = [layers[n].register_forward_pre_hook(make_hook(n)) for n in layers]
             accs = [sv.acc for sv in solvers.values()]
             for acc in accs:
                 acc.defer = True  # the Hessian updates of one forward go out as ONE launch, after that forward
@@ -1046,8 +1071,15 @@ class RAWGPTQuantizer(object):
             def after_forward(j, out):
                 live.clear()
                 HessianAccumulator.flush_many(accs)
+                if capture["probe"]:
+                    # the first (complete) forward of the pass showed the order in which the hooked modules run: when each ran
+                    # exactly once, later forwards of this pass end at the last one -- its own GEMM and everything behind it
+                    # only produce the output that a capture pass throws away
+                    capture["probe"] = False
+                    if CAPTURE_EARLY_STOP and len(fired) == len(layers) and set(fired) == set(layers):
+                        capture["stop"] = fired[-1]
 
-            self._run_block(block, on_output=after_forward)
+            self._run_block(block, on_output=after_forward, capture=True)
             HessianAccumulator.flush_many(accs)
             for acc in accs:
                 acc.defer = False
