@@ -435,6 +435,7 @@ def main():
     clock.wrap(ops, "gptq_hessian_accum_multi", lambda items: "hessian_multi_K" + "+".join(str(x.shape[1]) for _, x, _, _ in items),
                lambda items: sum(2.0 * x.shape[0] * x.shape[1] ** 2 for _, x, _, _ in items))
     clock.wrap(ops, "gptq_quant_block", lambda w, *a: "quant_block", lambda w, *a: 2.0 * w.shape[0] * w.shape[1] * 4)
+    clock.wrap(ops, "gptq_quant_block_params", lambda w, *a: "quant_block", lambda w, *a: 2.0 * w.shape[0] * w.shape[1] * 4)  # find_params fused in
     clock.wrap(ops, "gptq_lazy_update", lambda w, h, e, i1, c: "lazy_update", lambda w, h, e, i1, c: 2.0 * w.shape[0] * c * max(w.shape[1] - i1 - c, 0))
     # look-ahead column loop: the next block's 128 columns on the main stream, the rest of the trailing matrix on the second stream
     clock.wrap(ops, "gptq_lazy_update_cols", lambda w, h, e, i1, c, c0, c1: "lazy_update_next" if c0 == i1 + c else "lazy_update_rest",

@@ -224,6 +224,16 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
                          int64_t G, int64_t i1, int count, int group_size, int bits,
                          inc_stream_t stream);
 
+/* == inc_gptq_quant_block that ALSO computes the (scale, zero) of the block's groups first: Quantizer.find_params
+ *   (gptq.py:1501-1571; perchannel, weight=True, no mse search) on the 128 columns as they are when the block starts
+ *   (gptq.py:1266-1272), written to scale / zero [N,G].  Only for a full block on a 128-column boundary whose groups lie
+ *   inside it (group_size 32 / 64 / 128) and a reference block size of 128: INC_ERR_UNSUPPORTED otherwise (callers then
+ *   use inc_gptq_find_params + inc_gptq_quant_block).  Saves one launch per 128 columns of the serial chain.          */
+int inc_gptq_quant_block_params(const float* w, const float* Hinv, float* scale, float* zero,
+                                uint8_t* codes, void* q_out, int q_dtype, float* err, int64_t N, int64_t K,
+                                int64_t G, int64_t i1, int count, int group_size, int bits, int sym,
+                                inc_stream_t stream);
+
 /* == W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:]  (gptq.py:1304), fp32 MFMA.  err [N,128].           */
 int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t N, int64_t K,
                          int64_t i1, int count, inc_stream_t stream);

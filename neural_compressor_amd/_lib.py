@@ -64,6 +64,7 @@ SIGNATURES = {
         c_int,
         [_P, _P, _P, _P, _P, _P, c_int, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P],
     ),
+    "inc_gptq_quant_block_params": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
     "inc_gptq_lazy_update": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "inc_gptq_lazy_update_cols": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int64, c_int64, _P]),
     "inc_chol_diag_block": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, c_int, _P]),

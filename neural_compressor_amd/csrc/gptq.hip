@@ -801,11 +801,14 @@ __device__ __forceinline__ float quad_bcast(float v, int src) {
 #pragma clang fp contract(off)
 // GPB = scale groups per 128-column block (1, 2 or 4: group_size >= 128 / 64 / 32 with i1 % 128 == 0), known
 // at compile time so that the 128 steps contain no branch at all; count == 128 on this path.
-template <int QDT, int GPB>
+// PARAMS: the kernel first computes the (scale, zero) of the block's own groups from the weights it has just loaded --
+// Quantizer.find_params (gptq.py:1501-1571, perchannel, weight=True, no mse search) on W "as it is now" (gptq.py:1266-1272) --
+// and writes them to scale / zero [N, G]: one launch less per 128 columns of the serial chain.  sym_flag as in find_params.
+template <int QDT, int GPB, bool PARAMS = false>
 __global__ __launch_bounds__(64) void gptq_quant_block_q4_kernel(
-    const float* __restrict__ w, const float* __restrict__ Hinv, const float* __restrict__ scale,
-    const float* __restrict__ zero, uint8_t* __restrict__ codes, void* __restrict__ q_out,
-    float* __restrict__ err, int64_t N, int64_t K, int64_t G, int64_t i1, int64_t g0, float maxq) {
+    const float* __restrict__ w, const float* __restrict__ Hinv, float* __restrict__ scale,
+    float* __restrict__ zero, uint8_t* __restrict__ codes, void* __restrict__ q_out,
+    float* __restrict__ err, int64_t N, int64_t K, int64_t G, int64_t i1, int64_t g0, float maxq, int sym_flag) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* hs = reinterpret_cast<float*>(smem_raw);  // [QB][QB] Hinv1 tile, later reused as the output stage
   const int lane = threadIdx.x, r = lane >> 2, q = lane & 3;
@@ -833,12 +836,45 @@ __global__ __launch_bounds__(64) void gptq_quant_block_q4_kernel(
 #pragma unroll
   for (int c = 0; c < 8; ++c) cw[c] = 0u;
   float sg[GPB], zg[GPB];
+  if constexpr (!PARAMS) {
 #pragma unroll
-  for (int g = 0; g < GPB; ++g) {
-    sg[g] = scale[rowc * G + g0 + g];
-    zg[g] = zero[rowc * G + g0 + g];
+    for (int g = 0; g < GPB; ++g) {
+      sg[g] = scale[rowc * G + g0 + g];
+      zg[g] = zero[rowc * G + g0 + g];
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (PARAMS) {
+    // group g of the block = block columns [g * 128 / GPB, (g + 1) * 128 / GPB): this lane holds 4c + q for c in [g * 32 / GPB, ...)
+#pragma unroll
+    for (int g = 0; g < GPB; ++g) {
+      float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+      for (int c = g * (32 / GPB); c < (g + 1) * (32 / GPB); ++c) {
+        vmax = fmaxf(vmax, wr[c]);
+        vmin = fminf(vmin, wr[c]);
+      }
+      vmax = fmaxf(vmax, __shfl_xor(vmax, 1, 64));
+      vmin = fminf(vmin, __shfl_xor(vmin, 1, 64));
+      vmax = fmaxf(vmax, __shfl_xor(vmax, 2, 64));
+      vmin = fminf(vmin, __shfl_xor(vmin, 2, 64));
+      // gptq.py:1547-1571 (the arithmetic of gptq_find_params_kernel, quant.hip)
+      float xmin = fminf(vmin, 0.f), xmax = fmaxf(vmax, 0.f);
+      if (sym_flag) {
+        xmax = fmaxf(fabsf(xmin), xmax);
+        if (xmin < 0.f) xmin = -xmax;
+      }
+      if (xmin == 0.f && xmax == 0.f) { xmin = -1.f; xmax = 1.f; }
+      const float sv = (xmax - xmin) / maxq;
+      const float zv = sym_flag ? (maxq + 1.f) * 0.5f : rintf(-xmin / sv);
+      sg[g] = sv;
+      zg[g] = zv;
+      if (q == 0 && row < N) {
+        scale[row * G + g0 + g] = sv;
+        zero[row * G + g0 + g] = zv;
+      }
+    }
+  }
   __syncthreads();
 
   // The row of Hinv1 needed by step i+1 is read from LDS while step i computes: two register sets used
@@ -1287,7 +1323,7 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
 #undef INC_Q4_ATTR
     const unsigned blocks4 = (unsigned)ceil_div64(N, Q4R);
     const int64_t g0 = group_size > 0 ? i1 / group_size : 0;
-#define INC_Q4(GP) gptq_quant_block_q4_kernel<DT, GP><<<blocks4, 64, smem4, s>>>(w, Hinv, scale, zero, codes, q_out, err, N, K, G, i1, g0, maxq)
+#define INC_Q4(GP) gptq_quant_block_q4_kernel<DT, GP><<<blocks4, 64, smem4, s>>>(w, Hinv, const_cast<float*>(scale), const_cast<float*>(zero), codes, q_out, err, N, K, G, i1, g0, maxq, 0)
     INC_DISPATCH_DTYPE(q_dtype, DT, {
       if (gpb == 1) INC_Q4(1); else if (gpb == 2) INC_Q4(2); else INC_Q4(4);
     })
@@ -1297,6 +1333,41 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
   INC_DISPATCH_DTYPE(q_dtype, DT, {
     gptq_quant_block_kernel<DT><<<blocks, 64, smem, s>>>(w, Hinv, scale, zero, codes, q_out, err, N, K, G, i1, count, group_size, maxq);
   })
+  INC_LAUNCH_RETURN();
+}
+
+// inc_gptq_quant_block for a full 128-column block whose groups lie inside it (group_size 32 / 64 / 128, i1 on a 128-column
+// boundary), computing the groups' (scale, zero) itself -- see the PARAMS form of the kernel.  INC_ERR_UNSUPPORTED otherwise.
+int inc_gptq_quant_block_params(const float* w, const float* Hinv, float* scale, float* zero, uint8_t* codes, void* q_out,
+                                int q_dtype, float* err, int64_t N, int64_t K, int64_t G, int64_t i1, int count, int group_size,
+                                int bits, int sym, inc_stream_t stream) {
+  INC_CHECK_ARG(w && Hinv && scale && zero && err && N > 0 && K > 0 && G > 0);
+  INC_CHECK_ARG(i1 >= 0 && count > 0 && count <= QB && i1 + count <= K && bits >= 1 && bits <= 8);
+  int gpb = 0;
+  if (group_size == QB) gpb = 1;
+  else if (group_size == 64) gpb = 2;
+  else if (group_size == 32) gpb = 4;
+  if (!(gpb && count == QB && (i1 % QB) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32))) return INC_ERR_UNSUPPORTED;
+  const int64_t g0 = i1 / group_size;
+  INC_CHECK_ARG(g0 + gpb <= G);
+  const float maxq = (float)((1 << bits) - 1);
+  hipStream_t s = inc_s(stream);
+  const size_t smem4 = (size_t)QB * QB * 4;
+  static std::atomic<uint64_t> attr_set{0};
+#define INC_Q4P_ATTR(DT, GP) (void)hipFuncSetAttribute((const void*)gptq_quant_block_q4_kernel<DT, GP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)
+  if (inc_attr_needed(attr_set)) {
+    INC_Q4P_ATTR(INC_F32, 1); INC_Q4P_ATTR(INC_F32, 2); INC_Q4P_ATTR(INC_F32, 4);
+    INC_Q4P_ATTR(INC_F16, 1); INC_Q4P_ATTR(INC_F16, 2); INC_Q4P_ATTR(INC_F16, 4);
+    INC_Q4P_ATTR(INC_BF16, 1); INC_Q4P_ATTR(INC_BF16, 2); INC_Q4P_ATTR(INC_BF16, 4);
+    inc_attr_done(attr_set);
+  }
+#undef INC_Q4P_ATTR
+  const unsigned blocks4 = (unsigned)ceil_div64(N, Q4R);
+#define INC_Q4P(GP) gptq_quant_block_q4_kernel<DT, GP, true><<<blocks4, 64, smem4, s>>>(w, Hinv, scale, zero, codes, q_out, err, N, K, G, i1, g0, maxq, sym)
+  INC_DISPATCH_DTYPE(q_dtype, DT, {
+    if (gpb == 1) INC_Q4P(1); else if (gpb == 2) INC_Q4P(2); else INC_Q4P(4);
+  })
+#undef INC_Q4P
   INC_LAUNCH_RETURN();
 }
 

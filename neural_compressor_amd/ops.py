@@ -436,6 +436,23 @@ def gptq_quant_block(w32, hinv, scale, zero, codes, q_out, err, i1, count, group
         )
 
 
+def gptq_quant_block_params(w32, hinv, scale, zero, codes, q_out, err, i1, count, group_size, bits, sym):
+    """`gptq_quant_block` that first computes the block's own group parameters (find_params fused into the launch; see
+    include/inc_mi355x.h).  Returns False when the library has no such form for this block."""
+    dev = _dev(w32, hinv, scale, zero, codes, q_out, err)
+    N, K = w32.shape
+    G = scale.shape[1]
+    with torch.cuda.device(dev):
+        rc = lib.inc_gptq_quant_block_params(
+            _ptr(w32), _ptr(hinv), _ptr(scale), _ptr(zero), _ptr(codes), _ptr(q_out),
+            dtype_code(q_out.dtype) if q_out is not None else INC_F32, _ptr(err), N, K, G, i1, count, group_size, bits,
+            1 if sym else 0, _stream())
+    if rc == -2:  # INC_ERR_UNSUPPORTED
+        return False
+    check(rc, "inc_gptq_quant_block_params")
+    return True
+
+
 def gptq_lazy_update(w32, hinv, err, i1, count):
     dev = _dev(w32, hinv, err)
     N, K = w32.shape

@@ -90,6 +90,7 @@ LOOKAHEAD = os.environ.get("INC_MI355X_GPTQ_LOOKAHEAD", "1") == "1"
 # the capture pass of a block (forward with the Hessian hooks; its OUTPUT is discarded, reference gptq.py:690-702) stops at the
 # last hooked Linear instead of also running that Linear and whatever follows it
 CAPTURE_EARLY_STOP = os.environ.get("INC_MI355X_GPTQ_CAPTURE_EARLY_STOP", "1") == "1"
+FUSE_FIND_PARAMS = os.environ.get("INC_MI355X_GPTQ_FUSE_FIND_PARAMS", "1") == "1"
 
 
 class _CaptureDone(Exception):
@@ -561,10 +562,15 @@ class GPTQ:
             side.wait_stream(main)  # w32 / Hinv / scales were produced on the main stream
             rest_done = None
             blk = 0
+        # find_params fused into the quantisation launch (one kernel less per 128 columns of the serial chain): only when the
+        # reference block IS the 128-column block and every group lies inside it -- with a larger reference block the second
+        # half's parameters must come from W BEFORE the first half's lazy update (gptq.py:1266-1272 reads the global W)
+        fuse_params = (FUSE_FIND_PARAMS and dynamic_groups and not mse and blocksize == QBLOCK and gs in (32, 64, QBLOCK)
+                       and K % QBLOCK == 0 and loop_scale is scale and N > 0)
         while i1 < K:
             ref_end = min((i1 // blocksize + 1) * blocksize, K)  # end of the reference's block (gptq.py:1250)
             count = min(QBLOCK, ref_end - i1)
-            if dynamic_groups and i1 % blocksize == 0:
+            if dynamic_groups and i1 % blocksize == 0 and not fuse_params:
                 # groups that START inside this reference block read the global W as it is now (gptq.py:1266-1272)
                 g_first = -(-i1 // gs)
                 g_last = (ref_end - 1) // gs
@@ -574,13 +580,20 @@ class GPTQ:
                         # are still being updated by the previous block's remainder on the second stream
                         main.wait_event(rest_done)
                     ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first, mse=mse)
+            def quant_block(e):
+                if fuse_params:
+                    if not ops.gptq_quant_block_params(w32, Hinv, scale, zero, codes, Q, e, i1, count, gs, bits, sym):
+                        raise RuntimeError("inc_gptq_quant_block_params refused a full 128-column block")
+                else:
+                    ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, e, i1, count, kernel_gs, bits)
+
             if not lookahead:
-                ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, err, i1, count, kernel_gs, bits)
+                quant_block(err)
                 ops.gptq_lazy_update(w32, Hinv, err, i1, count)
                 i1 += count
                 continue
             e = errs[blk & 1]
-            ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, e, i1, count, kernel_gs, bits)
+            quant_block(e)
             i2 = i1 + count
             if i2 < K:
                 if rest_done is not None:
