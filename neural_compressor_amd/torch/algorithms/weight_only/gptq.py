@@ -1051,7 +1051,7 @@ class RAWGPTQuantizer(object):
             live, alias = {}, {}
             share = self.share_hessians
 
-            fired, capture = [], {"probe": True, "stop": None}
+            fired, seen, capture = [], set(), {"probe": True, "stop": None}
 
             def make_hook(name):
                 def body(inp):
@@ -1070,8 +1070,11 @@ class RAWGPTQuantizer(object):
                 def hook(_, inp):  # a forward PRE-hook: the input is all the Hessian needs (the reference hooks the output side)
                     if capture["probe"]:
                         fired.append(name)
+                    seen.add(name)
                     body(inp)
-                    if capture["stop"] == name:
+                    # only once EVERY hooked module of this forward has been served (a block whose modules run in a
+                    # data-dependent order simply never stops early)
+                    if capture["stop"] == name and len(seen) == len(layers):
                         raise _CaptureDone
 
                 return hook
@@ -1083,6 +1086,7 @@ class RAWGPTQuantizer(object):
 
             def after_forward(j, out):
                 live.clear()
+                seen.clear()
                 HessianAccumulator.flush_many(accs)
                 if capture["probe"]:
                     # the first (complete) forward of the pass showed the order in which the hooked modules run: when each ran
