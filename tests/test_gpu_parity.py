@@ -690,3 +690,42 @@ def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize
     same_rows = (a[0].cpu().to(torch.int32) == ref_codes).all(dim=1).float().mean()
     assert float(same_rows) >= 0.97, float(same_rows)
     assert rel_fro(a[1].cpu(), ref["scale"]) <= 1e-6
+
+
+GQW_CASES = {
+    "gqw_sym_g256_bs128": dict(bits=4, sym=True, blocksize=128, groupsize=256),
+    "gqw_asym_g128_bs256": dict(bits=4, sym=False, blocksize=256, groupsize=128),
+    "gqw_sym_g64_bs256": dict(bits=4, sym=True, blocksize=256, groupsize=64),
+    "gqw_asym_g256_bs384": dict(bits=4, sym=False, blocksize=384, groupsize=256),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(GQW_CASES))
+def test_gptq_layer_wide_groups_and_blocks_vs_reference(hip, tag):
+    """add_batch -> fasterquant on the MI355X against the unmodified reference's outputs for layouts whose groups or reference
+    blocks are wider than the 128-column step (tests/golden/make_golden_gptq_wide.py): the look-ahead loop has to wait for
+    the previous remainder before find_params there."""
+    import os
+
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import GPTQ
+
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gptq_wide_golden.npz"))
+    kw = GQW_CASES[tag]
+    W = torch.from_numpy(golden[f"{tag}_W"])
+    X = torch.from_numpy(golden[f"{tag}_X"])
+    N, K = W.shape
+    layer = torch.nn.Linear(K, N, bias=False).to(hip)
+    layer.weight.data.copy_(W)
+    gq = GPTQ(layer, device=hip)
+    gq.configure(dict(bits=kw["bits"], sym=kw["sym"], dtype="int", mse=False))
+    for j in range(X.shape[0]):
+        gq.add_batch(X[j : j + 1].to(hip))
+    scale, _, zero, Q = gq.fasterquant(layer.weight.data, blocksize=kw["blocksize"], percdamp=0.01, groupsize=kw["groupsize"])
+    ref_ints = golden[f"{tag}_ints"].astype(np.int32) + (8 if kw["sym"] else 0)
+    match = float((gq.codes.cpu().numpy().astype(np.int32) == ref_ints).mean())
+    assert match >= 0.99, f"only {match:.4f} of the codes match the reference"
+    assert rel_fro(scale.cpu(), torch.from_numpy(golden[f"{tag}_scale"])) <= 1e-3
+    if not kw["sym"]:
+        assert float((zero.cpu() != torch.from_numpy(golden[f"{tag}_zero"])).float().mean()) <= 0.01
+    assert rel_fro(Q.cpu(), torch.from_numpy(golden[f"{tag}_Q"])) <= 3e-2

@@ -234,3 +234,36 @@ def test_oracle_nf4_fp4_double_quant_vs_reference_golden(tag):
     assert (zp is None) == (f"{tag}_zp" not in g.files)
     if zp is not None:
         assert np.array_equal(zp.numpy(), g[f"{tag}_zp"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPTQ layouts wider than the 128-column step (tests/golden/make_golden_gptq_wide.py)
+# ---------------------------------------------------------------------------------------------------
+GQW_CASES = {
+    "gqw_sym_g256_bs128": dict(bits=4, sym=True, blocksize=128, groupsize=256),
+    "gqw_asym_g128_bs256": dict(bits=4, sym=False, blocksize=256, groupsize=128),
+    "gqw_sym_g64_bs256": dict(bits=4, sym=True, blocksize=256, groupsize=64),
+    "gqw_asym_g256_bs384": dict(bits=4, sym=False, blocksize=384, groupsize=256),
+}
+
+
+@pytest.fixture(scope="module")
+def golden_wide():
+    return np.load(os.path.join(ROOT, "tests", "golden", "gptq_wide_golden.npz"))
+
+
+@pytest.mark.parametrize("tag", list(GQW_CASES))
+def test_gptq_layer_wide_groups_and_blocks(golden_wide, tag):
+    """The oracle's fasterquant against the unmodified reference where find_params reads past the 128-column step."""
+    kw = GQW_CASES[tag]
+    W = torch.from_numpy(golden_wide[f"{tag}_W"])
+    X = torch.from_numpy(golden_wide[f"{tag}_X"])
+    H, n = torch.zeros(W.shape[1], W.shape[1]), 0
+    for j in range(X.shape[0]):
+        H, n = O.gptq_add_batch(H, n, X[j : j + 1])
+    r = O.gptq_fasterquant(W, H, **kw)
+    assert np.array_equal(r["scale"].numpy(), golden_wide[f"{tag}_scale"])
+    assert np.array_equal(r["zero"].numpy(), golden_wide[f"{tag}_zero"])
+    assert np.array_equal(r["Q"].numpy(), golden_wide[f"{tag}_Q"])
+    ints = O.gptq_export_ints(r["Q"], r["scale"], r["zero"], kw["sym"], kw["groupsize"], r["perm"])
+    assert np.array_equal(ints.numpy(), golden_wide[f"{tag}_ints"].astype(np.int32))
