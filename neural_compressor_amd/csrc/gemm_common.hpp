@@ -1,0 +1,176 @@
+// gemm_common.hpp -- helpers shared by the dequant-GEMM translation units (gemm.hip, gemm_d2r.hip): MFMA wrappers,
+// the int4 -> bf16 / f16 dequantisation arithmetic and the 256 x 256 x 64 tile constants.
+#pragma once
+#include "common.hpp"
+
+// gemm_d2r.hip: launcher of the direct-to-register dequant-GEMM, called by inc_woq_gemm (gemm.hip)
+int inc_launch_woq_gemm_d2r(const uint16_t* x, const uint32_t* qw, const uint16_t* scales, const uint32_t* qz, const uint16_t* bias,
+                            uint16_t* y, int64_t M, int64_t N, int64_t K, int64_t NW, int g_shift, int y_vec_ok, float* part, int steps,
+                            int splits, bool bf, int ns, int abl, hipStream_t s);
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <bool IS_BF16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  if constexpr (IS_BF16) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  } else {
+    return (uint32_t)f32_to_f16_bits(lo) | ((uint32_t)f32_to_f16_bits(hi) << 16);
+  }
+}
+
+template <bool IS_BF16>
+__device__ __forceinline__ float cvt16(uint16_t b) {
+  if constexpr (IS_BF16) return bf16_bits_to_f32(b);
+  else return f16_bits_to_f32(b);
+}
+
+// group parameters of one (group, column): fp32 scale and integer zero point
+struct GroupQ {
+  float s;
+  int z;
+};
+
+template <int BITS>
+__device__ __forceinline__ GroupQ load_group(const uint16_t* __restrict__ scales,
+                                             const uint32_t* __restrict__ qzeros, int64_t g, int64_t n,
+                                             int64_t N, int64_t NW) {
+  constexpr int NP = 32 / BITS;
+  constexpr uint32_t MASK = (1u << BITS) - 1u;
+  GroupQ r;
+  r.s = f16_bits_to_f32(scales[g * N + n]);
+  uint32_t zz = ((qzeros[g * NW + n / NP] >> (BITS * (uint32_t)(n % NP))) & MASK) + 1u;  // modules.py:407-410
+  r.z = zz > MASK ? 0 : (int)zz;
+  return r;
+}
+
+// dequantise one packed word (NP consecutive k of one column) into NP/2 dwords of 16-bit pairs
+template <int BITS, bool IS_BF16>
+__device__ __forceinline__ void dequant_word(uint32_t word, const GroupQ& gq, uint32_t (&out)[16 / BITS]) {
+  constexpr int NP = 32 / BITS;
+  constexpr uint32_t MASK = (1u << BITS) - 1u;
+#pragma unroll
+  for (int h = 0; h < NP / 2; ++h) {
+    const int q0 = (int)((word >> (BITS * (2 * h))) & MASK);
+    const int q1 = (int)((word >> (BITS * (2 * h + 1))) & MASK);
+    const float v0 = (float)(int8_t)(q0 - gq.z) * gq.s;
+    const float v1 = (float)(int8_t)(q1 - gq.z) * gq.s;
+    out[h] = pack2<IS_BF16>(v0, v1);
+  }
+}
+
+template <bool IS_BF16>
+__device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, f32x16 c) {
+  if constexpr (IS_BF16) {
+    bf16x8 fa, fb;
+    __builtin_memcpy(&fa, &a, 16);
+    __builtin_memcpy(&fb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, c, 0, 0, 0);
+  } else {
+    f16x8 fa, fb;
+    __builtin_memcpy(&fa, &a, 16);
+    __builtin_memcpy(&fb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c, 0, 0, 0);
+  }
+}
+template <bool IS_BF16>
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+  if constexpr (IS_BF16) {
+    bf16x8 fa, fb;
+    __builtin_memcpy(&fa, &a, 16);
+    __builtin_memcpy(&fb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, c, 0, 0, 0);
+  } else {
+    f16x8 fa, fb;
+    __builtin_memcpy(&fa, &a, 16);
+    __builtin_memcpy(&fb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, c, 0, 0, 0);
+  }
+}
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int T_ASTAGE = TM * TK * 2;  // bytes
+constexpr int T_BSTAGE = TN * TK * 2;
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+template <bool IS_BF16>
+__device__ __forceinline__ uint32_t cvt_pair(float a, float b) {
+  f32x2 f = {a, b};
+  uint32_t r;
+  if constexpr (IS_BF16) {
+    bf16x2 h = __builtin_convertvector(f, bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+    __builtin_memcpy(&r, &h, 4);
+  } else {
+    f16x2 h = __builtin_convertvector(f, f16x2);
+    __builtin_memcpy(&r, &h, 4);
+  }
+  return r;
+}
+
+// 8 nibbles of `w` -> 8 x rn16((q - z) * s), k-ordered, as 4 dwords.
+// int -> float goes through the fp8 converter: an e4m3 byte with value q in 0..15 decodes to q * u (u = 2^-9 for the
+// OCP format of gfx950: codes 0..7 are subnormals m * 2^-9, codes 8..15 are (1 + m/8) * 2^-6 = (8 + m) * 2^-9), so ONE
+// v_cvt_pk_f32_fp8 turns two nibbles (bytes of `w & 0x0F0F0F0F`) into two floats -- 4 instead of 8 conversions per word.
+// `s_over_u` = s / u (exact: a power-of-two rescale); fma(q*u, s/u, -z*s) is exact in fp32 (q, z < 32 and s has 11
+// significant bits), so the single rounding is the 16-bit conversion: bit-identical to inc_woq_dequant.
+__device__ __forceinline__ float fp8_unit_inverse() {
+  return 1.0f / __builtin_amdgcn_cvt_pk_f32_fp8(0x00000001, false)[0];  // measured, not assumed: 2^9 on gfx950
+}
+// one fp32 FMA that the SLP vectoriser cannot fuse into v_pk_fma_f32 (see dequant8's SFMA form)
+__device__ __forceinline__ float fma_single(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// FORM 0 (default): eight v_fma_f32; FORM 1: four v_pk_fma_f32 (the first generation; same values -- each half of the packed op
+// is the same fused multiply-add); FORM 2: eight single v_cvt_f32_fp8 (byte select) + eight v_fma_f32.
+// MI355X_MICROARCH.md: a packed fp32 VALU op next to MFMAs costs ~22 cycles more than the two scalar ops it replaces -- measured
+// here: the producer / consumer GEMM gains 6-10 % from FORM 0 (tools/kbench pcfma), outputs bit-identical.
+template <bool IS_BF16, int FORM = 0>
+__device__ __forceinline__ uint4 dequant8(uint32_t w, float s_over_u, float nzs) {
+  const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;  // bytes: k0,k2,k4,k6 / k1,k3,k5,k7
+  if constexpr (FORM == 0) {
+    const f32x2 c01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), c23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2 d01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    uint4 o;
+    o.x = cvt_pair<IS_BF16>(fma_single(c01[0], s_over_u, nzs), fma_single(d01[0], s_over_u, nzs));
+    o.y = cvt_pair<IS_BF16>(fma_single(c01[1], s_over_u, nzs), fma_single(d01[1], s_over_u, nzs));
+    o.z = cvt_pair<IS_BF16>(fma_single(c23[0], s_over_u, nzs), fma_single(d23[0], s_over_u, nzs));
+    o.w = cvt_pair<IS_BF16>(fma_single(c23[1], s_over_u, nzs), fma_single(d23[1], s_over_u, nzs));
+    return o;
+  }
+  if constexpr (FORM == 2) {
+    float e[4], f[4];
+    e[0] = __builtin_amdgcn_cvt_f32_fp8((int)lo, 0); e[1] = __builtin_amdgcn_cvt_f32_fp8((int)lo, 1);
+    e[2] = __builtin_amdgcn_cvt_f32_fp8((int)lo, 2); e[3] = __builtin_amdgcn_cvt_f32_fp8((int)lo, 3);
+    f[0] = __builtin_amdgcn_cvt_f32_fp8((int)hi, 0); f[1] = __builtin_amdgcn_cvt_f32_fp8((int)hi, 1);
+    f[2] = __builtin_amdgcn_cvt_f32_fp8((int)hi, 2); f[3] = __builtin_amdgcn_cvt_f32_fp8((int)hi, 3);
+    uint4 o;
+    o.x = cvt_pair<IS_BF16>(fma_single(e[0], s_over_u, nzs), fma_single(f[0], s_over_u, nzs));
+    o.y = cvt_pair<IS_BF16>(fma_single(e[1], s_over_u, nzs), fma_single(f[1], s_over_u, nzs));
+    o.z = cvt_pair<IS_BF16>(fma_single(e[2], s_over_u, nzs), fma_single(f[2], s_over_u, nzs));
+    o.w = cvt_pair<IS_BF16>(fma_single(e[3], s_over_u, nzs), fma_single(f[3], s_over_u, nzs));
+    return o;
+  }
+  const f32x2 sv = {s_over_u, s_over_u}, nv = {nzs, nzs};
+  const f32x2 e01 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), sv, nv);  // k0, k2
+  const f32x2 e23 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true), sv, nv);   // k4, k6
+  const f32x2 o01 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), sv, nv);  // k1, k3
+  const f32x2 o23 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true), sv, nv);   // k5, k7
+  uint4 o;
+  o.x = cvt_pair<IS_BF16>(e01[0], o01[0]);
+  o.y = cvt_pair<IS_BF16>(e01[1], o01[1]);
+  o.z = cvt_pair<IS_BF16>(e23[0], o23[0]);
+  o.w = cvt_pair<IS_BF16>(e23[1], o23[1]);
+  return o;
+}
+
+}  // namespace

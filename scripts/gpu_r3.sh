@@ -1,0 +1,31 @@
+#!/bin/bash
+# One gpurun call of round 3.  usage: scripts/gpu_r3.sh [tests] [bench] [kbench <args>] [prof]   (any subset, in order)
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-.}"
+R=$PWD
+while [[ $# -gt 0 ]]; do
+  case $1 in
+    tests)
+      timeout 1700 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+      echo "pytest exit $?" | tee -a gpurun_out/pytest_gpu.log
+      grep -E "^\[|passed|failed|Error|error" gpurun_out/pytest_gpu.log | tail -60
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" | tee -a gpurun_out/smoke.log
+      tail -2 gpurun_out/smoke.log ;;
+    newtests)
+      timeout 1700 python -m pytest tests/test_gpu_baseline_parity.py tests/test_gpu_models.py -m gpu -q -s --timeout=900 -p no:cacheprovider -k "baseline or awq or row_sharded or sample_and_row or vs_oracle or staged or running_mean" > gpurun_out/pytest_new.log 2>&1
+      echo "pytest(new) exit $?" | tee -a gpurun_out/pytest_new.log
+      grep -E "^\[|passed|failed|Error|error|assert" gpurun_out/pytest_new.log | tail -80 ;;
+    bench)
+      timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2> gpurun_out/bench.err
+      echo "bench exit $?"; tail -c 6000 gpurun_out/bench.log; tail -25 gpurun_out/bench.err ;;
+    kbench)
+      shift
+      timeout 600 tools/kbench $1 > gpurun_out/kbench_$1.log 2>&1; echo "kbench $1 exit $?"; tail -60 gpurun_out/kbench_$1.log ;;
+    prof)
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r2 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
+      echo "prof exit $?"; find gpurun_out/prof -name "*kernel_stats*" | head -3 ;;
+  esac
+  shift
+done

@@ -261,6 +261,71 @@ static int run_gemm_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool
   return ok ? 0 : 1;
 }
 
+// ---- direct-to-register dequant-GEMM (gemm_d2r.hip, harness flags 90..99) vs the producer / consumer kernel (flag 42): bitwise, then timed ----
+static int run_d2r_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool with_bias, bool time_it, bool ablate) {
+  Packed W(N, K, gs, sym);
+  DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N), y2((size_t)M * N), bias((size_t)N);
+  {
+    std::vector<uint16_t> hx(x.n), hb(N);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    for (auto& v : hb) v = f2bf(rnd_normal());
+    x.upload(hx);
+    bias.upload(hb);
+  }
+  const int64_t wsb = inc_woq_gemm_workspace_bytes(M, N, K);
+  DevBuf<char> ws((size_t)(wsb > 0 ? wsb : 16));
+  ws.zero();
+  const void* bp = with_bias ? bias.p : nullptr;
+  auto run = [&](int mode, uint16_t* out) {
+    inc_debug_set_small_tiles(mode);
+    INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, out, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
+  };
+  HIPCHECK(hipMemset(y.p, 0xff, y.n * 2));
+  HIPCHECK(hipMemset(y2.p, 0xee, y2.n * 2));
+  run(42, y.p);
+  HIPCHECK(hipDeviceSynchronize());
+  int fails = 0;
+  const int chk[2] = {90, 91};
+  std::vector<uint16_t> h1 = y.download();
+  for (int c = 0; c < 2; ++c) {
+    HIPCHECK(hipMemset(y2.p, 0xee, y2.n * 2));
+    run(chk[c], y2.p);
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<uint16_t> h2 = y2.download();
+    size_t diff = 0, first = 0;
+    for (size_t i = 0; i < h1.size(); ++i)
+      if (h1[i] != h2[i]) { if (!diff) first = i; ++diff; }
+    printf("D2R M=%ld N=%ld K=%ld gs=%d %s%s flag %d: %zu of %zu outputs differ from the producer/consumer kernel%s", (long)M, (long)N, (long)K, gs,
+           sym ? "sym" : "asym", with_bias ? "+bias" : "", chk[c], diff, h1.size(), diff ? "" : "  OK\n");
+    if (diff) { printf(" (first at row %zu col %zu: %04x vs %04x)  FAIL\n", first / N, first % N, h2[first], h1[first]); ++fails; }
+  }
+  if (time_it) {
+    const int nv_all = 11;
+    const int modes[nv_all] = {42, 90, 91, 92, 93, 94, 95, 96, 97, 98, 99};
+    const char* labels[nv_all] = {"PC producer/consumer", "D2R 4 x-stages", "D2R 3 x-stages", "D2R - dequant arithmetic", "D2R - x LDS-DMA", "D2R - W loads",
+                                  "D2R - all global traffic", "D2R - fragment reads", "D2R - MFMA", "D2R MFMA + barrier only", "D2R MFMA only"};
+    const int nv = ablate ? nv_all : 3, rounds = 5, iters = 8;
+    std::vector<std::vector<float>> ms(nv);
+    Timer t;
+    for (int i = 0; i < 10; ++i) run(42, y.p);
+    for (int r = 0; r < rounds; ++r)
+      for (int vi = 0; vi < nv; ++vi) {
+        const int mi = (vi + r) % nv;
+        run(modes[mi], y.p);
+        t.start();
+        for (int i = 0; i < iters; ++i) run(modes[mi], y.p);
+        ms[mi].push_back(t.stop_ms() / iters);
+      }
+    for (int mi = 0; mi < nv; ++mi) {
+      std::sort(ms[mi].begin(), ms[mi].end());
+      const float med = ms[mi][ms[mi].size() / 2];
+      printf("  %-28s median %8.4f ms %8.1f TFLOP/s   (best %8.4f ms %8.1f)\n", labels[mi], med, 2.0 * M * N * K / med / 1e9, ms[mi][0], 2.0 * M * N * K / ms[mi][0] / 1e9);
+    }
+  }
+  inc_debug_set_small_tiles(0);
+  return fails;
+}
+
 // ---- mid-M strip kernel vs the 256-row tile + split-K path: checked against the fp32 reference rows, then timed --------
 static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool with_bias, bool time_it) {
   Packed W(N, K, gs, sym);
@@ -742,6 +807,17 @@ int main(int argc, char** argv) {
     fails += run_strip_case(128, 11008, 4096, 128, true, false, true);
     fails += run_strip_case(512, 11008, 4096, 128, true, false, true);
     fails += run_strip_case(512, 4096, 11008, 128, true, false, true);
+  }
+  if (what == "d2r" || what == "all") {
+    fails += run_d2r_case(256, 256, 128, 64, false, true, false, false);      // one tile, two K-steps, gs=64 asym + bias
+    fails += run_d2r_case(300, 1000, 256, 64, false, true, false, false);     // ragged M and N
+    fails += run_d2r_case(700, 520, 384, 128, false, true, false, false);     // split-K slabs, ragged tiles
+    fails += run_d2r_case(1024, 768, 1024, 1024, true, false, false, false);  // single group
+    fails += run_d2r_case(512, 512, 896, 128, true, false, false, false);     // 14 K-steps: every remainder of the 3-step unroll
+    fails += run_d2r_case(4096, 4096, 4096, 128, true, false, true, true);
+    fails += run_d2r_case(4096, 11008, 4096, 128, true, false, true, false);
+    fails += run_d2r_case(4096, 4096, 11008, 128, true, false, true, false);
+    fails += run_d2r_case(8192, 4096, 4096, 128, false, true, true, false);
   }
   if (what == "gemm" || what == "all") {
     fails += run_gemm_case(256, 256, 64, 32, false, true, false, 64);     // one tile, one K-step, gs=32 asym
