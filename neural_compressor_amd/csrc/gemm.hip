@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_big_kernel(
 // 1: the producer / consumer kernel (woq_gemm_w4_pc_kernel) takes the large-M 4-bit path whenever it applies
 // 1: the direct-to-register kernel (gemm_d2r.hip) takes the large-M 4-bit path whenever it applies
 #ifndef INC_GEMM_DEFAULT_D2R
-#define INC_GEMM_DEFAULT_D2R 0
+#define INC_GEMM_DEFAULT_D2R 1
 #endif
 #ifndef INC_GEMM_DEFAULT_PC
 #define INC_GEMM_DEFAULT_PC 1
@@ -2017,7 +2017,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
       if (bf) splitk_slab_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
       else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
     }
-  } else if (big_ok && (K % 128) == 0 && (g_shift == -1 || g_shift >= 6) && ((dbg == 0 && INC_GEMM_DEFAULT_D2R) || (dbg >= 90 && dbg <= 99))) {
+  } else if (big_ok && (K % 128) == 0 && (g_shift == -1 || g_shift >= 6) && (N % 2) == 0 && ((dbg == 0 && INC_GEMM_DEFAULT_D2R) || (dbg >= 90 && dbg <= 99))) {
     // weights direct to registers (gemm_d2r.hip): four waves, one per SIMD, no dequantised tile in LDS
     const int y_vec_ok = (((N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0)) ? 1 : 0) |
                          (((N % 8 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0)) ? 2 : 0);
@@ -2029,8 +2029,8 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
         part = (float*)((char*)workspace + WS_COUNTER_BYTES);
       else { splits = 1; steps = (int)(K / TK); }
     }
-    static const int d2r_abl[10] = {0, 0, 1, 4, 8, 12, 16, 32, 61, 125};  // harness flags 90..99 (91: three x stages)
-    const int abl = dbg >= 90 ? (dbg == 99 ? 125 : d2r_abl[dbg - 90]) : 0;
+    static const int d2r_abl[10] = {0, 0, 4, 8, 12, 76, 128, 0, 0, 0};  // harness flags 90..96 (91: three x stages; 92..96 timing-only)
+    const int abl = dbg >= 90 ? d2r_abl[dbg - 90] : 0;
     (void)inc_launch_woq_gemm_d2r(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps, splits, bf, dbg == 91 ? 3 : 4, abl, s);
     if (part) {
       int64_t rb = ceil_div64(M * N / 4, 256);

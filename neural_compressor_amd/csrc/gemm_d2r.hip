@@ -26,6 +26,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 constexpr int D2R_THREADS = 256;
 constexpr int D2R_CPITCH = TN * 2 + 16;  // epilogue image of the bf16 tile in LDS: 528-byte rows
 
@@ -77,8 +78,7 @@ __device__ __forceinline__ void acc_zero() {
   static_for<0, 256>([&](auto R) { acc_zero<R.value>(); })
 #define INC_SB() __builtin_amdgcn_sched_barrier(0)
 
-// ABL (harness build only, timing-only, WRONG results): bit 0 no dequant arithmetic, 2 no x LDS-DMA, 3 no W loads,
-// 4 no fragment reads, 5 no MFMA, 6 no per-step barrier, 7 no epilogue stores
+// ABL (harness build only, timing-only, WRONG results): bit 2 no x LDS-DMA, 3 no W loads, 6 no per-step barrier, 7 no epilogue stores
 template <bool IS_BF16, int NS, int ABL>
 __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     int64_t K, int64_t NW, int g_shift, int y_vec_ok, float* __restrict__ partial, int steps_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = NS - 1;                   // the x DMA runs D steps ahead
-  constexpr int VM_STEADY = D >= 3 ? 28 : 20;  // see "counted waits" below
+  constexpr int VM_STEADY = D >= 3 ? 22 : 14;  // see "counted waits" below
   const int tiles_n = (int)((N + TN - 1) / TN);
   const int tiles_m = (int)((M + TM - 1) / TM);
   const int nwg = tiles_m * tiles_n;
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
   const uint32_t dma_lds0 = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
 #define INC_D2R_DMA(I)                                                                                                        \
   if constexpr ((ABL & 4) == 0) {                                                                                             \
-    /* M0 = LDS base of the piece; s_nop 4 covers M0 -> LDS-DMA and a freshly written scalar base */                          \
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(avoff[I]), "s"(xptr), "s"(dma_lds0 + dma_off), "i"((I)*1024) : "memory", "scc"); \
+    /* M0 = LDS base of the piece (s_nop 0: M0 write -> LDS-DMA); xptr was advanced and pinned a sub-region earlier */                          \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(avoff[I]), "s"(xptr), "s"(dma_lds0 + dma_off), "i"((I)*1024) : "memory", "scc"); \
   }
   const uint16_t* const xbase = xptr;
   auto advance_x = [&]() {  // scalar arithmetic only (no branch): the tile index saturates at the last tile
@@ -137,18 +137,21 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     asm volatile("" : "+s"(xptr), "+s"(dma_off), "+s"(xt));  // computed HERE, in this slot (the compiler would sink it to its first use)
   };
 
-  // ---- packed words: this lane's A operands.  Fragment (nf, kk): column n0 + 64 wave + 32 nf + (lane & 31), k-octet 2 kk + (lane >> 5)
-  uint32_t wvoff[8], svoff[2], zvoff[2];  // wvoff[2 kk + nf]
+  // ---- packed words: this lane's A operands.  Accumulator row r = lane & 31 of fragment nf IS column n0 + 64 wave + 2 r + nf: the
+  // lane's two columns are adjacent in memory, so ONE 8-byte request fetches the words of both fragments for a k-octet (2 kk +
+  // (lane >> 5)), one dword both fp16 scales, one dword the zero-point word of both -- 6 requests per step instead of 12.  (Which
+  // columns a wave's MFMA rows stand for is free: the epilogue writes them where they belong.)
+  uint32_t wvoff[4], svoff, zvoff;  // wvoff[kk]
   int zshift[2];
+  {
+    int64_t ncol = n0 + wave * 64 + 2 * (lane & 31);
+    if (ncol > N - 2) ncol = N - 2;  // N is even (launcher); columns past N are computed from valid words and never stored
 #pragma unroll
-  for (int nf = 0; nf < 2; ++nf) {
-    int64_t ncol = n0 + wave * 64 + nf * 32 + (lane & 31);
-    if (ncol > N - 1) ncol = N - 1;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) wvoff[2 * kk + nf] = (uint32_t)((((int64_t)(2 * kk + (lane >> 5))) * N + ncol) * 4);
-    svoff[nf] = (uint32_t)(ncol * 2);
-    zvoff[nf] = (uint32_t)((ncol / 8) * 4);
-    zshift[nf] = 4 * (int)(ncol % 8);
+    for (int kk = 0; kk < 4; ++kk) wvoff[kk] = (uint32_t)((((int64_t)(2 * kk + (lane >> 5))) * N + ncol) * 4);
+    svoff = (uint32_t)(ncol * 2);
+    zvoff = (uint32_t)((ncol / 8) * 4);
+    zshift[0] = 4 * (int)(ncol % 8);
+    zshift[1] = zshift[0] + 4;
   }
   // running pointers of the NEXT register loads (tile `wt`, clamped at the last tile) and of its group's parameters
   const uint32_t* wptr = qweight + (int64_t)kbase * (TK / 8) * N;
@@ -162,148 +165,215 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
   const uint32_t* const wbase = wptr;
   const int64_t wstride = (int64_t)(TK / 8) * N;
   const int gsh = g_shift >= 6 ? g_shift - 6 : -1;  // tiles per group = 1 << gsh; -1: a single group
+  uint32_t gi_ = 0;
   const uint32_t wstride32 = (uint32_t)wstride, n32 = (uint32_t)N, nw32 = (uint32_t)NW;  // every offset below is < 2^31 elements (inc_woq_gemm checks)
-  auto advance_w = [&]() {  // scalar arithmetic only (no branch)
-    asm volatile("" : "+s"(wt));
-    wt = min(wt + 1, nk - 1);
-    wptr = wbase + (uint32_t)wt * wstride32;
-    const uint32_t gi = gsh >= 0 ? (uint32_t)((kbase + wt) >> gsh) - (uint32_t)g0base : 0u;
-    sptr = sbase + gi * n32;
-    zptr = zbase + gi * nw32;
-    asm volatile("" : "+s"(wptr), "+s"(sptr), "+s"(zptr), "+s"(wt));  // see advance_x
+  auto advance_w = [&](int part) {  // scalar arithmetic only (no branch), in three small pieces for three gaps of the step
+    if (part == 0) {
+      asm volatile("" : "+s"(wt));
+      wt = min(wt + 1, nk - 1);
+      wptr = wbase + (uint32_t)wt * wstride32;
+      asm volatile("" : "+s"(wptr), "+s"(wt));  // see advance_x
+    } else if (part == 1) {
+      gi_ = gsh >= 0 ? (uint32_t)((kbase + wt) >> gsh) - (uint32_t)g0base : 0u;
+      sptr = sbase + gi_ * n32;
+      asm volatile("" : "+s"(sptr), "+s"(gi_));
+    } else {
+      asm volatile("" : "+s"(gi_));
+      zptr = zbase + gi_ * nw32;
+      asm volatile("" : "+s"(zptr));
+    }
   };
-  uint32_t W[3][8], SC[3][2], ZW[3][2];  // [tile % 3][2 kk + nf]
-  // the step's 12 register loads as three requests of four: part 0 = words of kk 0, 1; part 1 = kk 2, 3; part 2 = scales + zero words
+  u32x2 W[3][4];            // [tile % 3][kk]: .x = word of fragment 0, .y = fragment 1
+  uint32_t SC[3], ZW[3];    // both fp16 scales / the zero-point word of the lane's two columns
+  // the step's 6 register loads as three requests of two: part 0 = words of kk 0, 1; part 1 = kk 2, 3; part 2 = scales + zero word.
+  // No s_nop in front: the pointers were advanced (and pinned) a sub-region earlier.
 #define INC_D2R_LOADW(SET, PART)                                                                                                   \
   if constexpr ((ABL & 8) != 0) {                                                                                                  \
-    asm volatile("" : "=v"(W[SET][4 * (PART)]), "=v"(W[SET][4 * (PART) + 1]), "=v"(W[SET][4 * (PART) + 2]), "=v"(W[SET][4 * (PART) + 3])); \
+    asm volatile("" : "=v"(W[SET][2 * (PART)]), "=v"(W[SET][2 * (PART) + 1]));                                                     \
   } else {                                                                                                                         \
     asm volatile(                                                                                                                  \
-        "s_nop 4\n\t"                                                                                                              \
-        "global_load_dword %0, %4, %8\n\t"                                                                                         \
-        "global_load_dword %1, %5, %8\n\t"                                                                                         \
-        "global_load_dword %2, %6, %8\n\t"                                                                                         \
-        "global_load_dword %3, %7, %8"                                                                                             \
-        : "=&v"(W[SET][4 * (PART)]), "=&v"(W[SET][4 * (PART) + 1]), "=&v"(W[SET][4 * (PART) + 2]), "=&v"(W[SET][4 * (PART) + 3])   \
-        : "v"(wvoff[4 * (PART)]), "v"(wvoff[4 * (PART) + 1]), "v"(wvoff[4 * (PART) + 2]), "v"(wvoff[4 * (PART) + 3]), "s"(wptr)    \
+        "global_load_dwordx2 %0, %2, %4\n\t"                                                                                       \
+        "global_load_dwordx2 %1, %3, %4"                                                                                           \
+        : "=&v"(W[SET][2 * (PART)]), "=&v"(W[SET][2 * (PART) + 1])                                                                 \
+        : "v"(wvoff[2 * (PART)]), "v"(wvoff[2 * (PART) + 1]), "s"(wptr)                                                            \
         : "memory");                                                                                                               \
   }
 #define INC_D2R_LOADP(SET)                                                                                                         \
   if constexpr ((ABL & 8) != 0) {                                                                                                  \
-    asm volatile("" : "=v"(SC[SET][0]), "=v"(SC[SET][1]), "=v"(ZW[SET][0]), "=v"(ZW[SET][1]));                                     \
+    asm volatile("" : "=v"(SC[SET]), "=v"(ZW[SET]));                                                                               \
   } else {                                                                                                                         \
     asm volatile(                                                                                                                  \
-        "s_nop 4\n\t"                                                                                                              \
-        "global_load_ushort %0, %4, %8\n\t"                                                                                        \
-        "global_load_ushort %1, %5, %8\n\t"                                                                                        \
-        "global_load_dword %2, %6, %9\n\t"                                                                                         \
-        "global_load_dword %3, %7, %9"                                                                                             \
-        : "=&v"(SC[SET][0]), "=&v"(SC[SET][1]), "=&v"(ZW[SET][0]), "=&v"(ZW[SET][1])                                               \
-        : "v"(svoff[0]), "v"(svoff[1]), "v"(zvoff[0]), "v"(zvoff[1]), "s"(sptr), "s"(zptr)                                         \
+        "global_load_dword %0, %2, %4\n\t"                                                                                         \
+        "global_load_dword %1, %3, %5"                                                                                             \
+        : "=&v"(SC[SET]), "=&v"(ZW[SET])                                                                                           \
+        : "v"(svoff), "v"(zvoff), "s"(sptr), "s"(zptr)                                                                             \
         : "memory");                                                                                                               \
   }
-  // counted waits.  Program order of a step's 20 requests: 12 register loads (tile t+2), then 8 DMA pieces (tile t+D).  At the
+  // counted waits.  Program order of a step's 14 requests: 6 register loads (tile t+2), then 8 DMA pieces (tile t+D).  At the
   // wait of step t the words of tile t+1 (issued in step t-1) and the x pieces of tile t+1 (issued in step t+1-D) must be
-  // back: D = 2 -> everything up to step t-1, this step's 20 stay in flight; D >= 3 -> step t-1's 8 pieces stay in flight too.
+  // back: D = 2 -> everything up to step t-1, this step's 14 stay in flight; D >= 3 -> step t-1's 8 pieces stay in flight too.
 #define INC_D2R_WAIT(SET, NN)                                                                                                       \
   if constexpr ((ABL & 12) == 12)                                                                                                   \
-    asm volatile("" : "+v"(W[SET][0]), "+v"(W[SET][1]), "+v"(W[SET][2]), "+v"(W[SET][3]), "+v"(W[SET][4]), "+v"(W[SET][5]), "+v"(W[SET][6]), \
-                 "+v"(W[SET][7]), "+v"(SC[SET][0]), "+v"(SC[SET][1]), "+v"(ZW[SET][0]), "+v"(ZW[SET][1]) : : "memory");             \
+    asm volatile("" : "+v"(W[SET][0]), "+v"(W[SET][1]), "+v"(W[SET][2]), "+v"(W[SET][3]), "+v"(SC[SET]), "+v"(ZW[SET]) : : "memory"); \
   else                                                                                                                              \
-    asm volatile("s_waitcnt vmcnt(%12)"                                                                                             \
-                 : "+v"(W[SET][0]), "+v"(W[SET][1]), "+v"(W[SET][2]), "+v"(W[SET][3]), "+v"(W[SET][4]), "+v"(W[SET][5]), "+v"(W[SET][6]), \
-                   "+v"(W[SET][7]), "+v"(SC[SET][0]), "+v"(SC[SET][1]), "+v"(ZW[SET][0]), "+v"(ZW[SET][1])                          \
-                 : "i"(NN)                                                                                                          \
-                 : "memory");
-
-  // ---- dequantisation of one packed word in two halves of three instruction slots each (dequant8's FORM 0 arithmetic, bit-identical):
-  // a slot is what rides behind ONE MFMA.  Temporaries are named so that the slots can be separated by scheduling fences.
-  float sc[2], nzs[2];
-  uint32_t mlo, mhi;
-  f32x2 cq, dq;
-  float f0, f1, f2, f3;
-  // sched_barrier fences only bind the machine scheduler; instruction selection and the IR passes before it (SLP vectoriser, sinking)
-  // move pure arithmetic freely.  Every slot therefore ends by passing what it produced through an empty volatile asm: volatile
-  // statements (the MFMAs among them) keep their order, so a slot's arithmetic is bracketed between the MFMA in front of it (its
-  // inputs were pinned by the previous slot) and the one behind it.
-#define INC_PIN1(a) asm volatile("" : "+v"(a))
-#define INC_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#define INC_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
-#define INC_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-  auto dqa = [&](int slot, uint32_t w, int nf, uint4& o) {  // half A: k 0..3 of the word -> o.x, o.y
-    if constexpr ((ABL & 1) != 0) {
-      if (slot == 0) { mlo = w; mhi = w ^ __float_as_uint(sc[nf]); INC_PIN2(mlo, mhi); }
-      if (slot == 2) { o.x = mlo; o.y = mhi; INC_PIN2(o.x, o.y); }
-      return;
-    }
-    if (slot == 0) { INC_PIN1(w); mlo = w & 0x0F0F0F0Fu; mhi = (w >> 4) & 0x0F0F0F0Fu; cq = __builtin_amdgcn_cvt_pk_f32_fp8((int)mlo, false); INC_PIN3(mlo, mhi, cq); }
-    if (slot == 1) { dq = __builtin_amdgcn_cvt_pk_f32_fp8((int)mhi, false); f0 = fma_single(cq[0], sc[nf], nzs[nf]); f2 = fma_single(cq[1], sc[nf], nzs[nf]); INC_PIN3(dq, f0, f2); }
-    if (slot == 2) { f1 = fma_single(dq[0], sc[nf], nzs[nf]); f3 = fma_single(dq[1], sc[nf], nzs[nf]); o.x = cvt_pair<IS_BF16>(f0, f1); o.y = cvt_pair<IS_BF16>(f2, f3); INC_PIN2(o.x, o.y); }
-  };
-  auto dqb = [&](int slot, int nf, uint4& o) {  // half B: k 4..7 -> o.z, o.w (masks left by half A)
-    if constexpr ((ABL & 1) != 0) {
-      if (slot == 2) { o.z = mlo ^ __float_as_uint(nzs[nf]); o.w = mhi; INC_PIN2(o.z, o.w); }
-      return;
-    }
-    if (slot == 0) { cq = __builtin_amdgcn_cvt_pk_f32_fp8((int)mlo, true); dq = __builtin_amdgcn_cvt_pk_f32_fp8((int)mhi, true); f0 = fma_single(cq[0], sc[nf], nzs[nf]); INC_PIN3(cq, dq, f0); }
-    if (slot == 1) { f1 = fma_single(dq[0], sc[nf], nzs[nf]); f2 = fma_single(cq[1], sc[nf], nzs[nf]); f3 = fma_single(dq[1], sc[nf], nzs[nf]); INC_PIN3(f1, f2, f3); }
-    if (slot == 2) { o.z = cvt_pair<IS_BF16>(f0, f1); o.w = cvt_pair<IS_BF16>(f2, f3); INC_PIN2(o.z, o.w); }
-  };
-  // group parameters of column nf from register set `set`, in two slots
-  float gp_s0;
-  uint32_t gp_z;
-  auto gpar = [&](int slot, int set, int nf) {
-    if (slot == 0) {
-      INC_PIN2(SC[set][nf], ZW[set][nf]);
-      gp_s0 = f16_bits_to_f32((uint16_t)SC[set][nf]);
-      gp_z = ((ZW[set][nf] >> zshift[nf]) & 15u) + 1u;  // modules.py:407-410 (stored zp - 1; wraps above 15)
-      INC_PIN2(gp_s0, gp_z);
-    } else {
-      gp_z = gp_z > 15u ? 0u : gp_z;
-      nzs[nf] = -(float)gp_z * gp_s0;
-      sc[nf] = gp_s0 * inv_u;
-      INC_PIN2(nzs[nf], sc[nf]);
-    }
-  };
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(W[SET][0]), "+v"(W[SET][1]), "+v"(W[SET][2]), "+v"(W[SET][3]), "+v"(SC[SET]), "+v"(ZW[SET]) : "i"(NN) : "memory");
 
   // ---- x fragments: B operand (mf): rows 32 mf + (lane & 31), 16-byte chunk (2 kk + (lane >> 5)) ^ ((row >> 1) & 7) --------------
   const int a_sw = ((lane & 31) >> 1) & 7, a_hi = lane >> 5;
-  const char* const xrow = smem + (lane & 31) * 128;
-  uint32_t xchunk[4];
+  uint32_t xaddr[4];  // LDS byte address of this lane's chunk of row lane & 31, stage 0, per k16 group
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) xchunk[kk] = (uint32_t)(((2 * kk + a_hi) ^ a_sw) << 4);
+  for (int kk = 0; kk < 4; ++kk) xaddr[kk] = lds0 + (uint32_t)((lane & 31) * 128) + (uint32_t)(((2 * kk + a_hi) ^ a_sw) << 4);
   uint32_t rd_off = 0, rd_nxt = 0;  // LDS stage of the tile being multiplied / of the next one
-  auto read_x = [&](uint32_t stage_off, int kk, int mf, uint4& dst) {
-    if constexpr ((ABL & 16) != 0) { asm volatile("" : "=v"(dst.x), "=v"(dst.y), "=v"(dst.z), "=v"(dst.w)); return; }
-    dst = *reinterpret_cast<const uint4*>(xrow + stage_off + mf * 4096 + xchunk[kk]);
-  };
+  u32x4 X[2][8];
+  uint32_t xa_;
+#define INC_PIN1(a) asm volatile("" : "+v"(a))
+#define INC_D2R_XADDR(ST, KK) xa_ = xaddr[KK] + (ST); INC_PIN1(xa_)
+#define INC_LGKM(NN) asm volatile("s_waitcnt lgkmcnt(%0)" : : "i"(NN) : "memory")
 
   // The 256 accumulators are the AGPR half of the SIMD's register file, addressed LITERALLY (a[16 j : 16 j + 15] for accumulator
   // j = 8 nf + mf) by asm statements only: the compiler never sees them as values, so it cannot shuffle them between the two halves
-  // of the file (it did: 1400 spilled registers with `f32x16 acc[2][8]`), and the volatile asm MFMAs keep their order against the
-  // requests, reads and waits around them.  The first statement clobbers a0..a255, which makes the kernel descriptor allocate
-  // them; audit after every edit: no compiler-generated v_accvgpr_* and no scratch in the ISA (tools/audit_d2r.py).
-  uint4 X[2][8], Wf[2][2];
+  // of the file (it did: 1400 spilled registers with `f32x16 acc[2][8]`).  The first statement clobbers a0..a255, which makes the
+  // kernel descriptor allocate them; audit after every edit: no compiler-generated v_accvgpr_* and no scratch (tools/audit_d2r.py).
+  uint4 Wf[2][2];
+  float sc[2], nzs[2];   // per fragment: scale / 2^-9 (the fp8 decoder's unit) and -zero * scale
+  uint32_t mlo, mhi;     // nibble masks of the word being dequantised (half A leaves them for half B)
+  float gp_s0;           // group-parameter temporaries that cross a sub-region
+  uint32_t gp_z;
   INC_D2R_ZERO_ACC();
-#define INC_D2R_MMA(CUR, NF, MF)                                                                                                   \
-  {                                                                                                                                \
-    const u32x4 av_ = {Wf[CUR][NF].x, Wf[CUR][NF].y, Wf[CUR][NF].z, Wf[CUR][NF].w};                                               \
-    const u32x4 bv_ = {X[CUR][MF].x, X[CUR][MF].y, X[CUR][MF].z, X[CUR][MF].w};                                                   \
-    if constexpr ((ABL & 32) != 0) asm volatile("" : : "v"(av_), "v"(bv_));                                                       \
-    else if constexpr (IS_BF16)                                                                                                    \
-      asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(av_), "v"(bv_), "i"(16 * (8 * (NF) + (MF))), "i"(16 * (8 * (NF) + (MF)) + 15)); \
-    else                                                                                                                           \
-      asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(av_), "v"(bv_), "i"(16 * (8 * (NF) + (MF))), "i"(16 * (8 * (NF) + (MF)) + 15)); \
+
+  // ==== the K-loop's building block: ONE asm statement per sub-region = 4 MFMAs, each followed by its slot ====================
+  // A single wave per SIMD issues in order, so every instruction between two MFMAs is paid for unless there are at most ~5 of
+  // them (MI355X_MICROARCH.md); with C++ slots the compiler added a wait-state pad or an s_waitcnt to almost every one.  Inside a
+  // statement nothing is added.  Temporaries that live inside one statement are literal registers v246..v255 (clobbered, so the
+  // compiler keeps nothing there): cq = v[252:253], dq = v[254:255] (the two halves of a packed fp8 conversion cannot be named
+  // through an operand), f0..f3 = v248..v251, f16 conversion temporaries v246, v247.
+  // Arithmetic = dequant8's FORM 0 (gemm_common.hpp), instruction for instruction: bit-identical to inc_woq_dequant.
+  // accumulator I of the sub-region = a[16 (J + I) : 16 (J + I) + 15], J = %c[aj] (the assembler evaluates the expressions)
+#define D2R_MFMA(MN, I) MN " a[%c[aj]+" #I "*16:%c[aj]+" #I "*16+15], %[wf], %[x" #I "], a[%c[aj]+" #I "*16:%c[aj]+" #I "*16+15]\n\t"
+#define D2R_RD(I) "ds_read_b128 %[r" #I "], %[xa] offset:%c[o" #I "]\n\t"
+  // half A of word %[w]: k 0..3 -> %[oa], %[ob]; leaves the masks in %[mlo], %[mhi]
+#define D2R_DQA0 "v_and_b32 %[mlo], 0xf0f0f0f, %[w]\n\tv_lshrrev_b32 %[mhi], 4, %[w]\n\tv_cvt_pk_f32_fp8 v[252:253], %[mlo]\n\tv_and_b32 %[mhi], 0xf0f0f0f, %[mhi]\n\t"
+#define D2R_DQA1 "v_cvt_pk_f32_fp8 v[254:255], %[mhi]\n\tv_fma_f32 v248, v252, %[sc], %[nz]\n\tv_fma_f32 v250, v253, %[sc], %[nz]\n\t"
+#define D2R_DQA2(CVTP) "v_fma_f32 v249, v254, %[sc], %[nz]\n\tv_fma_f32 v251, v255, %[sc], %[nz]\n\t" CVTP("%[oa]", "v248", "v249") CVTP("%[ob]", "v250", "v251")
+  // half B: k 4..7 of the masked word -> %[oa], %[ob]
+#define D2R_DQB0 "v_cvt_pk_f32_fp8_sdwa v[252:253], %[mlo] src0_sel:WORD_1\n\tv_cvt_pk_f32_fp8_sdwa v[254:255], %[mhi] src0_sel:WORD_1\n\t"
+#define D2R_DQB1 "v_fma_f32 v248, v252, %[sc], %[nz]\n\tv_fma_f32 v249, v254, %[sc], %[nz]\n\tv_fma_f32 v250, v253, %[sc], %[nz]\n\t"
+#define D2R_DQB2(CVTP) "v_fma_f32 v251, v255, %[sc], %[nz]\n\t" CVTP("%[oa]", "v248", "v249") CVTP("%[ob]", "v250", "v251")
+  // group parameters (modules.py:407-410: the stored zero point is zp - 1 and wraps above 15).  GP0 extracts the fp16 scale (low /
+  // high half of the pair's dword) and zero + 1; GP1 finishes: zero > 15 -> 0, %[nz] = -zero * scale, %[sc] = scale * 2^9
+#define D2R_GP0_LO "v_cvt_f32_f16 %[gs], %[scw]\n\tv_bfe_u32 %[gz], %[zw], %[zsh], 4\n\tv_add_u32 %[gz], 1, %[gz]\n\t"
+#define D2R_GP0_HI "v_cvt_f32_f16_sdwa %[gs], %[scw] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\tv_bfe_u32 %[gz], %[zw], %[zsh], 4\n\tv_add_u32 %[gz], 1, %[gz]\n\t"
+#define D2R_GP1 "v_cmp_gt_u32 vcc, 16, %[gz]\n\tv_cndmask_b32 %[gz], 0, %[gz], vcc\n\tv_cvt_f32_u32 %[gz], %[gz]\n\tv_mul_f32_e64 %[nz], %[gs], -%[gz]\n\tv_mul_f32 %[sc], %[iu], %[gs]\n\t"
+#define D2R_CVTP_BF16(D, A, B) "v_cvt_pk_bf16_f32 " D ", " A ", " B "\n\t"
+#define D2R_CVTP_F16(D, A, B) "v_cvt_f16_f32 v246, " A "\n\tv_cvt_f16_f32 v247, " B "\n\tv_pack_b32_f16 " D ", v246, v247\n\t"
+#define D2R_TMPS "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+  // inputs every sub-region has: the W fragment (A operand), four x fragments (B operands), the first accumulator's index
+#define D2R_IN(CUR, Q)                                                                                                            \
+  [wf] "v"(wf_), [x0] "v"(X[CUR][4 * ((Q)&1)]), [x1] "v"(X[CUR][4 * ((Q)&1) + 1]), [x2] "v"(X[CUR][4 * ((Q)&1) + 2]),              \
+      [x3] "v"(X[CUR][4 * ((Q)&1) + 3]), [aj] "i"(16 * (8 * ((Q) >> 1) + 4 * ((Q)&1)))
+#define D2R_WF(CUR, Q) const u32x4 wf_ = {Wf[CUR][(Q) >> 1].x, Wf[CUR][(Q) >> 1].y, Wf[CUR][(Q) >> 1].z, Wf[CUR][(Q) >> 1].w};
+#define D2R_MN_BF16 "v_mfma_f32_32x32x16_bf16"
+#define D2R_MN_F16 "v_mfma_f32_32x32x16_f16"
+
+  // kind A (sub-regions 0 / 2 of groups 0..2): reads x fragments MA, MA + 1 of set NXT; half A of WORD -> Wf[NXT][NF].x/.y
+#define D2R_ASM_A(MN, CVTP, CUR, Q, NXT, MA, NF)                                                                                  \
+  asm volatile(D2R_MFMA(MN, 0) D2R_RD(0) D2R_DQA0 D2R_MFMA(MN, 1) D2R_RD(1) D2R_DQA1 D2R_MFMA(MN, 2) D2R_DQA2(CVTP) D2R_MFMA(MN, 3) \
+               : [r0] "=&v"(X[NXT][MA]), [r1] "=&v"(X[NXT][(MA) + 1]), [oa] "=&v"(Wf[NXT][NF].x), [ob] "=&v"(Wf[NXT][NF].y),        \
+                 [mlo] "=&v"(mlo), [mhi] "=&v"(mhi)                                                                                \
+               : D2R_IN(CUR, Q), [xa] "v"(xa_), [w] "v"(w_), [sc] "v"(sc[NF]), [nz] "v"(nzs[NF]), [o0] "i"((MA)*4096),              \
+                 [o1] "i"(((MA) + 1) * 4096)                                                                                       \
+               : D2R_TMPS)
+#define INC_D2R_SUB_A(CUR, Q, NXT, MA, WORD, NF)                                                                                  \
+  {                                                                                                                               \
+    D2R_WF(CUR, Q)                                                                                                                \
+    const uint32_t w_ = (WORD);                                                                                                   \
+    if constexpr (IS_BF16) D2R_ASM_A(D2R_MN_BF16, D2R_CVTP_BF16, CUR, Q, NXT, MA, NF);                                            \
+    else D2R_ASM_A(D2R_MN_F16, D2R_CVTP_F16, CUR, Q, NXT, MA, NF);                                                                \
+  }
+  // kind B (sub-regions 1 / 3): reads x fragments MA, MA + 1 of set NXT; half B of the masked word -> Wf[NXT][NF].z/.w
+#define D2R_ASM_B(MN, CVTP, CUR, Q, NXT, MA, NF)                                                                                  \
+  asm volatile(D2R_MFMA(MN, 0) D2R_RD(0) D2R_DQB0 D2R_MFMA(MN, 1) D2R_RD(1) D2R_DQB1 D2R_MFMA(MN, 2) D2R_DQB2(CVTP) D2R_MFMA(MN, 3) \
+               : [r0] "=&v"(X[NXT][MA]), [r1] "=&v"(X[NXT][(MA) + 1]), [oa] "=&v"(Wf[NXT][NF].z), [ob] "=&v"(Wf[NXT][NF].w)         \
+               : D2R_IN(CUR, Q), [xa] "v"(xa_), [mlo] "v"(mlo), [mhi] "v"(mhi), [sc] "v"(sc[NF]), [nz] "v"(nzs[NF]),               \
+                 [o0] "i"((MA)*4096), [o1] "i"(((MA) + 1) * 4096)                                                                  \
+               : D2R_TMPS)
+#define INC_D2R_SUB_B(CUR, Q, NXT, MA, NF)                                                                                        \
+  {                                                                                                                               \
+    D2R_WF(CUR, Q)                                                                                                                \
+    if constexpr (IS_BF16) D2R_ASM_B(D2R_MN_BF16, D2R_CVTP_BF16, CUR, Q, NXT, MA, NF);                                            \
+    else D2R_ASM_B(D2R_MN_F16, D2R_CVTP_F16, CUR, Q, NXT, MA, NF);                                                                \
+  }
+  // kind B + the first half of fragment 0's NEXT group parameters behind the last MFMA (group 2's last sub-region)
+#define D2R_ASM_BG(MN, CVTP, CUR, Q, NXT, MA, NF, SET)                                                                            \
+  asm volatile(D2R_MFMA(MN, 0) D2R_RD(0) D2R_DQB0 D2R_MFMA(MN, 1) D2R_RD(1) D2R_DQB1 D2R_MFMA(MN, 2) D2R_DQB2(CVTP) D2R_MFMA(MN, 3) \
+                   D2R_GP0_LO                                                                                                     \
+               : [r0] "=&v"(X[NXT][MA]), [r1] "=&v"(X[NXT][(MA) + 1]), [oa] "=&v"(Wf[NXT][NF].z), [ob] "=&v"(Wf[NXT][NF].w),        \
+                 [gs] "=&v"(gp_s0), [gz] "=&v"(gp_z)                                                                               \
+               : D2R_IN(CUR, Q), [xa] "v"(xa_), [mlo] "v"(mlo), [mhi] "v"(mhi), [sc] "v"(sc[NF]), [nz] "v"(nzs[NF]),               \
+                 [o0] "i"((MA)*4096), [o1] "i"(((MA) + 1) * 4096), [scw] "v"(SC[SET]), [zw] "v"(ZW[SET]), [zsh] "v"(zshift[0])      \
+               : D2R_TMPS)
+#define INC_D2R_SUB_BG(CUR, Q, NXT, MA, NF, SET)                                                                                  \
+  {                                                                                                                               \
+    D2R_WF(CUR, Q)                                                                                                                \
+    if constexpr (IS_BF16) D2R_ASM_BG(D2R_MN_BF16, D2R_CVTP_BF16, CUR, Q, NXT, MA, NF, SET);                                      \
+    else D2R_ASM_BG(D2R_MN_F16, D2R_CVTP_F16, CUR, Q, NXT, MA, NF, SET);                                                          \
+  }
+  // group 3, sub-region 0 (no reads: the next stage is not visible yet): fragment 0's new parameters, then half A of tile t+1's
+  // first word of fragment 0 -> Wf[0][0].x/.y
+#define D2R_ASM_G0(MN, CVTP, SET)                                                                                                 \
+  asm volatile(D2R_MFMA(MN, 0) D2R_GP1 D2R_MFMA(MN, 1) D2R_DQA0 D2R_MFMA(MN, 2) D2R_DQA1 D2R_MFMA(MN, 3) D2R_DQA2(CVTP)            \
+               : [oa] "=&v"(Wf[0][0].x), [ob] "=&v"(Wf[0][0].y), [mlo] "=&v"(mlo), [mhi] "=&v"(mhi), [sc] "=&v"(sc[0]),             \
+                 [nz] "=&v"(nzs[0]), [gz] "+v"(gp_z)                                                                               \
+               : D2R_IN(1, 0), [w] "v"(w_), [gs] "v"(gp_s0), [iu] "v"(inv_u)                                                       \
+               : D2R_TMPS, "vcc")
+#define INC_D2R_SUB_G0(SET)                                                                                                       \
+  {                                                                                                                               \
+    D2R_WF(1, 0)                                                                                                                  \
+    const uint32_t w_ = W[SET][0].x;                                                                                              \
+    if constexpr (IS_BF16) D2R_ASM_G0(D2R_MN_BF16, D2R_CVTP_BF16, SET);                                                           \
+    else D2R_ASM_G0(D2R_MN_F16, D2R_CVTP_F16, SET);                                                                               \
+  }
+  // group 3, sub-region 1 (behind the barrier): x fragments 0..2 of the next stage, half B of fragment 0's word, first half of
+  // fragment 1's parameters
+#define D2R_ASM_G1(MN, CVTP, SET)                                                                                                 \
+  asm volatile(D2R_MFMA(MN, 0) D2R_RD(0) D2R_DQB0 D2R_MFMA(MN, 1) D2R_RD(1) D2R_DQB1 D2R_MFMA(MN, 2) D2R_RD(2) D2R_DQB2(CVTP)      \
+                   D2R_MFMA(MN, 3) D2R_GP0_HI                                                                                     \
+               : [r0] "=&v"(X[0][0]), [r1] "=&v"(X[0][1]), [r2] "=&v"(X[0][2]), [oa] "=&v"(Wf[0][0].z), [ob] "=&v"(Wf[0][0].w),     \
+                 [gs] "=&v"(gp_s0), [gz] "=&v"(gp_z)                                                                               \
+               : D2R_IN(1, 1), [xa] "v"(xa_), [mlo] "v"(mlo), [mhi] "v"(mhi), [sc] "v"(sc[0]), [nz] "v"(nzs[0]), [o0] "i"(0),       \
+                 [o1] "i"(4096), [o2] "i"(8192), [scw] "v"(SC[SET]), [zw] "v"(ZW[SET]), [zsh] "v"(zshift[1])                       \
+               : D2R_TMPS)
+#define INC_D2R_SUB_G1(SET)                                                                                                       \
+  {                                                                                                                               \
+    D2R_WF(1, 1)                                                                                                                  \
+    if constexpr (IS_BF16) D2R_ASM_G1(D2R_MN_BF16, D2R_CVTP_BF16, SET);                                                           \
+    else D2R_ASM_G1(D2R_MN_F16, D2R_CVTP_F16, SET);                                                                               \
+  }
+  // group 3, sub-region 2: x fragments 3..5, fragment 1's new parameters, half A of its first word -> Wf[0][1].x/.y
+#define D2R_ASM_G2(MN, CVTP, SET)                                                                                                 \
+  asm volatile(D2R_MFMA(MN, 0) D2R_RD(0) D2R_GP1 D2R_MFMA(MN, 1) D2R_RD(1) D2R_DQA0 D2R_MFMA(MN, 2) D2R_RD(2) D2R_DQA1            \
+                   D2R_MFMA(MN, 3) D2R_DQA2(CVTP)                                                                                 \
+               : [r0] "=&v"(X[0][3]), [r1] "=&v"(X[0][4]), [r2] "=&v"(X[0][5]), [oa] "=&v"(Wf[0][1].x), [ob] "=&v"(Wf[0][1].y),     \
+                 [mlo] "=&v"(mlo), [mhi] "=&v"(mhi), [sc] "=&v"(sc[1]), [nz] "=&v"(nzs[1]), [gz] "+v"(gp_z)                         \
+               : D2R_IN(1, 2), [xa] "v"(xa_), [w] "v"(w_), [gs] "v"(gp_s0), [iu] "v"(inv_u), [o0] "i"(3 * 4096),                   \
+                 [o1] "i"(4 * 4096), [o2] "i"(5 * 4096)                                                                            \
+               : D2R_TMPS, "vcc")
+#define INC_D2R_SUB_G2(SET)                                                                                                       \
+  {                                                                                                                               \
+    D2R_WF(1, 2)                                                                                                                  \
+    const uint32_t w_ = W[SET][0].y;                                                                                              \
+    if constexpr (IS_BF16) D2R_ASM_G2(D2R_MN_BF16, D2R_CVTP_BF16, SET);                                                           \
+    else D2R_ASM_G2(D2R_MN_F16, D2R_CVTP_F16, SET);                                                                               \
   }
 
   // ---- prologue: words of tiles 0, 1 and x tiles 0 .. D-1 requested; tile 0 complete ---------------------------------------
   INC_D2R_LOADW(0, 0) INC_D2R_LOADW(0, 1) INC_D2R_LOADP(0)
   INC_D2R_DMA(0) INC_D2R_DMA(1) INC_D2R_DMA(2) INC_D2R_DMA(3) INC_D2R_DMA(4) INC_D2R_DMA(5) INC_D2R_DMA(6) INC_D2R_DMA(7)
-  advance_w();
+  advance_w(0); advance_w(1); advance_w(2);
   advance_x();
   INC_SB();
   INC_D2R_LOADW(1, 0) INC_D2R_LOADW(1, 1) INC_D2R_LOADP(1)
-  advance_w();
+  advance_w(0); advance_w(1); advance_w(2);
 #pragma unroll
   for (int d = 1; d < D; ++d) {
     INC_SB();
@@ -311,65 +381,72 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     advance_x();
   }
   INC_SB();
-  INC_D2R_WAIT(0, VM_STEADY)  // outstanding allowed: tile 1's 12 words + (D-1) x 8 pieces = 20 (D = 2) or 28 (D = 3)
+  INC_D2R_WAIT(0, VM_STEADY)  // outstanding allowed: tile 1's 6 requests + (D-1) x 8 pieces = 14 (D = 2) or 22 (D = 3)
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int nf = 0; nf < 2; ++nf) {
-    gpar(0, 0, nf); gpar(1, 0, nf);
-#pragma unroll
-    for (int sl = 0; sl < 3; ++sl) dqa(sl, W[0][nf], nf, Wf[0][nf]);
-#pragma unroll
-    for (int sl = 0; sl < 3; ++sl) dqb(sl, nf, Wf[0][nf]);
+  for (int nf = 0; nf < 2; ++nf) {  // tile 0's parameters and first fragments, in plain C++ (once per tile of the output)
+    const float s0 = f16_bits_to_f32((uint16_t)(nf ? SC[0] >> 16 : SC[0]));
+    uint32_t zz = ((ZW[0] >> zshift[nf]) & 15u) + 1u;
+    zz = zz > 15u ? 0u : zz;
+    nzs[nf] = -(float)zz * s0;
+    sc[nf] = s0 * inv_u;
+    Wf[0][nf] = dequant8<IS_BF16>(nf ? W[0][0].y : W[0][0].x, sc[nf], nzs[nf]);
   }
-#pragma unroll
-  for (int mf = 0; mf < 8; ++mf) read_x(0u, 0, mf, X[0][mf]);
+  INC_D2R_XADDR(0u, 0);
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %8 offset:12288\n\t"
+               "ds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %8 offset:20480\n\tds_read_b128 %6, %8 offset:24576\n\tds_read_b128 %7, %8 offset:28672"
+               : "=&v"(X[0][0]), "=&v"(X[0][1]), "=&v"(X[0][2]), "=&v"(X[0][3]), "=&v"(X[0][4]), "=&v"(X[0][5]), "=&v"(X[0][6]), "=&v"(X[0][7])
+               : "v"(xa_)
+               : "memory");
   INC_SB();
 
-  // One sub-region = 4 MFMAs (accumulators (nf, mb .. mb+3) with nf = Q >> 1, mb = 4 (Q & 1)) of fragment set CUR, each followed by
-  // its slot: S0..S3 are statements (fragment reads of the other set, dequantisation slots, parameter slots), fenced so that every
-  // slot stays behind its MFMA.  PRE is the sub-region's request (register loads, a DMA piece, the counted wait) or empty; the slot
-  // in front of a request (S3) is kept empty so that the request is all that sits between two MFMAs.
-#define INC_D2R_SUB(CUR, Q, PRE, S0, S1, S2, S3)                       \
-  PRE                                                                  \
-  INC_SB();                                                            \
-  INC_D2R_MMA(CUR, (Q) >> 1, 4 * ((Q) & 1) + 0) S0; INC_SB();          \
-  INC_D2R_MMA(CUR, (Q) >> 1, 4 * ((Q) & 1) + 1) S1; INC_SB();          \
-  INC_D2R_MMA(CUR, (Q) >> 1, 4 * ((Q) & 1) + 2) S2; INC_SB();          \
-  INC_D2R_MMA(CUR, (Q) >> 1, 4 * ((Q) & 1) + 3) S3; INC_SB();
-#define INC_NONE (void)0
-  // a group that prepares fragment set NXT (k16 group KK of stage offset ST, words 2 KK + nf of set WS) while it multiplies set CUR
-#define INC_D2R_GROUP(CUR, NXT, ST, KK, WS, P0, P1, P2, P3, E3)                                                                                    \
-  INC_D2R_SUB(CUR, 0, P0, (read_x(ST, KK, 0, X[NXT][0]), dqa(0, W[WS][2 * (KK)], 0, Wf[NXT][0])), (read_x(ST, KK, 1, X[NXT][1]), dqa(1, 0u, 0, Wf[NXT][0])), \
-              dqa(2, 0u, 0, Wf[NXT][0]), INC_NONE)                                                                                                \
-  INC_D2R_SUB(CUR, 1, P1, (read_x(ST, KK, 2, X[NXT][2]), dqb(0, 0, Wf[NXT][0])), (read_x(ST, KK, 3, X[NXT][3]), dqb(1, 0, Wf[NXT][0])),           \
-              dqb(2, 0, Wf[NXT][0]), INC_NONE)                                                                                                    \
-  INC_D2R_SUB(CUR, 2, P2, (read_x(ST, KK, 4, X[NXT][4]), dqa(0, W[WS][2 * (KK) + 1], 1, Wf[NXT][1])), (read_x(ST, KK, 5, X[NXT][5]), dqa(1, 0u, 1, Wf[NXT][1])), \
-              dqa(2, 0u, 1, Wf[NXT][1]), INC_NONE)                                                                                                \
-  INC_D2R_SUB(CUR, 3, P3, (read_x(ST, KK, 6, X[NXT][6]), dqb(0, 1, Wf[NXT][1])), (read_x(ST, KK, 7, X[NXT][7]), dqb(1, 1, Wf[NXT][1])),           \
-              dqb(2, 1, Wf[NXT][1]), E3)
   // One K-step.  `SET` = t % 3 (compile time: register sets); the LDS stages are run-time offsets.
-  //   groups 0..2 (kk = g of tile t): multiply set g & 1, prepare kk = g + 1 of the same stage / register set; their requests:
-  //            group 0: the 12 register loads of tile t+2 and DMA piece 0 of tile t+D; group 1: pieces 1..4; group 2: pieces 5..7 and
-  //            the counted wait for tile t+1 (words + this wave's x pieces); parameters of column 0 behind it
-  //   group 3: parameters of column 1, words kk = 0 of tile t+1; the step's barrier after its first sub-region, then the x fragments
-  //            kk = 0 of the next stage; the running pointers advance in its last slot
-#define INC_D2R_STEP(SET)                                                                                                       \
-  {                                                                                                                             \
-    constexpr int s1_ = ((SET) + 1) % 3, s2_ = ((SET) + 2) % 3;                                                                  \
-    rd_nxt = rd_off + T_ASTAGE == NS * T_ASTAGE ? 0u : rd_off + T_ASTAGE;                                                       \
-    INC_D2R_GROUP(0, 1, rd_off, 1, SET, INC_D2R_LOADW(s2_, 0), INC_D2R_LOADW(s2_, 1), INC_D2R_LOADP(s2_), INC_D2R_DMA(0), INC_NONE) \
-    INC_D2R_GROUP(1, 0, rd_off, 2, SET, INC_D2R_DMA(1), INC_D2R_DMA(2), INC_D2R_DMA(3), INC_D2R_DMA(4), INC_NONE)                \
-    INC_D2R_GROUP(0, 1, rd_off, 3, SET, INC_D2R_DMA(5), INC_D2R_DMA(6), INC_D2R_DMA(7), INC_D2R_WAIT(s1_, VM_STEADY), gpar(0, s1_, 0)) \
-    INC_D2R_SUB(1, 0, INC_NONE;, (gpar(1, s1_, 0), dqa(0, W[s1_][0], 0, Wf[0][0])), (dqa(1, 0u, 0, Wf[0][0]), gpar(0, s1_, 1)),  \
-                dqa(2, 0u, 0, Wf[0][0]), advance_x())                                                                           \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                          \
-    if constexpr ((ABL & 64) == 0) __builtin_amdgcn_s_barrier();                                                                \
-    INC_D2R_SUB(1, 1, INC_NONE;, (read_x(rd_nxt, 0, 0, X[0][0]), dqb(0, 0, Wf[0][0])), (read_x(rd_nxt, 0, 1, X[0][1]), dqb(1, 0, Wf[0][0])), \
-                (read_x(rd_nxt, 0, 2, X[0][2]), dqb(2, 0, Wf[0][0])), gpar(1, s1_, 1))                                           \
-    INC_D2R_SUB(1, 2, INC_NONE;, (read_x(rd_nxt, 0, 3, X[0][3]), dqa(0, W[s1_][1], 1, Wf[0][1])), (read_x(rd_nxt, 0, 4, X[0][4]), dqa(1, 0u, 1, Wf[0][1])), \
-                (read_x(rd_nxt, 0, 5, X[0][5]), dqa(2, 0u, 1, Wf[0][1])), advance_w())                                           \
-    INC_D2R_SUB(1, 3, INC_NONE;, (read_x(rd_nxt, 0, 6, X[0][6]), dqb(0, 1, Wf[0][1])), (read_x(rd_nxt, 0, 7, X[0][7]), dqb(1, 1, Wf[0][1])), \
-                dqb(2, 1, Wf[0][1]), rd_off = rd_nxt)                                                                           \
+  //   groups 0..2 (kk = g of tile t): multiply fragment set g & 1, prepare kk = g + 1 of the same stage / register set.  Between the
+  //            sub-regions sit the step's requests: group 0: the 6 register loads of tile t+2 and DMA piece 0 of tile t+D; group 1:
+  //            pieces 1..4; group 2: pieces 5..7 and the counted wait for tile t+1 (words + this wave's x pieces)
+  //   group 3: new group parameters, words kk = 0 of tile t+1; the step's barrier after its first sub-region (every fragment read of
+  //            this stage has returned: lgkmcnt(0)), then the x fragments kk = 0 of the next stage; the running pointers advance
+  //   LDS returns in order: at a group's first MFMA x fragments 0..3 of its set must be back (the last four requests may still
+  //   be out: lgkmcnt(4)); at its fifth MFMA fragments 4..7 (only the two reads sub-region 0 has just issued: lgkmcnt(2)).
+#define INC_D2R_GROUP(CUR, NXT, KK, SET, P0, P1, P2, P3, LAST)                                                                    \
+  INC_D2R_XADDR(rd_off, KK);                                                                                                     \
+  P0 INC_LGKM(4); INC_SB();                                                                                                      \
+  INC_D2R_SUB_A(CUR, 0, NXT, 0, W[SET][KK].x, 0)                                                                                 \
+  INC_SB(); P1 INC_LGKM(2); INC_SB();                                                                                            \
+  INC_D2R_SUB_B(CUR, 1, NXT, 2, 0)                                                                                               \
+  INC_SB(); P2 INC_SB();                                                                                                         \
+  INC_D2R_SUB_A(CUR, 2, NXT, 4, W[SET][KK].y, 1)                                                                                 \
+  INC_SB(); P3 INC_SB();                                                                                                         \
+  LAST                                                                                                                           \
+  INC_SB();
+#define INC_D2R_STEP(SET)                                                                                                         \
+  {                                                                                                                               \
+    constexpr int s1_ = ((SET) + 1) % 3, s2_ = ((SET) + 2) % 3;                                                                    \
+    rd_nxt = rd_off + T_ASTAGE == NS * T_ASTAGE ? 0u : rd_off + T_ASTAGE;                                                         \
+    INC_D2R_GROUP(0, 1, 1, SET, INC_D2R_LOADW(s2_, 0), INC_D2R_LOADW(s2_, 1), INC_D2R_LOADP(s2_), INC_D2R_DMA(0), INC_D2R_SUB_B(0, 3, 1, 6, 1)) \
+    INC_D2R_GROUP(1, 0, 2, SET, INC_D2R_DMA(1), INC_D2R_DMA(2), INC_D2R_DMA(3), INC_D2R_DMA(4), INC_D2R_SUB_B(1, 3, 0, 6, 1))      \
+    INC_D2R_GROUP(0, 1, 3, SET, INC_D2R_DMA(5), INC_D2R_DMA(6), INC_D2R_DMA(7), INC_D2R_WAIT(s1_, VM_STEADY), INC_D2R_SUB_BG(0, 3, 1, 6, 1, s1_)) \
+    INC_LGKM(4); INC_SB();                                                                                                        \
+    INC_D2R_SUB_G0(s1_)                                                                                                           \
+    INC_SB();                                                                                                                     \
+    advance_x();                                                                                                                  \
+    INC_LGKM(0);                                                                                                                  \
+    if constexpr ((ABL & 64) == 0) __builtin_amdgcn_s_barrier();                                                                  \
+    INC_D2R_XADDR(rd_nxt, 0);                                                                                                     \
+    INC_SB();                                                                                                                     \
+    INC_D2R_SUB_G1(s1_)                                                                                                           \
+    INC_SB();                                                                                                                     \
+    advance_w(0);                                                                                                                 \
+    INC_SB();                                                                                                                     \
+    INC_D2R_SUB_G2(s1_)                                                                                                           \
+    INC_SB();                                                                                                                     \
+    advance_w(1);                                                                                                                 \
+    INC_SB();                                                                                                                     \
+    INC_D2R_SUB_B(1, 3, 0, 6, 1)                                                                                                  \
+    INC_SB();                                                                                                                     \
+    advance_w(2);                                                                                                                 \
+    rd_off = rd_nxt;                                                                                                              \
+    INC_SB();                                                                                                                     \
   }
   for (int t0 = 0; t0 < nk; t0 += 3) {
     INC_D2R_STEP(0)
@@ -380,39 +457,38 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
   }
 #undef INC_D2R_STEP
 #undef INC_D2R_GROUP
-#undef INC_D2R_SUB
-#undef INC_D2R_MMA
 #undef INC_D2R_WAIT
 #undef INC_D2R_LOADP
 #undef INC_D2R_LOADW
 #undef INC_D2R_DMA
-#undef INC_NONE
+#undef INC_D2R_XADDR
+#undef INC_LGKM
 #undef INC_PIN1
-#undef INC_PIN2
-#undef INC_PIN3
-#undef INC_PIN4
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail requests
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results: nothing the compiler emits may read them early
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail requests
   if constexpr ((ABL & 128) != 0) return;
 
-  // ---- epilogue: accumulator j = 8 nf + mf, register r of it: D row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column (m) = lane & 31 ----
+  // ---- epilogue.  Accumulator j = 8 nf + mf, register r = 4 rq + e of it: D row i = e + 8 rq + 4 (lane >> 5), column (m) = lane & 31;
+  // row i of fragment nf is output column 64 wave + 2 i + nf (the paired-column assignment above), so for a fixed (rq, lane >> 5) the
+  // two fragments hold the EIGHT consecutive columns c0 = 64 wave + 16 rq + 8 (lane >> 5) .. c0 + 7, dword e = (nf 0, nf 1) of i = .. + e:
+  // one 16-byte piece of an output row per (rq, mf).
   if (lds_epilogue) {
     // full tile, 16-byte aligned y: through LDS (the stages are dead), then whole 512-byte rows per store instruction
     __builtin_amdgcn_s_barrier();  // every wave has drained its DMA (vmcnt(0) above) and finished its fragment reads
-    static_for<0, 8>([&](auto NFRQ) {
-      constexpr int nf = NFRQ.value >> 2, rq = NFRQ.value & 3;
-      const int nl = wave * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    static_for<0, 4>([&](auto RQ) {
+      constexpr int rq = RQ.value;
+      const int c0 = wave * 64 + 16 * rq + 8 * (lane >> 5);
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (bias) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = cvt16<IS_BF16>(bias[n0 + nl + e]);
+        for (int j = 0; j < 8; ++j) bv[j] = cvt16<IS_BF16>(bias[n0 + c0 + j]);
       }
       static_for<0, 8>([&](auto MF) {
-        constexpr int mf = MF.value, r0 = 16 * (8 * nf + mf) + 4 * rq;
+        constexpr int mf = MF.value, r0 = 16 * mf + 4 * rq, r1 = 16 * (8 + mf) + 4 * rq;
         const int ml = mf * 32 + (lane & 31);
-        *reinterpret_cast<uint2*>(smem + ml * D2R_CPITCH + nl * 2) =
-            make_uint2(cvt_pair<IS_BF16>(acc_read<r0>() + bv[0], acc_read<r0 + 1>() + bv[1]), cvt_pair<IS_BF16>(acc_read<r0 + 2>() + bv[2], acc_read<r0 + 3>() + bv[3]));
+        *reinterpret_cast<uint4*>(smem + ml * D2R_CPITCH + c0 * 2) =
+            make_uint4(cvt_pair<IS_BF16>(acc_read<r0>() + bv[0], acc_read<r1>() + bv[1]), cvt_pair<IS_BF16>(acc_read<r0 + 1>() + bv[2], acc_read<r1 + 1>() + bv[3]),
+                       cvt_pair<IS_BF16>(acc_read<r0 + 2>() + bv[4], acc_read<r1 + 2>() + bv[5]), cvt_pair<IS_BF16>(acc_read<r0 + 3>() + bv[6], acc_read<r1 + 3>() + bv[7]));
       });
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -427,37 +503,40 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     return;
   }
   float* const slab = partial ? partial + (int64_t)blockIdx.y * M * N : nullptr;  // split-K: raw fp32 tile into this split's slab
-  static_for<0, 8>([&](auto NFRQ) {
-    constexpr int nf = NFRQ.value >> 2, rq = NFRQ.value & 3;
-    const int64_t nb = n0 + wave * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  static_for<0, 4>([&](auto RQ) {
+    constexpr int rq = RQ.value;
+    const int64_t nb = n0 + wave * 64 + 16 * rq + 8 * (lane >> 5);
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (bias && !slab) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (nb + e < N) bv[e] = cvt16<IS_BF16>(bias[nb + e]);
+      for (int j = 0; j < 8; ++j)
+        if (nb + j < N) bv[j] = cvt16<IS_BF16>(bias[nb + j]);
     }
     static_for<0, 8>([&](auto MF) {
-      constexpr int mf = MF.value, r0 = 16 * (8 * nf + mf) + 4 * rq;
-      const float vv[4] = {acc_read<r0>() + bv[0], acc_read<r0 + 1>() + bv[1], acc_read<r0 + 2>() + bv[2], acc_read<r0 + 3>() + bv[3]};
+      constexpr int mf = MF.value, r0 = 16 * mf + 4 * rq, r1 = 16 * (8 + mf) + 4 * rq;
+      const float vv[8] = {acc_read<r0>() + bv[0],     acc_read<r1>() + bv[1],     acc_read<r0 + 1>() + bv[2], acc_read<r1 + 1>() + bv[3],
+                           acc_read<r0 + 2>() + bv[4], acc_read<r1 + 2>() + bv[5], acc_read<r0 + 3>() + bv[6], acc_read<r1 + 3>() + bv[7]};
       const int64_t m = m0 + mf * 32 + (lane & 31);
       if (m < M) {
         if (slab) {  // (bias and conversion happen in the finalize kernel)
           float* dst = slab + m * N + nb;
-          if (nb + 4 <= N && (N % 4) == 0) {
+          if (nb + 8 <= N && (N % 4) == 0) {
             *reinterpret_cast<float4*>(dst) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (nb + e < N) dst[e] = vv[e];
+            for (int j = 0; j < 8; ++j)
+              if (nb + j < N) dst[j] = vv[j];
           }
         } else {
           uint16_t* dst = y + m * N + nb;
-          if ((y_vec_ok & 1) && nb + 4 <= N) {
+          if ((y_vec_ok & 1) && nb + 8 <= N) {  // 8-byte aligned rows: two 8-byte stores
             *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair<IS_BF16>(vv[0], vv[1]), cvt_pair<IS_BF16>(vv[2], vv[3]));
+            *reinterpret_cast<uint2*>(dst + 4) = make_uint2(cvt_pair<IS_BF16>(vv[4], vv[5]), cvt_pair<IS_BF16>(vv[6], vv[7]));
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (nb + e < N) dst[e] = IS_BF16 ? f32_to_bf16_bits(vv[e]) : f32_to_f16_bits(vv[e]);
+            for (int j = 0; j < 8; ++j)
+              if (nb + j < N) dst[j] = IS_BF16 ? f32_to_bf16_bits(vv[j]) : f32_to_f16_bits(vv[j]);
           }
         }
       }
@@ -489,15 +568,11 @@ int inc_launch_woq_gemm_d2r(const uint16_t* x, const uint32_t* qw, const uint16_
   }
 #ifdef INC_KBENCH
   else if (ns == 3) INC_D2R(true, 3, 0)
-  else if (abl == 1) INC_D2R(true, 4, 1)
-  else if (abl == 4) INC_D2R(true, 4, 4)
-  else if (abl == 8) INC_D2R(true, 4, 8)
-  else if (abl == 12) INC_D2R(true, 4, 12)
-  else if (abl == 16) INC_D2R(true, 4, 16)
-  else if (abl == 32) INC_D2R(true, 4, 32)
-  else if (abl == 61) INC_D2R(true, 4, 61)   /* MFMA + barrier only */
-  else if (abl == 125) INC_D2R(true, 4, 125) /* MFMA only */
-  else if (abl == 128) INC_D2R(true, 4, 128)
+  else if (abl == 4) INC_D2R(true, 4, 4)     /* no x LDS-DMA */
+  else if (abl == 8) INC_D2R(true, 4, 8)     /* no W loads */
+  else if (abl == 12) INC_D2R(true, 4, 12)   /* no global traffic */
+  else if (abl == 76) INC_D2R(true, 4, 76)   /* no global traffic, no barrier */
+  else if (abl == 128) INC_D2R(true, 4, 128) /* no epilogue stores */
 #endif
   else INC_D2R(true, 4, 0)
 #undef INC_D2R

@@ -10,7 +10,7 @@ usage: tools/audit_d2r.py [--dump N]   (compiles neural_compressor_amd/csrc/gemm
 import collections, os, subprocess, sys, tempfile
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tmp = tempfile.mkdtemp(prefix="d2r_audit_")
+tmp = "/tmp/d2r_audit"; os.makedirs(tmp, exist_ok=True)
 src = os.path.join(root, "neural_compressor_amd", "csrc", "gemm_d2r.hip")
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-w", "-c", src,

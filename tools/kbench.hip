@@ -300,10 +300,10 @@ static int run_d2r_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool 
     if (diff) { printf(" (first at row %zu col %zu: %04x vs %04x)  FAIL\n", first / N, first % N, h2[first], h1[first]); ++fails; }
   }
   if (time_it) {
-    const int nv_all = 11;
-    const int modes[nv_all] = {42, 90, 91, 92, 93, 94, 95, 96, 97, 98, 99};
-    const char* labels[nv_all] = {"PC producer/consumer", "D2R 4 x-stages", "D2R 3 x-stages", "D2R - dequant arithmetic", "D2R - x LDS-DMA", "D2R - W loads",
-                                  "D2R - all global traffic", "D2R - fragment reads", "D2R - MFMA", "D2R MFMA + barrier only", "D2R MFMA only"};
+    const int nv_all = 8;
+    const int modes[nv_all] = {42, 90, 91, 92, 93, 94, 95, 96};
+    const char* labels[nv_all] = {"PC producer/consumer", "D2R 4 x-stages", "D2R 3 x-stages", "D2R - x LDS-DMA", "D2R - W loads", "D2R - all global traffic",
+                                  "D2R - global - barrier", "D2R - epilogue stores"};
     const int nv = ablate ? nv_all : 3, rounds = 5, iters = 8;
     std::vector<std::vector<float>> ms(nv);
     Timer t;
