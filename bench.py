@@ -10,11 +10,20 @@ random init) with the BASELINE calibration set (128 samples x 2048 tokens, synth
     -> second forward with the quantised weights (feeds the next block) -> on-device packing (inc_woq_pack),
 driven through the public API objects (prepare -> run_fn -> RAWGPTQuantizer.quantize_block).
 `value` = wall-clock seconds to GPTQ-quantise Llama-2-7B (32 such blocks) = 32 * T / K, T = time of the K timed steps.
-With N > 1 the N ranks quantise ONE model together (neural_compressor_amd/distributed.py, mode "sample+rows", exact
-reference semantics): calibration samples are sharded (block forwards + Hessian accumulation run on 128/N samples per
-rank, no activation crosses GPUs), the i-th distinct Hessian of the block is reduced to rank i % N, factorised there and
-its factor broadcast over RCCL/xGMI, every column loop runs row-sharded and the codes / scales are all-gathered; every
-rank ends with the same packed block.  Total work is fixed -> "strong" scaling; nothing is divided by N.
+With N > 1 the N ranks quantise ONE model together (neural_compressor_amd/distributed.py); when the script is started WITHOUT
+a torchrun environment it launches its own N ranks (torch.distributed.run, one per GPU, backend "nccl" = RCCL) and fails if the
+process group it ends up in does not have N ranks.  Two modes (--mgpu-mode):
+  layer (default for N > 1; BASELINE north_star, SURVEY 8(e) mode B): one transformer block per GPU.  Samples are sharded; every
+      rank forwards its samples through the float blocks of a round (N consecutive blocks), the block inputs travel to the block's
+      owner over RCCL / xGMI (point-to-point, INC_MI355X_GPTQ_ACT_EXCHANGE=broadcast for the broadcast form), each rank quantises
+      ITS block on the full calibration set.  Every block is calibrated on the FLOAT model's activations -- a documented deviation
+      from the reference's sequential scheme (gptq.py:749-762); per block the result is bit-identical to a single process run of
+      the same mode.  A STEP is then one ROUND (N blocks, one per rank): value = ceil(32 / N) * T / K.
+  exact (mode "sample+rows", exact reference semantics): calibration samples are sharded (block forwards + Hessian accumulation
+      run on 128/N samples per rank, no activation crosses GPUs), the i-th distinct Hessian of the block is reduced to rank
+      i % N, factorised there and its factor broadcast, every column loop runs row-sharded and the codes / scales are
+      all-gathered; every rank ends with the same packed block.
+Total work is fixed -> "strong" scaling; nothing is divided by N.
 `e2e` times the thing the north_star names once more, without extrapolation: a full 32-block model through
 prepare -> run_fn (calibration capture) -> convert, wall-clock.  The second half of the metric, the fused INT4->bf16
 dequant-GEMM, is timed on the BASELINE shapes and reported in `dequant_gemm`; `roofline` describes the kernel that
@@ -395,7 +404,20 @@ def main():
     ap.add_argument("--no-gemm", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--mgpu-mode", choices=("layer", "exact"), default="layer", help="N > 1: one block per GPU on float activations (north_star) | exact reference semantics")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain script: launch the N ranks ourselves (one process per GPU, RCCL) and hand their output through
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without a torchrun environment: launching {' '.join(cmd)}", file=sys.stderr, flush=True)
+        sys.exit(subprocess.call(cmd))
 
     def note(msg):  # progress on stderr: the single JSON line on stdout stays clean
         print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
@@ -404,15 +426,24 @@ def main():
     from neural_compressor_amd import ops
     from neural_compressor_amd.torch.quantization import GPTQConfig, prepare
 
+    backend = os.environ.get("INC_MI355X_DIST_BACKEND") or "nccl"
+    if args.gpus > 1 and backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s); RCCL needs one device per rank "
+                         "(INC_MI355X_DIST_BACKEND=gloo lets test ranks share a device)")
     rank, world, local_rank = D.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world} rank(s): refusing to report a number for another job size")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    layer_mode = world > 1 and args.mgpu_mode == "layer"
     if world > 1:
-        # ONE model, N ranks: samples sharded, Hessians reduced to their owner rank, factors broadcast, row-sharded solves
-        os.environ["INC_MI355X_GPTQ_MULTI_GPU"] = "sample+rows"
+        # ONE model, N ranks.  layer: one block per rank on the float model's activations; exact: samples sharded, Hessians reduced to
+        # their owner rank, factors broadcast, row-sharded solves
+        os.environ["INC_MI355X_GPTQ_MULTI_GPU"] = "layer" if layer_mode else "sample+rows"
+    rccl_ranks = torch.distributed.get_world_size() if world > 1 else 1
+    dist_backend = torch.distributed.get_backend() if world > 1 else None
 
-    n_blocks = args.warmup + args.steps
+    n_blocks = (args.warmup + args.steps) * (world if layer_mode else 1)
     note(f"building {n_blocks}-block Llama-2-7B-shaped model on {device}")
     model = build_model(n_blocks, device)  # same seed on every rank: the ranks hold replicas of the one model
     ids = calib_ids(args.samples, args.seq)
@@ -425,8 +456,10 @@ def main():
             model(ids[j].to(device))
     note(f"calibration inputs captured ({len(mine)} of {len(ids)} samples on this rank)")
     rq = model.quantizer.gptq_quantizer
-    assert (rq.dist_ctx is not None) == (world > 1)
+    assert ((rq.layer_ctx if layer_mode else rq.dist_ctx) is not None) == (world > 1)
     rq.remove_prepare_for_calibration()
+    if layer_mode:
+        rq.independent_setup()
     blocks = rq.gptq_related_blocks["transformers"]
 
     clock = KernelClock()
@@ -442,26 +475,34 @@ def main():
                lambda w, h, e, i1, c, c0, c1: 2.0 * w.shape[0] * c * max(c1 - c0, 0))
 
     with torch.no_grad():
+        def step(i):  # exact / single GPU: one block; layer: one round = `world` blocks, one per rank
+            if layer_mode:
+                rq.independent_round(blocks, i * world)
+            else:
+                rq.quantize_block(blocks[i], i)
+
         for i in range(args.warmup):
-            rq.quantize_block(blocks[i], i)
+            step(i)
             torch.cuda.synchronize()
-            note(f"warmup block {i} done")
+            note(f"warmup step {i} done")
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         clock.enabled = True
         t0 = time.perf_counter()
-        for i in range(args.warmup, n_blocks):
-            rq.quantize_block(blocks[i], i)
+        for i in range(args.warmup, args.warmup + args.steps):
+            step(i)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
         clock.enabled = False
-    note(f"timed region done: {elapsed:.2f}s for {args.steps} blocks")
+    note(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
     elapsed = D.barrier_max_time(elapsed, device=device)
     ms_per_step = elapsed * 1e3 / args.steps
-    value = 32.0 * elapsed / args.steps  # N ranks work on the SAME blocks: nothing is divided by N
+    # whole job = a 32-block model.  exact / single GPU: 32 steps (N ranks work on the SAME block); layer: ceil(32 / N) rounds
+    steps_per_model = -(-32 // world) if layer_mode else 32
+    value = steps_per_model * elapsed / args.steps
 
     kern = clock.summary()
     breakdown = {k: dict(launches=v["launches"], total_ms=round(v["total_ms"], 3), avg_ms=round(v["avg_ms"], 4)) for k, v in kern.items()}
@@ -493,7 +534,8 @@ def main():
                              "algorithmic flops of EVERY Hessian launch of the timed region / their summed time")
 
     result = dict(
-        metric="llama2_7b_gptq_int4_g128_quantize_wall_clock", value=round(value, 3), unit="s", n_gpus=world,
+        metric="llama2_7b_gptq_int4_g128_quantize_wall_clock", value=round(value, 3), unit="s", n_gpus=world, rccl_ranks=rccl_ranks,
+        dist_backend=dist_backend,
         steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 2), higher_is_better=False,
         scaling="strong", vs_baseline=None, dtype="bf16", data="synthetic",
         config=dict(workload="Llama-2-7B GPTQ INT4 group_size=128 sym, 128 calib samples x 2048 tokens; step = one transformer block "
@@ -504,8 +546,13 @@ def main():
                                   "INC_MI355X_GPTQ_CAPTURE_EARLY_STOP=0 runs it in full; the quantised model is bit-identical either way"),
                     arithmetic="bf16 activations/weights (MFMA, fp32 accumulate), fp32 Hessian + Cholesky + column loop, int4 codes",
                     parallelism=("single GPU" if world == 1 else
+                                 (f"ONE model on {world} ranks, one transformer block per rank (step = one round of {world} blocks): samples sharded "
+                                  f"{world}-way for the float forwards, block inputs sent to the block's owner over RCCL ({os.environ.get('INC_MI355X_GPTQ_ACT_EXCHANGE', 'scatter')}), "
+                                  "each block calibrated on the FLOAT model's activations (north_star's layer-per-GPU mode; deviates from the reference's "
+                                  "sequential gptq.py:749-762, per-block results bit-identical to a single process of this mode)") if layer_mode else
                                  f"ONE model on {world} ranks: samples sharded {world}-way, Hessians reduced to owner ranks + factor broadcast "
-                                 "(RCCL), row-sharded column loop + all-gather; exact reference semantics")),
+                                 "(RCCL), row-sharded column loop + all-gather; exact reference semantics"),
+                    steps_per_model=steps_per_model),
         roofline=roofline, kernel_breakdown=breakdown,
     )
     del model, rq, blocks

@@ -441,6 +441,8 @@ class HessianAccumulator:
         `inverse_factor` waits on the handles when a solve first needs the factor)."""
         if ctx.rank == owner:
             Hinv, dead, perm = self.inverse_factor(percdamp, act_order)
+            if self._info is None:  # (the rocSOLVER trio raises on its own)
+                self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
         else:
             self.flush()
             self._stage, self.H = None, None
@@ -449,7 +451,10 @@ class HessianAccumulator:
             dead = torch.empty(K, dtype=torch.uint8, device=self.device)
             perm = torch.empty(K, dtype=torch.int64, device=self.device) if act_order else None
             self.finalized = ((float(percdamp), bool(act_order)), Hinv, dead, perm)
-        handles = [ctx.broadcast(t, owner, async_op=True) for t in (Hinv, dead, perm) if t is not None]
+            self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # the "not positive definite" status word travels with the factor: every rank raises together in check() instead of the
+        # owner alone (the others would walk into the next collective and hang)
+        handles = [ctx.broadcast(t, owner, async_op=True) for t in (Hinv, dead, perm, self._info) if t is not None]
         handles = [h for h in handles if h is not None]
         if ctx.rank != owner and handles:
             self._handles = handles
@@ -471,6 +476,8 @@ class GPTQ:
         self.row_ctx = None  # distributed.CalibrationGroup: solve only this rank's weight rows, all-gather the results
 
     # the reference's Quantizer.configure (gptq.py:1375) copies the per-layer dict onto the quantizer
+    defer_check = False  # RAWGPTQuantizer sets it and checks every factorisation of a block at once
+
     def configure(self, weight_config_this_layer):
         self.cfg = dict(weight_config_this_layer)
 
@@ -632,6 +639,10 @@ class GPTQ:
         if self.is_conv1d:
             Q = Q.t().contiguous()
         Q = Q.reshape(weight_shape)
+        if not self.defer_check:
+            # a non-positive-definite Hessian raises here like the reference's torch.linalg.cholesky (gptq.py:1228), after all of the
+            # solve's work is queued: one host synchronisation per solve.  The block driver defers it to one check per block.
+            self.acc.check()
         return scale, torch.tensor([-1]), zero, Q
 
     def free(self):
@@ -692,9 +703,24 @@ class RAWGPTQuantizer(object):
             import torch.distributed as dist
 
             live = bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-            assert mode in ("sample", "rows", "sample+rows"), f"INC_MI355X_GPTQ_MULTI_GPU={mode!r}"
+            assert mode in ("sample", "rows", "sample+rows", "layer"), f"INC_MI355X_GPTQ_MULTI_GPU={mode!r}"
             self.hessian_allreduce = live and mode in ("sample", "sample+rows")
             self.row_shard_solve = live and mode in ("rows", "sample+rows")
+            if mode == "layer" and kwargs.get("independent_blocks") is None:
+                kwargs["independent_blocks"] = True
+        # mode "layer" (distributed.py; BASELINE north_star / SURVEY 8(e) mode B): one transformer block per rank, calibrated on the
+        # FLOAT model's activations.  True = default process group (or a single process), or pass a process group.
+        self.independent_blocks = kwargs.get("independent_blocks", None)
+        self.layer_ctx = None
+        if self.independent_blocks:
+            import torch.distributed as dist
+
+            assert not (self.hessian_allreduce or self.row_shard_solve), "independent_blocks excludes the sample / rows modes"
+            if dist.is_available() and dist.is_initialized():
+                from ....distributed import CalibrationGroup
+
+                ctx = CalibrationGroup(None if self.independent_blocks is True else self.independent_blocks)
+                self.layer_ctx = ctx if ctx.world > 1 else None
         self.dist_ctx = None
         if self.row_shard_solve:
             from ....distributed import CalibrationGroup
@@ -967,6 +993,12 @@ class RAWGPTQuantizer(object):
         seq_map = self.analyze_true_sequential(blocks[0])
         for p in self.model.parameters():
             p.requires_grad = False
+        if self.independent_blocks:
+            self._execute_independent_blocks(blocks, seq_map if true_sequential else None)
+            if self.quant_lm_head:
+                self.quantize_post_layer()
+            logger.info("Quantization done")
+            return self.model
         for block_idx in range(len(blocks)):
             t0 = time.time()
             block = blocks[block_idx].to(self.device)
@@ -978,6 +1010,234 @@ class RAWGPTQuantizer(object):
             self.quantize_post_layer()
         logger.info("Quantization done")
         return self.model
+
+    # -- mode "layer": one transformer block per GPU, calibrated on the float model's activations ---------------------
+    def _hidden_list(self):
+        return self.cache_key_arguments["hidden_states"] if "hidden_states" in self.cache_key_arguments else self.cache_positional_arguments[0]
+
+    def _set_hidden_list(self, lst):
+        if "hidden_states" in self.cache_key_arguments:
+            self.cache_key_arguments["hidden_states"] = lst
+        else:
+            self.cache_positional_arguments[0] = lst
+
+    @torch.no_grad()
+    def _execute_independent_blocks(self, blocks, seq_map):
+        """BASELINE's north_star / SURVEY 8(e) mode B: block b is owned by rank b % world and calibrated on the inputs the FLOAT
+        model gives it -- NOT on the outputs of the quantised block b-1 as the reference does (gptq.py:749-762; the documented
+        deviation of this opt-in mode).  Every block's solve is then independent of every other block's, so `world` blocks are
+        quantised at once.  Per block the result is what `quantize_block` gives on the same inputs (bit-identical to a single
+        process run of this mode: test_gpu_models.py).  One round = `world` consecutive blocks:
+          1. every rank forwards ITS calibration samples through the round's float blocks, keeping each block's inputs;
+          2. the inputs of block b travel to its owner: by default point-to-point (each rank sends its shard of block b's inputs to
+             rank b % world only -- over xGMI's per-pair links the round is a balanced all-to-all), or, with
+             INC_MI355X_GPTQ_ACT_EXCHANGE=broadcast, every shard is broadcast to all ranks and kept by the owner;
+          3. each rank quantises its block on the full calibration set (Hessian forward + solve + pack; no second forward: nothing
+             downstream reads the quantised block's outputs in this mode).
+        At the end the packed blocks are broadcast from their owners, so every rank holds the whole quantised model."""
+        self.independent_setup()
+        for start in range(0, len(blocks), self._layer_state["world"]):
+            self.independent_round(blocks, start, seq_map)
+        self.independent_finish(blocks)
+
+    def independent_setup(self):
+        """Sample counts of every rank and the shape / dtype of one calibration sample (once per run)."""
+        ctx = self.layer_ctx
+        world, rank = (ctx.world, ctx.rank) if ctx is not None else (1, 0)
+        exchange = os.environ.get("INC_MI355X_GPTQ_ACT_EXCHANGE", "scatter")
+        assert exchange in ("scatter", "broadcast"), f"INC_MI355X_GPTQ_ACT_EXCHANGE={exchange!r}"
+        n_local = self.cache_key_arguments["batch_num"]
+        counts = [n_local]
+        if ctx is not None:
+            t = torch.zeros(world, dtype=torch.int64, device="cpu" if ctx.backend == "gloo" else self.device)
+            t[rank] = n_local
+            counts = [int(v) for v in ctx.all_reduce(t).tolist()]
+        ref = self._hidden_list()[0] if n_local else None
+        if ctx is not None:  # shape / dtype of one calibration sample, from the first rank that has any
+            import torch.distributed as dist
+
+            meta = [(tuple(ref.shape), str(ref.dtype).replace("torch.", "")) if ref is not None else None]
+            src = next(r for r in range(world) if counts[r] > 0)
+            dist.broadcast_object_list(meta, src=ctx._global(src), group=ctx.group)
+            shape, dtype = meta[0][0], getattr(torch, meta[0][1])
+        else:
+            shape, dtype = tuple(ref.shape), ref.dtype
+        self._layer_state = dict(world=world, rank=rank, exchange=exchange, counts=counts, n_total=sum(counts), shape=shape, dtype=dtype)
+
+    @torch.no_grad()
+    def independent_round(self, blocks, start, seq_map=None):
+        """One round of mode "layer": blocks start .. start + world - 1, one per rank (steps 1-3 of `_execute_independent_blocks`)."""
+        from ....distributed import owner_of_block
+
+        st = self._layer_state
+        ctx, world, rank = self.layer_ctx, st["world"], st["rank"]
+        t0 = time.time()
+        round_blocks = list(range(start, min(start + world, len(blocks))))
+        # 1. float forwards of this rank's samples; block b's inputs are kept (the list entries are replaced, not overwritten)
+        kept = {}
+        for b in round_blocks:
+            blocks[b].to(self.device)
+            kept[b] = list(self._hidden_list())
+            if b + 1 < len(blocks) or self.quant_lm_head:
+                def replace(j, out):
+                    self._hidden_list()[j] = out
+
+                self._run_block(blocks[b], on_output=replace)
+        # 2. the inputs of block b -> rank b % world
+        mine = next((b for b in round_blocks if owner_of_block(b, world) == rank), None)
+        if ctx is None:
+            full = kept[mine]
+        else:
+            full = self._exchange_block_inputs(ctx, round_blocks, kept, st["counts"], st["shape"], st["dtype"], st["exchange"], mine)
+        del kept
+        # 3. quantise the own block on the whole calibration set
+        if mine is not None:
+            saved = (self._hidden_list(), self.cache_key_arguments["batch_num"], getattr(self, "_fgroups", None), self._stacks,
+                     {k: v for k, v in self.cache_key_arguments.items() if k not in ("hidden_states", "batch_num")},
+                     [lst for lst in self.cache_positional_arguments])
+            try:
+                self._view_all_samples(full, st["n_total"])
+                self.quantize_block(blocks[mine], mine, seq_map, propagate=False)
+                if self.block_callback is not None:
+                    self.block_callback(mine, blocks[mine])
+            finally:
+                hidden, batch_num, fgroups, stacks, kws, poss = saved
+                for k, v in kws.items():
+                    self.cache_key_arguments[k] = v
+                for i, lst in enumerate(poss):
+                    self.cache_positional_arguments[i] = lst
+                self._set_hidden_list(hidden)
+                self.cache_key_arguments["batch_num"] = batch_num
+                self._fgroups, self._stacks = fgroups, stacks
+        del full
+        logger.info("Quantized blocks %d..%d of %d (one per rank) in %.2fs", round_blocks[0] + 1, round_blocks[-1] + 1, len(blocks), time.time() - t0)
+
+    def independent_finish(self, blocks):
+        """Every rank ends with the whole quantised model: the owners broadcast their packed blocks."""
+        from ....distributed import owner_of_block
+
+        ctx = self.layer_ctx
+        if ctx is not None:
+            for b in range(len(blocks)):
+                self._broadcast_packed_block(ctx, blocks[b], owner_of_block(b, ctx.world))
+
+    def _view_all_samples(self, hidden, n_total):
+        """Point the calibration cache at `hidden` (n_total samples): every other cached argument is the first local batch's,
+        repeated -- this mode requires what stacking requires anyway: arguments that do not differ between batches."""
+        n_local = self.cache_key_arguments["batch_num"]
+        for k, v in list(self.cache_key_arguments.items()):
+            if k in ("hidden_states", "batch_num"):
+                continue
+            assert n_local > 0, "a rank without calibration samples cannot own a block (it has no attention mask / position ids to reuse)"
+            self.cache_key_arguments[k] = [v[0]] * n_total
+        first = 0 if "hidden_states" in self.cache_key_arguments else 1
+        for i in range(first, len(self.cache_positional_arguments)):
+            self.cache_positional_arguments[i] = [self.cache_positional_arguments[i][0]] * n_total
+        self._set_hidden_list(list(hidden))
+        self.cache_key_arguments["batch_num"] = n_total
+        self._fgroups, self._stacks = None, {}
+
+    def _exchange_block_inputs(self, ctx, round_blocks, kept, counts, shape, dtype, exchange, mine):
+        """Collective C3 of SURVEY 8: returns the inputs of this rank's block as a list of n_total [1, seq, hidden] tensors in global
+        sample order (rank 0's samples first), or None when this rank owns no block of the round.  Shards travel as ONE message per
+        (block, source rank): 2 GiB / world for Llama-2-7B at 128 x 2048 tokens."""
+        import torch.distributed as dist
+
+        from ....distributed import owner_of_block
+
+        world, rank = ctx.world, ctx.rank
+        staged = ctx.backend == "gloo"
+        dev = "cpu" if staged else self.device
+
+        def shard_of(b):
+            if not kept[b]:
+                return torch.empty((0,) + tuple(shape[1:]), dtype=dtype, device=dev)
+            x = torch.cat(kept[b], dim=0)
+            return x.cpu() if staged else x
+
+        parts = None
+        if mine is not None:
+            parts = [None] * world
+            parts[rank] = kept[mine]
+        if exchange == "broadcast":
+            scratch = {}
+            for b in round_blocks:
+                owner = owner_of_block(b, world)
+                for s in range(world):
+                    if counts[s] == 0:
+                        continue
+                    if s == rank:
+                        buf = shard_of(b)
+                    else:
+                        key = counts[s]
+                        if owner == rank or key not in scratch:
+                            buf = torch.empty((counts[s],) + tuple(shape[1:]), dtype=dtype, device=dev)
+                            if owner != rank:
+                                scratch[key] = buf  # non-owners receive into a reused buffer and drop it
+                        else:
+                            buf = scratch[key]
+                    dist.broadcast(buf, src=ctx._global(s), group=ctx.group)
+                    if owner == rank and s != rank:
+                        buf = buf.to(self.device) if staged else buf
+                        parts[s] = [buf[i : i + 1] for i in range(counts[s])]
+        else:
+            ops, recvs, keep = [], {}, []
+            for b in round_blocks:
+                owner = owner_of_block(b, world)
+                if owner == rank:
+                    for s in range(world):
+                        if s != rank and counts[s] > 0:
+                            buf = torch.empty((counts[s],) + tuple(shape[1:]), dtype=dtype, device=dev)
+                            recvs[s] = buf
+                            ops.append(dist.P2POp(dist.irecv, buf, ctx._global(s), ctx.group))
+                elif counts[rank] > 0:
+                    x = shard_of(b)
+                    keep.append(x)
+                    ops.append(dist.P2POp(dist.isend, x, ctx._global(owner), ctx.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if not staged:
+                torch.cuda.current_stream().synchronize()
+            for s, buf in recvs.items():
+                buf = buf.to(self.device) if staged else buf
+                parts[s] = [buf[i : i + 1] for i in range(counts[s])]
+        if parts is None:
+            return None
+        return [x for s in range(world) if counts[s] > 0 for x in parts[s]]
+
+    def _broadcast_packed_block(self, ctx, block, owner):
+        """The packed modules of `block` from rank `owner` to every rank (C2's role in this mode: ~110 MiB per Llama-2-7B block)."""
+        import torch.distributed as dist
+
+        meta = [None]
+        if ctx.rank == owner:
+            meta[0] = []
+            for name, m in block.named_modules():
+                if isinstance(m, MI355XWeightOnlyLinear):
+                    ctor = dict(in_features=m.in_features, out_features=m.out_features, dtype=m.dtype, bits=m.bits, group_size=m.group_size,
+                                zp=hasattr(m, "qzeros"), bias=getattr(m, "bias", None) is not None, g_idx=getattr(m, "g_idx", None) is not None,
+                                use_optimum_format=m.use_optimum_format, compression_dim=m.compression_dim,
+                                compression_dtype=m.compression_dtype, scale_dtype=m.scale_dtype)
+                    bufs = [(bn, tuple(t.shape), t.dtype) for bn, t in sorted(m.named_buffers(recurse=False))]
+                    meta[0].append((name, ctor, bufs))
+        dist.broadcast_object_list(meta, src=ctx._global(owner), group=ctx.group)
+        for name, ctor, bufs in meta[0]:
+            if ctx.rank == owner:
+                mod = dict(block.named_modules())[name]
+            else:
+                mod = MI355XWeightOnlyLinear(device=self.device, **ctor)
+            for bn, shape, dt in bufs:
+                if ctx.rank == owner:
+                    t = getattr(mod, bn).contiguous()
+                else:
+                    t = torch.empty(shape, dtype=dt, device=self.device)
+                ctx.broadcast(t, owner)
+                if ctx.rank != owner:
+                    setattr(mod, bn, t)  # a registered buffer name keeps the tensor as a buffer
+            if ctx.rank != owner:
+                mod._plan_key = None
+                set_module(block, name, mod)
 
     @torch.no_grad()
     def quantize_post_layer(self):
@@ -997,6 +1257,7 @@ class RAWGPTQuantizer(object):
         logger.info("Quantizing post transformer layers")
         layer.to(self.device)
         solver = GPTQ(layer, device=self.device)
+        solver.defer_check = True  # checked below, after packing is queued
         solver.configure(cfg)
         handle = layer.register_forward_hook(lambda _, inp, out: solver.add_batch(inp[0].detach()))
         for j in range(self.cache_key_arguments["batch_num"]):
@@ -1030,7 +1291,7 @@ class RAWGPTQuantizer(object):
         set_module(self.model, full, new_module)
 
     @torch.no_grad()
-    def quantize_block(self, block, block_idx, seq_map=None):
+    def quantize_block(self, block, block_idx, seq_map=None, propagate=True):
         sub_layers = find_layers(block)
         sequentials = seq_map if seq_map else [list(sub_layers.keys())]
         for sequential in sequentials:
@@ -1045,6 +1306,7 @@ class RAWGPTQuantizer(object):
             solvers = {}
             for name, layer in layers.items():
                 solvers[name] = GPTQ(layer, device=self.device)
+                solvers[name].defer_check = True  # checked once per group of solves below
                 solvers[name].configure(self.get_layer_config(self.get_full_layer_name(name, block_idx)))
             # Step 2.3: hooks feeding the Hessians (reference :670-688).  Layers that receive the very same input
             # tensor in a forward (q/k/v, gate/up) share one accumulator instead of recomputing X^T X.
@@ -1188,7 +1450,8 @@ class RAWGPTQuantizer(object):
                 else:
                     self.cache_positional_arguments[0][j] = out
 
-            self._run_block(block, on_output=replace)
+            if propagate:
+                self._run_block(block, on_output=replace)
             # Step 2.6: export to the packed module (reference :769-849) -- on device, from the emitted codes
             for name, layer in layers.items():
                 cfg = self.get_layer_config(self.get_full_layer_name(name, block_idx))
@@ -1221,7 +1484,7 @@ class GPTQuantizer(INCQuantizer):
             model, weight_config=self.quant_config, nsamples=nsamples, use_max_length=use_max_length,
             max_seq_length=max_seq_length, device=device, use_layer_wise=use_layer_wise, model_path=model_path,
             quant_lm_head=quant_lm_head, use_block_wise=use_block_wise,
-            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback", "hessian_allreduce", "row_shard_solve")},
+            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback", "hessian_allreduce", "row_shard_solve", "independent_blocks")},
         )
         self.gptq_quantizer.prepare_for_calibration()
         return self.gptq_quantizer.model

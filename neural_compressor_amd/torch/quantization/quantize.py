@@ -45,14 +45,18 @@ def quantize(model, quant_config, run_fn=None, run_args=None, inplace=True, exam
     return q_model
 
 
-def prepare(model, quant_config, inplace=True, example_inputs=None):
-    """Install the calibration capture of every algorithm the config selects."""
+def prepare(model, quant_config, inplace=True, example_inputs=None, **kwargs):
+    """Install the calibration capture of every algorithm the config selects.
+
+    Extra keyword arguments go to the algorithm's `prepare` (an extension of the reference's signature, quantize.py:140): GPTQ takes
+    `independent_blocks=True` (one transformer block per rank, calibrated on the float model's activations: distributed.py mode
+    "layer"), `hessian_allreduce` / `row_shard_solve` (the exact multi-GPU modes)."""
     prepared = model if inplace else copy.deepcopy(model)
     prepared, configs_mapping = preprocess_quant_config(prepared, quant_config, mode="prepare", example_inputs=example_inputs)
     for algo_name, algo_func in algos_mapping.items():
         if need_apply(configs_mapping, algo_name):
             logger.info("Start to prepare model with %s.", algo_name)
-            prepared = algo_func(prepared, configs_mapping, example_inputs=example_inputs, mode=Mode.PREPARE)
+            prepared = algo_func(prepared, configs_mapping, example_inputs=example_inputs, mode=Mode.PREPARE, **kwargs)
             setattr(prepared, "is_prepared", True)
     setattr(prepared, "quant_config", quant_config)
     setattr(prepared, "example_inputs", example_inputs)

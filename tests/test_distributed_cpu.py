@@ -101,3 +101,44 @@ def test_single_process_paths_are_identity():
         assert parts[0][0] == 0 and parts[-1][1] == n_rows
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         assert all(p[0] == min(r * p[2], n_rows) for r, p in enumerate(parts))
+
+
+def _layer_exchange_worker(rank, world, port, exchange, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neural_compressor_amd import distributed as D
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import RAWGPTQuantizer
+
+    D.init_from_env(backend="gloo")
+    ctx = D.CalibrationGroup()
+    rq = object.__new__(RAWGPTQuantizer)  # only the collective bookkeeping is under test
+    rq.device = torch.device("cpu")
+    counts = [3, 2, 0][:world] if world == 3 else [3, 2]  # uneven shards
+    shape, dtype = (1, 4, 5), torch.float32
+    first = sum(counts[:rank])
+
+    def sample(b, j):  # global sample j of block b
+        return torch.full(shape, float(100 * b + j))
+
+    ok = True
+    for round_blocks in ([0, 1], [2]):  # a full round and a last, partial one
+        kept = {b: [sample(b, first + i) for i in range(counts[rank])] for b in round_blocks}
+        mine = next((b for b in round_blocks if D.owner_of_block(b, world) == rank), None)
+        full = rq._exchange_block_inputs(ctx, round_blocks, kept, counts, shape, dtype, exchange, mine)
+        if mine is None:
+            ok = ok and full is None
+        else:
+            ok = ok and len(full) == sum(counts) and all(torch.equal(full[j], sample(mine, j)) for j in range(sum(counts)))
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("exchange", ["scatter", "broadcast"])
+def test_layer_mode_activation_exchange_gloo_world2(exchange):
+    """Mode "layer" (one transformer block per rank): the calibration inputs of block b reach rank b % world complete and in
+    global sample order, for uneven sample shards, for both exchange forms and for a partial last round."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_layer_exchange_worker, args=(world, port, exchange, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}

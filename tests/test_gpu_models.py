@@ -818,9 +818,10 @@ def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out):
     torch.cuda.set_device(0)
     D.init_from_env(backend="gloo")
     ids = calib_ids()
-    mine = D.shard_samples(len(ids), rank, world) if "sample" in mode else range(len(ids))
+    mine = D.shard_samples(len(ids), rank, world) if ("sample" in mode or mode == "layer") else range(len(ids))
     model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw))
-    assert model.quantizer.gptq_quantizer.dist_ctx is not None
+    rq = model.quantizer.gptq_quantizer
+    assert (rq.layer_ctx if mode == "layer" else rq.dist_ctx) is not None
     for j in mine:
         model(ids[j])
     q = convert(model)
@@ -906,3 +907,46 @@ def test_gptq_sample_and_row_sharded_two_ranks():
     first = min(_nibble_match(res[0][n][0].numpy(), single[n][0].numpy()) for n in single if ".layers.0." in n)
     worst = min(_nibble_match(res[0][n][0].numpy(), single[n][0].numpy()) for n in single if n != "__logits__")
     assert first >= 0.99 and worst >= 0.95, (first, worst)
+
+
+def _single_process_independent_blocks(cfg_kw):
+    """Mode "layer" in ONE process (prepare(..., independent_blocks=True)): every block calibrated on the float model's activations."""
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    ids = calib_ids()
+    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw), independent_blocks=True)
+    assert model.quantizer.gptq_quantizer.independent_blocks
+    for x in ids:
+        model(x)
+    q = convert(model)
+    res = {n: (m.qweight.cpu(), m.scales.cpu(), m.qzeros.cpu(), None if m.g_idx is None else m.g_idx.cpu()) for n, m in _woq_modules(q).items()}
+    with torch.no_grad():
+        res["__logits__"] = q(ids[0].to("cuda")).logits.float().cpu()
+    return res
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("exchange", ["scatter", "broadcast"])
+def test_gptq_layer_per_gpu_two_ranks_is_bit_identical_to_single_process_given_the_same_inputs(exchange, monkeypatch):
+    """Multi-GPU mode "layer" (BASELINE north_star; SURVEY 8(e) mode B, collective C3): block b is owned by rank b % 2, the
+    calibration samples are sharded, every rank forwards ITS samples through the float blocks and the block inputs travel to the
+    owner (point-to-point, or broadcast), which quantises its block on the full set; the packed blocks are then broadcast.
+    "Per-layer results equal the single-GPU ones given the same inputs": both ranks must hold exactly the model that ONE process
+    produces in this mode (same float inputs for every block), bit for bit.  Block 0 sees the reference's own inputs, so its
+    packed tensors must also equal the sequential (exact-mode) run's."""
+    monkeypatch.setenv("INC_MI355X_GPTQ_ACT_EXCHANGE", exchange)
+    cfg_kw = dict(use_sym=True)
+    res = _spawn_multi_gpu("layer", cfg_kw)
+    single = _single_process_independent_blocks(cfg_kw)
+    assert res[0].keys() == res[1].keys() == single.keys() and len(single) == 15
+    for n in single:
+        if n == "__logits__":
+            assert torch.equal(res[0][n], single[n]) and torch.equal(res[1][n], single[n])
+            continue
+        for a, b, c in zip(res[0][n], res[1][n], single[n]):
+            assert _same(a, c) and _same(b, c), n
+    exact = _single_process(cfg_kw)
+    for n in exact:
+        if ".layers.0." in n:
+            for a, c in zip(single[n], exact[n]):
+                assert _same(a, c), n

@@ -644,6 +644,24 @@ def test_inverse_cholesky_upper_rejects_non_spd(hip):
 
 
 @pytest.mark.gpu
+def test_gptq_fasterquant_raises_on_a_non_positive_definite_hessian(hip):
+    """The public GPTQ class used directly (as the reference allows, gptq.py:1089): a Hessian that is not positive definite must
+    raise from `fasterquant` like the reference's torch.linalg.cholesky (gptq.py:1228) -- the factorisation's status word is read
+    at the end of the solve, not only by the block driver."""
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import GPTQ
+
+    torch.manual_seed(0)
+    layer = torch.nn.Linear(256, 64, bias=False).to(hip)
+    gq = GPTQ(layer, device=hip)
+    gq.configure(dict(bits=4, sym=True, dtype="int"))
+    gq.add_batch(torch.randn(1, 64, 256, device=hip))
+    gq.acc.flush()
+    gq.acc.H.copy_(-torch.eye(256, device=hip))  # negative definite: the damping term keeps the sign
+    with pytest.raises(torch.linalg.LinAlgError):
+        gq.fasterquant(layer.weight.data, blocksize=128, percdamp=0.01, groupsize=128)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("groupsize,blocksize,sym", [(128, 128, True), (32, 128, False), (256, 128, True), (128, 256, False), (-1, 128, True)])
 def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize, blocksize, sym):
     """The look-ahead column loop (next block's 128 columns first, the rest of the lazy update on a second stream) against the
