@@ -474,6 +474,10 @@ def main():
     clock.wrap(ops, "gptq_lazy_update_cols", lambda w, h, e, i1, c, c0, c1: "lazy_update_next" if c0 == i1 + c else "lazy_update_rest",
                lambda w, h, e, i1, c, c0, c1: 2.0 * w.shape[0] * c * max(c1 - c0, 0))
 
+    # the column loop as ONE C-ABI call per solve (inc_gptq_quantize_layer): timed on the main stream, the launches above stay empty
+    clock.wrap(ops, "gptq_quantize_layer", lambda w, *a, **k: f"quantize_layer_{w.shape[0]}x{w.shape[1]}",
+               lambda w, *a, **k: float(w.shape[0]) * w.shape[1] * (128 + w.shape[1]))
+
     with torch.no_grad():
         def step(i):  # exact / single GPU: one block; layer: one round = `world` blocks, one per rank
             if layer_mode:

@@ -246,6 +246,28 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
                               int64_t i1, int count, int64_t col_begin, int64_t col_end,
                               inc_stream_t stream);
 
+/* == K6 as ONE call: the blocked column loop of GPTQ.fasterquant (gptq.py:1250-1304) for one (N-stacked) layer, given the
+ *   inverse-Cholesky factor: per 128 columns [find_params ->] quantisation chain -> lazy update, issued by the library on
+ *   `stream` in the reference's order.  With `aux_stream` != NULL (and K a multiple of 128, K >= 384, block_size a multiple
+ *   of 128) the bulk of every lazy update runs on it underneath the next block's chain; results are bit-identical either way.
+ *     w [N,K] fp32 working copy (inc_gptq_prepare_weight; column-permuted by the caller for act_order) -- consumed;
+ *     Hinv [K,K] fp32; scale / zero [N,G] fp32: written for dynamic groups (find_params on W "as it is now", gptq.py:1266-1272),
+ *     read otherwise; loop_scale / loop_zero [N,loop_G] (may be NULL = scale / zero): the table the chain reads, with
+ *     kernel_group_size columns per entry (<= 0: one group) -- differs from scale / zero only for act_order + static_groups
+ *     (one entry per column); codes uint8 [N,K] and q_out [N,K] of q_dtype (either may be NULL); err_ws fp32 [2, N, 128];
+ *     group_size = columns per quantisation group (K for per-channel); block_size = GPTQConfig.block_size (<= 0: K);
+ *     flags: INC_GPTQ_DYNAMIC_GROUPS (group_size != -1 and not static_groups), INC_GPTQ_MSE (use_mse_search),
+ *            INC_GPTQ_NO_LOOKAHEAD, INC_GPTQ_NO_FUSED_PARAMS (A/B switches; default = fastest bit-identical form).      */
+#define INC_GPTQ_DYNAMIC_GROUPS 1
+#define INC_GPTQ_MSE 2
+#define INC_GPTQ_NO_LOOKAHEAD 4
+#define INC_GPTQ_NO_FUSED_PARAMS 8
+int inc_gptq_quantize_layer(float* w, const float* Hinv, float* scale, float* zero, int64_t G,
+                            const float* loop_scale, const float* loop_zero, int64_t loop_G, uint8_t* codes,
+                            void* q_out, int q_dtype, float* err_ws, int64_t N, int64_t K, int group_size,
+                            int kernel_group_size, int block_size, int bits, int sym, int flags,
+                            inc_stream_t stream, inc_stream_t aux_stream);
+
 /* ---- K6': diagonal block of the blocked inverse-Cholesky factor -------------------------------- *
  * The reference builds Hinv = cholesky(cholesky_inverse(cholesky(H)), upper) (gptq.py:1228-1230) with
  * three LAPACK factorisations.  Here U = J Lr^-1 J with J H J = Lr Lr^T (see gptq.py: inverse_cholesky_upper):

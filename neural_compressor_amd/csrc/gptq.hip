@@ -22,6 +22,8 @@
 
 #include <type_traits>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace {
@@ -1425,6 +1427,92 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
   gptq_lazy_update_v2_kernel<true><<<dim3((unsigned)nchunks, (unsigned)row_tiles), 256, smem2, inc_s(stream)>>>(
       w, Hinv, err, N, K, i1, col_begin, nchunks, ncol_tiles);
   INC_LAUNCH_RETURN();
+}
+
+
+// ---- K6 as ONE call: the whole blocked column loop of GPTQ.fasterquant (gptq.py:1250-1304) -------------------------------
+// The loop is a chain of launches per 128 columns -- [find_params] -> 128-step quantisation chain -> lazy update -- whose order
+// and stream placement a caller would otherwise have to restate (the look-ahead below, the rule that find_params reads W "as
+// it is now").  This entry point issues the chain itself on `stream`; with an `aux_stream` the bulk of every lazy update runs
+// there underneath the next block's quantisation chain (look-ahead: the chain of block b+1 needs only the NEXT 128 columns of
+// block b's update; rest(b-1) is awaited before next(b), so every column still receives its updates in block order from the
+// same 128-column tiles: W, codes and Q are bit-identical to the one-stream loop).  Nothing persistent is allocated: two HIP
+// events live for the duration of the call.
+int inc_gptq_quantize_layer(float* w, const float* Hinv, float* scale, float* zero, int64_t G, const float* loop_scale,
+                            const float* loop_zero, int64_t loop_G, uint8_t* codes, void* q_out, int q_dtype, float* err_ws,
+                            int64_t N, int64_t K, int group_size, int kernel_group_size, int block_size, int bits, int sym, int flags,
+                            inc_stream_t stream, inc_stream_t aux_stream) {
+  INC_CHECK_ARG(w && Hinv && scale && zero && err_ws && N > 0 && K > 0 && G > 0 && bits >= 1 && bits <= 8 && group_size > 0);
+  const bool dynamic_groups = (flags & INC_GPTQ_DYNAMIC_GROUPS) != 0, mse = (flags & INC_GPTQ_MSE) != 0;
+  const bool own_tables = loop_scale == nullptr || loop_scale == scale;
+  if (own_tables) { loop_scale = scale; loop_zero = zero; loop_G = G; }
+  INC_CHECK_ARG(loop_zero && loop_G > 0);
+  const int64_t blocksize = block_size > 0 ? block_size : K;
+  hipStream_t main = inc_s(stream), side = inc_s(aux_stream);
+  const bool lookahead = aux_stream != nullptr && (flags & INC_GPTQ_NO_LOOKAHEAD) == 0 && K % QB == 0 && blocksize % QB == 0 && K >= 3 * QB;
+  // find_params inside the quantisation launch: only when the reference block IS the 128-column block and every group lies inside it
+  const bool fuse_params = (flags & INC_GPTQ_NO_FUSED_PARAMS) == 0 && dynamic_groups && !mse && blocksize == QB &&
+                           (group_size == 32 || group_size == 64 || group_size == QB) && K % QB == 0 && own_tables &&
+                           (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32);
+  float* errs[2] = {err_ws, err_ws + N * QB};
+  hipEvent_t ready = nullptr, rest_done = nullptr;
+  bool rest_pending = false;
+  int rc = INC_OK;
+#define INC_TRY(call)                  \
+  {                                    \
+    const int r_ = (call);             \
+    if (r_ != INC_OK) { rc = r_; goto done; } \
+  }
+  if (lookahead) {
+    if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&rest_done, hipEventDisableTiming) != hipSuccess) {
+      rc = INC_ERR_LAUNCH;
+      goto done;
+    }
+    // w / Hinv / the tables were produced on the main stream
+    (void)hipEventRecord(ready, main);
+    (void)hipStreamWaitEvent(side, ready, 0);
+  }
+  {
+    int blk = 0;
+    for (int64_t i1 = 0; i1 < K; ++blk) {
+      const int64_t ref_end = std::min((i1 / blocksize + 1) * blocksize, K);  // end of the reference's block (gptq.py:1250)
+      const int count = (int)std::min<int64_t>(QB, ref_end - i1);
+      if (dynamic_groups && i1 % blocksize == 0 && !fuse_params) {
+        // groups that START inside this reference block read the global W as it is now (gptq.py:1266-1272)
+        const int64_t g_first = (i1 + group_size - 1) / group_size, g_last = (ref_end - 1) / group_size;
+        if (g_last >= g_first) {
+          if (lookahead && rest_pending && (g_last + 1) * group_size > i1 + QB) (void)hipStreamWaitEvent(main, rest_done, 0);
+          if (mse) INC_TRY(inc_gptq_find_params_mse(w, N, K, g_first * group_size, group_size, (int)(g_last - g_first + 1), bits, sym, 100, 0.8f, 2.4f, scale, zero, G, g_first, stream))
+          else INC_TRY(inc_gptq_find_params(w, N, K, g_first * group_size, group_size, (int)(g_last - g_first + 1), bits, sym, scale, zero, G, g_first, stream))
+        }
+      }
+      float* e = errs[lookahead ? (blk & 1) : 0];
+      if (fuse_params) INC_TRY(inc_gptq_quant_block_params(w, Hinv, scale, zero, codes, q_out, q_dtype, e, N, K, G, i1, count, group_size, bits, sym, stream))
+      else INC_TRY(inc_gptq_quant_block(w, Hinv, loop_scale, loop_zero, codes, q_out, q_dtype, e, N, K, loop_G, i1, count, kernel_group_size, bits, stream))
+      const int64_t i2 = i1 + count;
+      if (!lookahead) {
+        INC_TRY(inc_gptq_lazy_update(w, Hinv, e, N, K, i1, count, stream))
+      } else if (i2 < K) {
+        if (rest_pending) (void)hipStreamWaitEvent(main, rest_done, 0);  // rest(b-1) wrote the columns next(b) updates (and read Err of b-1)
+        const int64_t nxt_end = std::min<int64_t>(i2 + QB, K);
+        INC_TRY(inc_gptq_lazy_update_cols(w, Hinv, e, N, K, i1, count, i2, nxt_end, stream))
+        if (nxt_end < K) {
+          (void)hipEventRecord(ready, main);
+          (void)hipStreamWaitEvent(side, ready, 0);
+          INC_TRY(inc_gptq_lazy_update_cols(w, Hinv, e, N, K, i1, count, nxt_end, K, aux_stream))
+          (void)hipEventRecord(rest_done, side);
+          rest_pending = true;
+        }
+      }
+      i1 = i2;
+    }
+  }
+  if (lookahead && rest_pending) (void)hipStreamWaitEvent(main, rest_done, 0);  // w and both Err buffers are free again
+done:
+#undef INC_TRY
+  if (ready) (void)hipEventDestroy(ready);
+  if (rest_done) (void)hipEventDestroy(rest_done);
+  return rc;
 }
 
 }  // extern "C"

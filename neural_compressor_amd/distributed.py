@@ -3,12 +3,16 @@
 The reference has no distributed path on weight-only quantisation; this is new design, in the two
 forms SURVEY.md 8(e) derives from the algorithm's structure:
 
-  mode "layer"  (north_star): every transformer block is owned by one rank (block b -> rank b % world).  The input
-                activations of block b -- computed with the FLOAT model -- are broadcast from the rank that holds
-                them to the owner over xGMI, then all ranks quantise their own blocks concurrently.  Per-layer
-                results equal the single-GPU ones given the same inputs; the whole-model result differs from the
-                reference's sequential scheme (block b+1 calibrated on QUANTISED block b outputs, gptq.py:749-762),
-                which is why this mode is opt-in (`independent_blocks=True`) at the API level.
+  mode "layer"  (north_star; `prepare(model, GPTQConfig(...), independent_blocks=True)` or INC_MI355X_GPTQ_MULTI_GPU=layer; what
+                `bench.py --gpus N` times by default): every transformer block is owned by one rank (block b -> rank b % world).
+                Samples are sharded; per round of `world` blocks every rank forwards ITS samples through the round's FLOAT blocks,
+                the inputs of block b travel to its owner over xGMI -- point-to-point by default (each rank sends its shard to the
+                owner only: a balanced all-to-all over the per-pair links), INC_MI355X_GPTQ_ACT_EXCHANGE=broadcast for the
+                broadcast form -- and all ranks quantise their own blocks concurrently; the packed blocks are broadcast at the
+                end.  Per-layer results equal the single-GPU ones given the same inputs (bit-identical to a single process run of
+                this mode, tests/test_gpu_models.py); the whole-model result differs from the reference's sequential scheme
+                (block b+1 calibrated on QUANTISED block b outputs, gptq.py:749-762), which is why this mode is opt-in.
+                Implementation: RAWGPTQuantizer.independent_setup / independent_round / independent_finish (gptq.py).
   mode "sample" (exact): calibration samples are sharded across ranks; each rank accumulates its own running-mean
                 Hessian and `allreduce_hessian` combines them:  H = sum_r (n_r / n) H_r  (H is a sample mean, so the
                 combination is exact up to fp32 summation order).  One all-reduce of K*K fp32 per DISTINCT layer
@@ -16,7 +20,7 @@ forms SURVEY.md 8(e) derives from the algorithm's structure:
                 bound by one link, so large H go as reduce-scatter + all-gather (what RCCL's all_reduce does
                 internally for big messages); no activation ever crosses GPUs.
 
-  mode "sample+rows" (exact, what `bench.py --gpus N` times; SURVEY.md 8(e) (i)+(ii)+(iii)): ONE model quantised by N
+  mode "sample+rows" (exact; `bench.py --gpus N --mgpu-mode exact`; SURVEY.md 8(e) (i)+(ii)+(iii)): ONE model quantised by N
                 ranks.  Samples are sharded as in mode "sample" (block forwards and Hessian accumulation scale with N, no
                 activation crosses GPUs), but the solve is distributed too instead of being repeated on every rank:
                   * the i-th DISTINCT Hessian of a block is REDUCED to rank i % N (collective C1 as a reduce), which alone

@@ -473,6 +473,30 @@ def gptq_lazy_update_cols(w32, hinv, err, i1, count, col_begin, col_end):
     return True
 
 
+GPTQ_DYNAMIC_GROUPS, GPTQ_MSE, GPTQ_NO_LOOKAHEAD, GPTQ_NO_FUSED_PARAMS = 1, 2, 4, 8
+
+
+def gptq_quantize_layer(w32, hinv, scale, zero, loop_scale, loop_zero, codes, q_out, err_ws, group_size, kernel_group_size, block_size,
+                        bits, sym, flags, aux_stream=None):
+    """The whole blocked column loop of GPTQ.fasterquant (gptq.py:1250-1304) as ONE C-ABI call (include/inc_mi355x.h:
+    inc_gptq_quantize_layer): issued on the CURRENT stream, the bulk of the lazy updates on `aux_stream` (a torch stream) when
+    given.  `err_ws` is fp32 [2, N, 128]; `loop_scale` / `loop_zero` may be None (= scale / zero)."""
+    dev = _dev(w32, hinv, scale, zero, codes, q_out, err_ws)
+    N, K = w32.shape
+    assert err_ws.dtype == torch.float32 and err_ws.numel() >= 2 * N * 128
+    with torch.cuda.device(dev):
+        check(
+            lib.inc_gptq_quantize_layer(
+                _ptr(w32), _ptr(hinv), _ptr(scale), _ptr(zero), scale.shape[1], _ptr(loop_scale), _ptr(loop_zero),
+                loop_scale.shape[1] if loop_scale is not None else scale.shape[1], _ptr(codes), _ptr(q_out),
+                dtype_code(q_out.dtype) if q_out is not None else INC_F32, _ptr(err_ws), N, K, int(group_size), int(kernel_group_size),
+                int(block_size), int(bits), 1 if sym else 0, int(flags), _stream(),
+                aux_stream.cuda_stream if aux_stream is not None else None,
+            ),
+            "inc_gptq_quantize_layer",
+        )
+
+
 def chol_diag_block(A_view, Linv_view, info, tag):
     """In-place Cholesky of one <=128x128 diagonal block (a strided view into a larger fp32 matrix) + inverse of its
     factor into `Linv_view` (also a strided view).  See include/inc_mi355x.h: inc_chol_diag_block."""

@@ -100,6 +100,9 @@ class _CaptureDone(Exception):
 _LOOKAHEAD_STREAMS = {}
 
 
+ONE_CALL = os.environ.get("INC_MI355X_GPTQ_ONE_CALL", "1") != "0"  # the column loop through inc_gptq_quantize_layer
+
+
 def _lookahead_stream(device):
     """Second stream of the column loop (one per device, created on first use)."""
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
@@ -562,6 +565,22 @@ class GPTQ:
         # underneath it.  Every column still receives its updates in block order (rest(b-1) is awaited before next(b)), from
         # the same 128-column tiles: W, the codes and Q are bit-identical to the one-stream loop.
         lookahead = (LOOKAHEAD and N > 0 and K % QBLOCK == 0 and blocksize % QBLOCK == 0 and K >= 3 * QBLOCK and W.is_cuda)
+        if ONE_CALL and N > 0:
+            # the whole loop below as ONE C-ABI call (inc_gptq_quantize_layer issues the same launches in the same order from C++:
+            # bit-identical W / codes / Q; INC_MI355X_GPTQ_ONE_CALL=0 keeps the Python loop, which the tests compare it with)
+            flags = (ops.GPTQ_DYNAMIC_GROUPS if dynamic_groups else 0) | (ops.GPTQ_MSE if mse else 0)
+            flags |= 0 if FUSE_FIND_PARAMS else ops.GPTQ_NO_FUSED_PARAMS
+            main = torch.cuda.current_stream(W.device)
+            side = _lookahead_stream(W.device) if lookahead else None
+            err_ws = torch.empty((2, N, QBLOCK), dtype=torch.float32, device=W.device)
+            if side is not None:
+                for t in (w32, Hinv, scale, zero, loop_scale, loop_zero, codes, Q, err_ws):
+                    t.record_stream(side)
+            ops.gptq_quantize_layer(w32, Hinv, scale, zero, None if loop_scale is scale else loop_scale,
+                                    None if loop_scale is scale else loop_zero, codes, Q, err_ws, gs, kernel_gs, blocksize, bits, sym, flags,
+                                    aux_stream=side)
+            i1 = K
+            lookahead = False
         if lookahead:
             main = torch.cuda.current_stream(W.device)
             side = _lookahead_stream(W.device)

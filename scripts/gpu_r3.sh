@@ -23,6 +23,21 @@ while [[ $# -gt 0 ]]; do
     kbench)
       shift
       timeout 600 tools/kbench $1 > gpurun_out/kbench_$1.log 2>&1; echo "kbench $1 exit $?"; tail -60 gpurun_out/kbench_$1.log ;;
+    gptqtests)
+      timeout 1500 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider -k "gptq or fasterquant or column_loop or baseline" > gpurun_out/pytest_gptq.log 2>&1
+      echo "pytest(gptq) exit $?" | tee -a gpurun_out/pytest_gptq.log
+      grep -E "passed|failed|Error|error|assert" gpurun_out/pytest_gptq.log | tail -20 ;;
+    layer)
+      timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_parity.py -m gpu -q -s --timeout=900 -p no:cacheprovider -k "layer_per_gpu or non_positive_definite" > gpurun_out/pytest_layer.log 2>&1
+      echo "pytest(layer) exit $?" | tee -a gpurun_out/pytest_layer.log
+      grep -E "passed|failed|Error|error|assert" gpurun_out/pytest_layer.log | tail -20 ;;
+    bench2)
+      # the N-rank driver on ONE GPU: two ranks share the device, gloo between them (RCCL refuses two ranks per device)
+      for mode in layer exact; do
+        INC_MI355X_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --mgpu-mode $mode --steps 2 --warmup 1 --samples 32 --seq 1024 --no-cpu-baseline --no-gemm --no-extra-configs --e2e-blocks 4 > gpurun_out/bench_n2_$mode.log 2> gpurun_out/bench_n2_$mode.err
+        echo "bench --gpus 2 ($mode) exit $?"; tail -c 1500 gpurun_out/bench_n2_$mode.log; tail -8 gpurun_out/bench_n2_$mode.err
+      done
+      timeout 300 python bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_n2_nccl.log 2>&1; echo "bench --gpus 2 (nccl on one GPU: must refuse) exit $?"; tail -3 gpurun_out/bench_n2_nccl.log ;;
     prof)
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r2 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
       echo "prof exit $?"; find gpurun_out/prof -name "*kernel_stats*" | head -3 ;;

@@ -675,8 +675,11 @@ def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize
     W = torch.randn(N, K, generator=g) * 0.05
     X = torch.randn(6, 96, K, generator=g)
     outs = []
-    for look in (True, False):
+    # (look-ahead, one C-ABI call): inc_gptq_quantize_layer with / without its second stream, then the Python loop that issues the
+    # same launches one by one (INC_MI355X_GPTQ_ONE_CALL=0) with / without look-ahead -- all four must agree bit for bit
+    for look, one_call in ((True, True), (False, True), (True, False), (False, False)):
         monkeypatch.setattr(G, "LOOKAHEAD", look)
+        monkeypatch.setattr(G, "ONE_CALL", one_call)
         layer = torch.nn.Linear(K, N, bias=False).to(hip)
         layer.weight.data.copy_(W)
         gq = G.GPTQ(layer, device=hip)
@@ -686,10 +689,11 @@ def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize
         scale, _, zero, Q = gq.fasterquant(layer.weight.data, blocksize=blocksize, percdamp=0.01, groupsize=groupsize)
         torch.cuda.synchronize()
         outs.append((gq.codes.clone(), scale.clone(), None if zero is None else zero.clone(), Q.clone(), gq.acc.finalized))
-    a, b = outs
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
-    if a[2] is not None:
-        assert torch.equal(a[2], b[2])
+    a = outs[0]
+    for b in outs[1:]:
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+        if a[2] is not None:
+            assert torch.equal(a[2], b[2])
     # oracle with the HIP factor injected: rows may differ only where the oracle itself sits on a rounding tie
     fin = a[4]
     assert fin is not None and isinstance(fin[1], torch.Tensor) and fin[1].shape == (K, K)
