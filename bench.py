@@ -92,7 +92,7 @@ def _pmc_traffic(key):
     they come from separate `rocprofv3 --pmc` passes over THIS command (scripts/gpu_pmc_bench.sh: FETCH_SIZE doubled as
     the MI355X guide prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE), whose per-launch means are
     committed under profiles/ (newest round first); null when no PMC pass has been recorded for this kernel."""
-    for rnd in ("r2_pmc", "r1_pmc"):
+    for rnd in ("r3_pmc", "r2_pmc", "r1_pmc"):
         path = os.path.join(ROOT, "profiles", rnd, "bench_traffic.json")
         try:
             with open(path) as f:
@@ -266,7 +266,151 @@ def _cpu_baseline_worker(threads):
         t0 = time.time()
         layer(h, position_embeddings=pe, position_ids=pos)
         out["t_fwd"] = time.time() - t0
+    # pack / unpack / recover / quant_tensor of one 4096 x 4096 g128 layer (per-layer CPU figures)
+    import numpy as np
+
+    w = torch.randn(4096, 4096, generator=g) * 0.02
+    t0 = time.time()
+    iw, sc, _ = O.quant_tensor(w.clone(), bits=4, group_size=128, scheme="sym", return_int=True)
+    out["t_quant_tensor_4096"] = time.time() - t0
+    iwn, scn = iw.numpy().astype(np.int32), sc.numpy()
+    t0 = time.time()
+    qw, qz, s16 = O.woq_pack_optimum(iwn, scn, None, 4)
+    out["t_pack_4096"] = time.time() - t0
+    t0 = time.time()
+    O.woq_unpack_optimum(qw, qz, 4096, 4096, 32, 4)
+    out["t_unpack_4096"] = time.time() - t0
+    t0 = time.time()
+    O.woq_recover(qw, s16, qz, 4096, 4096, 4, 128)
+    out["t_recover_4096"] = time.time() - t0
     print(json.dumps(out), flush=True)
+
+
+def bench_ceilings(device):
+    """Measured ceilings of THIS chip in THIS run: a stream triad (a <- b + s c, fp32, 3 x 1 GiB) and a bare bf16 MFMA
+    loop on random operands, next to the datasheet figures the `frac` fields are priced against."""
+    from neural_compressor_amd import ops
+
+    n = 256 * 1024 * 1024
+    a = torch.empty(n, dtype=torch.float32, device=device)
+    b = torch.randn(n, dtype=torch.float32, device=device)
+    c = torch.randn(n, dtype=torch.float32, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        ops.probe_hbm_triad(a, b, c, 2.0)
+    e0.record()
+    for _ in range(5):
+        ops.probe_hbm_triad(a, b, c, 2.0)
+    e1.record()
+    torch.cuda.synchronize()
+    triad = 5 * 12.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b, c
+    src = torch.randn(64 * 1024, dtype=torch.bfloat16, device=device)
+    sink = torch.zeros(4096 * 256, dtype=torch.float32, device=device)
+    flops = ops.probe_mfma_bf16(src, sink, 4096, 2000)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        flops = ops.probe_mfma_bf16(src, sink, 4096, 2000)
+    e1.record()
+    torch.cuda.synchronize()
+    mfma = 3 * flops / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    torch.cuda.empty_cache()
+    return dict(hbm_stream_triad_gbs=round(triad, 1), hbm_spec_gbs=HBM_PEAK_GBS, bf16_mfma_loop_tflops=round(mfma, 1),
+                bf16_mfma_spec_tflops=BF16_MFMA_PEAK_TFLOPS,
+                note="measured in this run: triad = inc_probe_hbm_triad over 3 x 1 GiB fp32 (12 n bytes per call); MFMA loop = "
+                     "inc_probe_mfma_bf16, 16 waves per CU of back-to-back v_mfma_f32_32x32x16_bf16 on random operands (the chip "
+                     "clocks to its power budget: zero operands would read higher); every `frac` in this line is against the spec figures")
+
+
+def bench_per_layer(device, cpu):
+    """SURVEY 8(d) "report per-layer": the calls of one Llama-2-7B Linear on the GPU, each alone on the chip, next to the same
+    calls of the CPU baseline (`cpu` = the cpu_baseline object of this run, or None)."""
+    from neural_compressor_amd import ops
+    from neural_compressor_amd.torch.algorithms.weight_only import gptq as G
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps=3, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    def c(key):
+        return None if not cpu or cpu.get(key) is None else cpu[key]
+
+    out = {}
+    torch.manual_seed(0)
+    Hs = {}
+    for K in (4096, 11008):
+        x = torch.randn(16384, K, device=device, dtype=torch.bfloat16)
+        H = torch.zeros(K, K, device=device)
+        t = timed(lambda: ops.gptq_hessian_accum(H, x, 0.5, 0.5), reps=5, warm=2)
+        out[f"hessian_K{K}"] = dict(gpu_s_per_sample=round(t / 8, 6), cpu_s_per_sample=c(f"t_add_{K}"), tokens_per_launch=16384,
+                                    tflops=round(2.0 * 16384 * K * K / t / 1e12, 1), frac=round(2.0 * 16384 * K * K / t / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4))
+        acc = G.HessianAccumulator(K, device)
+        acc.add_batch(x.view(8, 2048, K))
+        Hs[K] = acc
+        del x, H
+    for N, K in ((4096, 4096), (11008, 4096), (4096, 11008)):
+        layer = torch.nn.Linear(K, N, bias=False, device=device, dtype=torch.bfloat16)
+        layer.weight.data.normal_(0, 0.02)
+        W0 = layer.weight.data.clone()
+        # (a) the whole solve: damp + inverse-Cholesky factor + column loop (GPTQ.fasterquant), a fresh accumulator copy each time
+        def solve():
+            a = G.HessianAccumulator(K, device)
+            a.H, a._n = Hs[K].H.clone(), Hs[K]._n
+            gq = G.GPTQ(layer, device=device, accumulator=a)
+            gq.configure(dict(bits=4, sym=True, dtype="int"))
+            gq.fasterquant(W0, blocksize=128, percdamp=0.01, groupsize=128)
+            return gq
+        Hs[K].flush()
+        t_solve = timed(solve, reps=2, warm=1)
+        # (b) the column loop alone, with the factor in hand (inc_gptq_quantize_layer)
+        a = G.HessianAccumulator(K, device)
+        a.H, a._n = Hs[K].H.clone(), Hs[K]._n
+        Hinv, dead, _ = a.inverse_factor(0.01, False)
+        scale = torch.empty(N, K // 128, device=device)
+        zero = torch.empty_like(scale)
+        codes = torch.empty(N, K, dtype=torch.uint8, device=device)
+        Q = torch.empty(N, K, dtype=torch.bfloat16, device=device)
+        err = torch.empty(2, N, 128, device=device)
+        side = G._lookahead_stream(device)
+
+        def loop():
+            w32 = ops.gptq_prepare_weight(W0, dead)
+            ops.gptq_quantize_layer(w32, Hinv, scale, zero, None, None, codes, Q, err, 128, 128, 128, 4, True, ops.GPTQ_DYNAMIC_GROUPS, aux_stream=side)
+        t_loop = timed(loop, reps=3, warm=1)
+        t_prep = timed(lambda: ops.gptq_prepare_weight(W0, dead), reps=3, warm=1)
+        t_loop -= t_prep
+        out[f"fasterquant_{N}x{K}"] = dict(gpu_s=round(t_solve, 5), cpu_s=c(f"t_fq_{N}x{K}"), column_loop_s=round(t_loop, 5),
+                                           column_loop_us_per_column=round(t_loop * 1e6 / K, 3),
+                                           column_loop_gbs=round(2.0 * N * K * 4 / t_loop / 1e9, 1),
+                                           column_loop_hbm_frac=round(2.0 * N * K * 4 / t_loop / 1e9 / HBM_PEAK_GBS, 4))
+        del layer, W0, Hinv, a, scale, zero, codes, Q, err
+    # pack / unpack / recover / quant_tensor of one 4096 x 4096 g128 layer (bytes: SURVEY 8(d))
+    N = K = 4096
+    w = torch.randn(N, K, device=device) * 0.02
+    t_q = timed(lambda: quant_tensor(w.clone(), bits=4, group_size=128, scheme="sym", return_int=True))
+    t_q -= timed(lambda: w.clone())
+    iw, sc, _ = quant_tensor(w.clone(), bits=4, group_size=128, scheme="sym", return_int=True)
+    m = MI355XWeightOnlyLinear(K, N, bits=4, group_size=128, device=device)
+    t_p = timed(lambda: m.pack(iw, sc, None, None))
+    t_u = timed(lambda: m.unpack())
+    t_r = timed(lambda: m.recover())
+    for key, t, byts, ck in (("quant_tensor_4096x4096", t_q, 2.0 * N * K * 4, "t_quant_tensor_4096"), ("pack_4096x4096", t_p, 4.0 * N * K + N * K / 2, "t_pack_4096"),
+                             ("unpack_4096x4096", t_u, N * K / 2 + 2.0 * N * K, "t_unpack_4096"), ("recover_4096x4096", t_r, N * K / 2 + 2.0 * N * K, "t_recover_4096")):
+        out[key] = dict(gpu_s=round(t, 6), cpu_s=c(ck), gbs=round(byts / t / 1e9, 1), hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(timeout_s=420):
@@ -404,6 +548,7 @@ def main():
     ap.add_argument("--no-gemm", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--no-per-layer", action="store_true")
     ap.add_argument("--mgpu-mode", choices=("layer", "exact"), default="layer", help="N > 1: one block per GPU on float activations (north_star) | exact reference semantics")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -575,6 +720,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         note("cpu baseline done")
+    if rank == 0 and not args.no_per_layer:
+        result["ceilings"] = bench_ceilings(device)
+        result["per_layer"] = bench_per_layer(device, result.get("cpu_baseline"))
+        note("ceilings + per-layer figures done")
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

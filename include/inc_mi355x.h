@@ -341,6 +341,13 @@ int inc_w8a8_gemm(const int8_t* xq, const int8_t* wq, const float* alpha, const 
                   int ydtype, int64_t M, int64_t N, int64_t K, void* workspace, int64_t workspace_bytes,
                   inc_stream_t stream);
 
+/* ---- measured ceilings (bench.py `ceilings`) -- measurement helpers, not on the hot path ------------- *
+ * inc_probe_hbm_triad: a <- b + s*c over n fp32 (n % 4 == 0): 12 n bytes of HBM traffic per call.
+ * inc_probe_mfma_bf16: `blocks` workgroups x 4 waves x `iters` x 8 v_mfma_f32_32x32x16_bf16 on operands read from `src`
+ *   (>= 64 KiB, any non-zero data); *flops_out (host pointer, may be NULL) receives the flops of the launch.            */
+int inc_probe_hbm_triad(float* a, const float* b, const float* c, float s, int64_t n, inc_stream_t stream);
+int inc_probe_mfma_bf16(const void* src, float* sink, int blocks, int iters, double* flops_out, inc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

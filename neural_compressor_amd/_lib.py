@@ -67,6 +67,8 @@ SIGNATURES = {
     "inc_gptq_quant_block_params": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
     "inc_gptq_lazy_update": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "inc_gptq_lazy_update_cols": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int64, c_int64, _P]),
+    "inc_probe_hbm_triad": (c_int, [_P, _P, _P, c_float, c_int64, _P]),
+    "inc_probe_mfma_bf16": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "inc_gptq_quantize_layer": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int, _P, c_int64, c_int64, c_int, c_int, c_int,
                                         c_int, c_int, c_int, _P, _P]),
     "inc_chol_diag_block": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, c_int, _P]),

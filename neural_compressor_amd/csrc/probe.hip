@@ -1,0 +1,66 @@
+// probe.hip -- measured ceilings for bench.py's `ceilings` object ("confirm the peaks with a stream triad and an
+// MFMA-loop microbenchmark and state the measured ceilings next to the paper ones").  Measurement helpers, not part of the hot path:
+// nothing in the product calls them.
+#include "common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// a[i] = b[i] + s * c[i], 16 bytes per lane and access, grid-stride: 3 * n * 4 bytes of HBM traffic
+__global__ __launch_bounds__(256) void probe_triad_kernel(float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c, float s, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 x = b[i], y = c[i];
+    a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+  }
+}
+
+// every wave: `iters` x 8 v_mfma_f32_32x32x16_bf16 on four independent accumulators, operands from memory (random data: the chip
+// clocks to its power budget, zero-filled operands would overstate the ceiling -- MI355X guide, DVFS)
+__global__ __launch_bounds__(256) void probe_mfma_kernel(const uint4* __restrict__ src, float* __restrict__ sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[2], b[2];
+  for (int i = 0; i < 2; ++i) {
+    const uint4 va = src[(threadIdx.x * 4 + i) & 4095], vb = src[(threadIdx.x * 4 + 2 + i) & 4095];
+    __builtin_memcpy(&a[i], &va, 16);
+    __builtin_memcpy(&b[i], &vb, 16);
+  }
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[3], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 16; ++r) s += acc[j][r];
+  if (s == 12345.678f) sink[blockIdx.x * 256 + threadIdx.x] = s + lane;  // keeps the MFMAs alive, (almost) never stores
+}
+
+}  // namespace
+
+extern "C" {
+
+// a <- b + s * c on n fp32 elements (n % 4 == 0, 16-byte aligned): HBM traffic 12 n bytes
+int inc_probe_hbm_triad(float* a, const float* b, const float* c, float s, int64_t n, inc_stream_t stream) {
+  INC_CHECK_ARG(a && b && c && n > 0 && (n % 4) == 0);
+  probe_triad_kernel<<<256 * 16, 256, 0, inc_s(stream)>>>((float4*)a, (const float4*)b, (const float4*)c, s, n / 4);
+  INC_LAUNCH_RETURN();
+}
+
+// `blocks` workgroups of 4 waves, each wave `iters` x 8 MFMA 32x32x16 bf16; src = 64 KiB of operand data; *flops_out (host) = flops launched
+int inc_probe_mfma_bf16(const void* src, float* sink, int blocks, int iters, double* flops_out, inc_stream_t stream) {
+  INC_CHECK_ARG(src && sink && blocks > 0 && iters > 0);
+  probe_mfma_kernel<<<blocks, 256, 0, inc_s(stream)>>>((const uint4*)src, sink, iters);
+  if (flops_out) *flops_out = (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;
+  INC_LAUNCH_RETURN();
+}
+
+}  // extern "C"

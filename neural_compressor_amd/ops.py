@@ -473,6 +473,25 @@ def gptq_lazy_update_cols(w32, hinv, err, i1, count, col_begin, col_end):
     return True
 
 
+def probe_hbm_triad(a, b, c, s):
+    """a <- b + s * c (fp32, same shape): the stream triad behind bench.py's `ceilings` (include/inc_mi355x.h)."""
+    dev = _dev(a, b, c)
+    with torch.cuda.device(dev):
+        check(lib.inc_probe_hbm_triad(_ptr(a), _ptr(b), _ptr(c), float(s), a.numel(), _stream()), "inc_probe_hbm_triad")
+
+
+def probe_mfma_bf16(src, sink, blocks, iters):
+    """Bare bf16 MFMA loop (bench.py `ceilings`); returns the flops of the launch."""
+    import ctypes
+
+    dev = _dev(src, sink)
+    assert src.numel() * src.element_size() >= 65536 and sink.numel() >= blocks * 256
+    flops = ctypes.c_double(0.0)
+    with torch.cuda.device(dev):
+        check(lib.inc_probe_mfma_bf16(_ptr(src), _ptr(sink), int(blocks), int(iters), ctypes.byref(flops), _stream()), "inc_probe_mfma_bf16")
+    return flops.value
+
+
 GPTQ_DYNAMIC_GROUPS, GPTQ_MSE, GPTQ_NO_LOOKAHEAD, GPTQ_NO_FUSED_PARAMS = 1, 2, 4, 8
 
 
