@@ -255,8 +255,10 @@ class HessianAccumulator:
 
     STAGE_TOKENS = int(os.environ.get("INC_MI355X_HESSIAN_STAGE_TOKENS", "16384"))
     # an input that already holds a full stage of tokens (the driver's stacked forwards) is read in place instead of being
-    # copied into the staging buffer; INC_MI355X_HESSIAN_ZERO_COPY=0 restores the copy (needed only for a model that
-    # modifies a Linear's input in place later in the same forward -- detected at launch time, never silent)
+    # copied into the staging buffer -- once the accumulator has SEEN that the model leaves such an input alone: the first
+    # eligible batch is still copied, and its version counter is compared when the update is launched (after the forward);
+    # only if it is unchanged do the later forwards skip the copy.  A model that edits a Linear's input in place later in
+    # the same forward therefore simply keeps the copying path.  INC_MI355X_HESSIAN_ZERO_COPY=0 forces the copy.
     ZERO_COPY = os.environ.get("INC_MI355X_HESSIAN_ZERO_COPY", "1") == "1"
 
     def __init__(self, columns, device):
@@ -268,6 +270,8 @@ class HessianAccumulator:
         self._stage = None    # [capacity tokens, K] staging buffer in the activation dtype
         self._fill = 0
         self._direct = None   # (x2d, version) of an input read in place at the next launch
+        self._zc_ok = None    # None: unknown yet; True: inputs survive their forward unmodified (zero-copy allowed); False: they do not
+        self._probe = None    # (x2d, version) of the copied batch whose version decides _zc_ok at launch time
         self.defer = False    # True: a full stage waits for flush_many (one launch for all Hessians of a forward)
         self.finalized = None  # (Hinv, dead, perm) cache keyed by (percdamp, act_order)
         self._info = None      # status word of a factorisation whose check was deferred (see check())
@@ -289,11 +293,14 @@ class HessianAccumulator:
         if self._direct is not None:
             self.flush()
         if self.ZERO_COPY and self._pending == 0 and T >= self.STAGE_TOKENS and x2d.is_contiguous() and x2d.data_ptr() % 16 == 0:
-            self._direct = (x2d, x2d._version)
-            self._pending = b
-            if not self.defer:
-                self.flush()
-            return
+            if self._zc_ok:
+                self._direct = (x2d, x2d._version)
+                self._pending = b
+                if not self.defer:
+                    self.flush()
+                return
+            if self._zc_ok is None and self.defer:
+                self._probe = (x2d, x2d._version)  # copied below; its version at launch time (after the forward) decides
         if self._stage is not None and (self._stage.dtype != x2d.dtype or self._fill + T > self._stage.shape[0]):
             self.flush()
             if self._stage.dtype != x2d.dtype or T > self._stage.shape[0]:
@@ -329,6 +336,10 @@ class HessianAccumulator:
                                    "set INC_MI355X_HESSIAN_ZERO_COPY=0 for this model")
         else:
             x = self._stage[: self._fill]
+            if self._probe is not None:
+                px, pv = self._probe
+                self._zc_ok = px._version == pv
+                self._probe = None
         n = self._n + self._pending
         return self.H, x, self._n / n, 2.0 / n
 
@@ -343,14 +354,17 @@ class HessianAccumulator:
             self._committed()
 
     @staticmethod
-    def flush_many(accs):
+    def flush_many(accs, only_due=False):
         """Fold the pending batches of several accumulators with ONE launch (inc_gptq_hessian_accum_multi) when the
-        library takes the batch, else one launch each; every tile is computed as in the single launch."""
+        library takes the batch, else one launch each; every tile is computed as in the single launch.  `only_due`: leave
+        partially filled stages alone (batches that cannot be stacked keep accumulating up to STAGE_TOKENS)."""
         todo, seen = [], set()
         for acc in accs:
             if id(acc) in seen:
                 continue
             seen.add(id(acc))
+            if only_due and acc._direct is None and acc._fill < acc.STAGE_TOKENS:
+                continue
             item = acc._launch_item()
             if item is not None:
                 todo.append((acc, item))
@@ -705,6 +719,7 @@ class RAWGPTQuantizer(object):
         self.share_hessians = kwargs.get("share_hessians", True)
         self.factor_streams = int(os.environ.get("INC_MI355X_GPTQ_FACTOR_STREAMS", "4"))
         self._fstreams = []
+        self._block_writes_input = None  # decided by the first block forward (see _run_block)
         self._stacks = {}  # first batch index of a forward group -> (stacked hidden states, the list entries that are its slices)
         self.block_callback = kwargs.get("block_callback", None)  # used by the multi-GPU driver
         # sample-sharded multi-GPU calibration: every rank feeds ITS calibration samples through prepare()/run_fn and the
@@ -879,12 +894,30 @@ class RAWGPTQuantizer(object):
                     kw["hidden_states"] = stacked
                 else:
                     pos[0] = stacked
+            # The hidden states handed to the block ARE the cached calibration inputs (or the stacked tensor whose slices they
+            # are): a block that writes its input in place would corrupt them for the next forward.  The first forward of the run
+            # therefore gets a clone whose version counter tells; such a model then always gets clones.
+            hkey = "hidden_states" if in_kwargs else None
+            given = kw[hkey] if in_kwargs else pos[0]
+            if isinstance(given, torch.Tensor) and self._block_writes_input is not False:
+                probe_in = given.clone()
+                v0 = probe_in._version
+                if in_kwargs:
+                    kw[hkey] = probe_in
+                else:
+                    pos[0] = probe_in
+            else:
+                probe_in = None
             try:
                 out = self.track_hidden_states(block(*pos, **kw))
             except _CaptureDone:
                 if not capture:
                     raise
                 out = None  # a capture pass that ended at its last hooked module: there is no output, and none is wanted
+            if probe_in is not None and self._block_writes_input is None:
+                self._block_writes_input = probe_in._version != v0
+                if self._block_writes_input:
+                    logger.warning("GPTQ: the block modifies its input in place; calibration inputs are cloned for every forward")
             if on_output is not None:
                 if out is None:
                     on_output(j0, None)
@@ -982,7 +1015,7 @@ class RAWGPTQuantizer(object):
             ref = torch.cat(singles, dim=0)
             if out.shape != ref.shape:
                 return False
-            tol = 1e-4 if stacked_in.dtype == torch.float32 else 3e-2
+            tol = 1e-4 if stacked_in.dtype == torch.float32 else 1e-2  # 16-bit GEMM-shape noise of a block is ~3-4e-3
             return bool((out - ref).norm() <= tol * ref.norm().clamp_min(1e-30))
         finally:
             for h, sv in zip(hooks, saved):
@@ -1368,7 +1401,7 @@ class RAWGPTQuantizer(object):
             def after_forward(j, out):
                 live.clear()
                 seen.clear()
-                HessianAccumulator.flush_many(accs)
+                HessianAccumulator.flush_many(accs, only_due=True)
                 if capture["probe"]:
                     # the first (complete) forward of the pass showed the order in which the hooked modules run: when each ran
                     # exactly once, later forwards of this pass end at the last one -- its own GEMM and everything behind it

@@ -30,6 +30,7 @@ from .modules import MI355XWeightOnlyLinear, MulLinear
 WEIGHT_NAME = "quantized_weight.pt"  # reference torch/utils/utility.py:56
 QCONFIG_NAME = "qconfig.json"        # reference torch/utils/utility.py:60
 HF_QCONFIG_NAME = "quantize_config.json"
+LAYOUT_NAME = "mi355x_woq_layout.json"  # layout of modules saved in the non-optimum format (NF4 / FP4, use_optimum_format=False)
 LM_HEAD_NAMES = [".*lm_head", ".*output_layer", ".*embed_out"]  # reference torch/utils/constants.py:69
 
 # device string -> packed Linear class (the reference's plug-in seam, save_load.py:50)
@@ -72,10 +73,16 @@ def change_config_to_hf_format(config_mappings):
 def save(model, output_dir="./saved_results", format="default", **kwargs):
     """Save the quantised model and its configuration (reference save_load.py:56-108)."""
     fmt = getattr(format, "value", format)
+    # modules in the reference's NON-optimum layout (NF4 / FP4 always, integer formats with use_optimum_format=False): the default
+    # format keeps their layout in a side file the loader reads (the reference's loader infers nothing either: it rebuilds with the
+    # flags of its own process); the huggingface format IS the optimum (AutoGPTQ) layout and cannot hold them
+    layout = {}
     for name, mod in model.named_modules():
         if isinstance(mod, MI355XWeightOnlyLinear) and not getattr(mod, "use_optimum_format", True):
-            # both on-disk formats ARE the optimum (HF / AutoGPTQ) layout; the loader rebuilds modules in that layout only
-            raise ValueError(f"{name} was packed with use_optimum_format=False; convert with the default optimum format to save it")
+            if fmt == "huggingface":
+                raise ValueError(f"{name} was packed with use_optimum_format=False; the huggingface format is the optimum layout")
+            layout[name] = dict(use_optimum_format=False, compression_dim=mod.compression_dim, compression_dtype=str(mod.compression_dtype).replace("torch.", ""),
+                                scale_dtype=str(mod.float_type).replace("torch.", ""), dtype=mod.dtype, bits=mod.bits, group_size=mod.group_size)
     os.makedirs(output_dir, exist_ok=True)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
@@ -98,6 +105,9 @@ def save(model, output_dir="./saved_results", format="default", **kwargs):
         raise ValueError(f"unknown save format {format!r}: expected 'default' or 'huggingface'")
     folder = os.path.abspath(os.path.expanduser(output_dir))
     save_config_mapping(model.qconfig, os.path.join(folder, QCONFIG_NAME))
+    if layout:
+        with open(os.path.join(folder, LAYOUT_NAME), "w", encoding="utf-8") as f:
+            json.dump(layout, f, indent=1)
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}  # device-neutral file, like the reference's CPU model
     torch.save(state, os.path.join(folder, WEIGHT_NAME))
     logger.info("Save quantized model weight to %s.", os.path.join(folder, WEIGHT_NAME))
@@ -116,8 +126,9 @@ def _module_config(quantization_config, name, module):
     return quantization_config
 
 
-def _build(original_model, state, quantization_config, device):
+def _build(original_model, state, quantization_config, device, layout=None):
     keys = set(state.keys())
+    layout = layout or {}
     try:
         from transformers import Conv1D
     except Exception:  # pragma: no cover
@@ -136,11 +147,20 @@ def _build(original_model, state, quantization_config, device):
         if name + ".linear.qweight" in keys:  # AWQ / TEQ: a multiplier in front of the packed layer (reference :479-482)
             set_module(original_model, name, MulLinear(module))
             target = name + ".linear"
-        new = MI355XWeightOnlyLinear(
-            in_features, out_features, dtype=cfg.get("dtype", "int"), bits=cfg.get("bits", 4),
-            group_size=cfg.get("group_size", 32), zp=(target + ".qzeros") in keys, bias=module.bias is not None,
-            g_idx=(target + ".g_idx") in keys, use_optimum_format=True, device=device,
-        )
+        lay = layout.get(target)
+        if lay is not None:  # saved from a non-optimum module: rebuild exactly that layout
+            new = MI355XWeightOnlyLinear(
+                in_features, out_features, dtype=lay["dtype"], bits=lay["bits"], group_size=lay["group_size"],
+                zp=(target + ".qzeros") in keys, bias=(target + ".bias") in keys, g_idx=(target + ".g_idx") in keys,
+                use_optimum_format=False, compression_dim=lay["compression_dim"], compression_dtype=getattr(torch, lay["compression_dtype"]),
+                scale_dtype=getattr(torch, lay["scale_dtype"]), device=device,
+            )
+        else:
+            new = MI355XWeightOnlyLinear(
+                in_features, out_features, dtype=cfg.get("dtype", "int"), bits=cfg.get("bits", 4),
+                group_size=cfg.get("group_size", 32), zp=(target + ".qzeros") in keys, bias=module.bias is not None,
+                g_idx=(target + ".g_idx") in keys, use_optimum_format=True, device=device,
+            )
         own = {}
         for k in ("qweight", "scales", "scale_bf16_to_fp8", "qzeros", "bias", "g_idx"):
             full = f"{target}.{k}"
@@ -181,7 +201,11 @@ def load(model_name_or_path, original_model=None, format="default", device="cuda
         state = torch.load(wpath, map_location="cpu", weights_only=True)  # safe defaults, reference :287-305
         with open(cpath) as f:
             qcfg = json.load(f)
-        model = _build(original_model, state, qcfg, dev)
+        layout = None
+        if os.path.exists(os.path.join(folder, LAYOUT_NAME)):
+            with open(os.path.join(folder, LAYOUT_NAME)) as f:
+                layout = json.load(f)
+        model = _build(original_model, state, qcfg, dev, layout)
         # what is left are float tensors AWQ/TEQ touched (folded norms, MulLinear.input_scale) and untouched parameters
         model.load_state_dict(state, strict=False, assign=True)
         model.to(dev)

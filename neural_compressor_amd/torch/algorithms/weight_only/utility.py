@@ -81,6 +81,16 @@ def quant_tensor(
     # ---- double quantisation (utility.py:378-436): the [N, G] scales are themselves quantised, as ONE row in groups of
     # double_quant_group_size; "asym" = subtract the mean, quantise symmetrically, add it back
     int_weight, scale, zp = actor(weight, True)
+    K_ = weight.shape[1]
+    if group_size != -1 and K_ > group_size and K_ % group_size != 0:
+        # the reference's "case 3" (a tail group) returns (ints, scale, zp) BEFORE its double-quant step, whatever return_int
+        # says (utility.py:334-376): reproduced as it is
+        return int_weight, scale, zp
+    # the reference double-quantises the scales in the dtype its actor returns them in -- fp32 from qdq_weight_asym, the WEIGHT
+    # dtype from qdq_weight_sym and quantize_4bit (probed on the unmodified reference, tests/golden/make_golden_nf4.py): mean,
+    # subtraction, quantisation and the final addition all round to it
+    if not (dtype == "int" and scheme == "asym"):
+        scale = scale.to(weight.dtype)
     scale_dtype = kwargs.get("double_quant_dtype", "int")
     scale_bits = kwargs.get("double_quant_bits", 8)
     scale_scheme = kwargs.get("double_quant_scheme", "asym")
@@ -110,7 +120,7 @@ def quant_tensor(
         vals = lut[(int_weight + 8).long()]
     elif zp is not None:
         vals = vals - zp.repeat_interleave(gs, dim=1)[:, :K]
-    weight.copy_((vals * scale.repeat_interleave(gs, dim=1)[:, :K]).to(weight.dtype))
+    weight.copy_((vals * scale.float().repeat_interleave(gs, dim=1)[:, :K]).to(weight.dtype))  # exact product, rounded once = the reference's 16-bit multiply
     return weight
 
 

@@ -112,13 +112,15 @@ def get_accelerator(device_name="auto"):
 def batch_broadcastable(obj):
     """True when `obj` (a block-forward argument other than the hidden states: tensor / nested tuples, lists, dicts /
     plain Python value) can be reused unchanged for a STACK of calibration batches: every tensor in it has a leading
-    dimension of 1 (or is 0-d), i.e. it broadcasts over the batch.  Batch-folded arguments such as Bloom / Falcon / MPT
+    dimension of 1 (or is 0-d / 1-d), i.e. it broadcasts over the batch.  Batch-folded arguments such as Bloom / Falcon / MPT
     `alibi` [batch * heads, 1, T] fail this test, and such models are then run one calibration batch per forward, as
     the reference does."""
     import torch
 
     if isinstance(obj, torch.Tensor):
-        return obj.dim() == 0 or obj.shape[0] == 1
+        # (a 1-D tensor has no batch dimension at all -- e.g. `cache_position` [T] of transformers 4.38+: stacking batches does not
+        # change it; the callers' faithful-stacking probe compares a stacked forward with the per-batch ones anyway)
+        return obj.dim() <= 1 or obj.shape[0] == 1
     if isinstance(obj, (tuple, list)):
         return all(batch_broadcastable(o) for o in obj)
     if isinstance(obj, dict):

@@ -6,6 +6,7 @@
         nf4_g32, fp4_g32, fp4e2m1_g32, nf4_tail (K = 80, group 32: a 16-wide tail group), nf4_pc (group_size -1),
         nf4_zero (one all-zero group: the reference's 0/0 path), nf4_q09 (quantile 0.9)
         dq_int4 (int4 asym g32 + double_quant int8 asym group 256), dq_nf4 (nf4 g32 + the same double quant)
+        dq_bf16 / dq_bf16_sym (bf16 weights: the asym actor hands fp32 scales on, the sym / code-book actors bf16 ones -- double-quantised in THAT dtype), dq_ragged (K = 80: no double quant, utility.py:334-376)
   rtn_nf4_<module>.qweight / .scales + rtn_nf4_logits   RTNConfig(dtype="nf4", group_size=32) on tests/model_zoo.tiny_llama
 """
 
@@ -58,6 +59,22 @@ def main():
         out[f"{tag}_scale"] = res[1].numpy()
         if res[2] is not None:
             out[f"{tag}_zp"] = res[2].numpy()
+
+    # 16-bit weights: the reference double-quantises the scales IN THE WEIGHT DTYPE (mean / sub / quant / add on a bf16 tensor),
+    # and a ragged K (K % group_size != 0) returns from its "case 3" branch BEFORE the double-quant step (utility.py:334-376)
+    w16 = (torch.randn(64, 128, generator=g) * 0.05).to(torch.bfloat16)
+    out["dq_bf16_w"] = w16.float().numpy().copy()
+    res = quant_tensor(w16.clone(), return_int=True, dtype="int", bits=4, group_size=32, scheme="asym", **DQ)
+    out["dq_bf16_int"], out["dq_bf16_scale"], out["dq_bf16_zp"] = res[0].float().numpy(), res[1].float().numpy(), res[2].float().numpy()
+    out["dq_bf16_qdq"] = quant_tensor(w16.clone(), dtype="int", bits=4, group_size=32, scheme="asym", **DQ).float().numpy()
+    res = quant_tensor(w16.clone(), return_int=True, dtype="int", bits=4, group_size=32, scheme="sym", **DQ)
+    out["dq_bf16_sym_int"], out["dq_bf16_sym_scale"] = res[0].float().numpy(), res[1].float().numpy()
+    out["dq_bf16_sym_scale_is_bf16"] = np.bool_(res[1].dtype == torch.bfloat16)
+    out["dq_bf16_sym_qdq"] = quant_tensor(w16.clone(), dtype="int", bits=4, group_size=32, scheme="sym", **DQ).float().numpy()
+    wr = torch.randn(16, 80, generator=g) * 0.05
+    out["dq_ragged_w"] = wr.numpy().copy()
+    res = quant_tensor(wr.clone(), return_int=True, dtype="int", bits=4, group_size=32, scheme="asym", **DQ)
+    out["dq_ragged_int"], out["dq_ragged_scale"], out["dq_ragged_zp"] = res[0].numpy(), res[1].numpy(), res[2].numpy()
 
     q = quantize(tiny_llama(), RTNConfig(dtype="nf4", group_size=32, use_layer_wise=False))
     n = 0

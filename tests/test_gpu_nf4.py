@@ -73,6 +73,33 @@ def test_double_quant_vs_reference_golden(hip, g, tag, kw):
     np.testing.assert_allclose(qdq.cpu().numpy(), g[f"{tag}_qdq"], rtol=3e-6, atol=1e-9)
 
 
+def test_double_quant_16bit_and_ragged_vs_reference_golden(hip, g):
+    """bf16 weights: the scales are double-quantised in the dtype the reference's actor returns them in (fp32 from the asym actor,
+    bf16 from the sym one: mean / sub / quant / add round to it); a ragged K returns (ints, scale, zp) WITHOUT double
+    quantisation, the reference's "case 3" (utility.py:334-376)."""
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    w = torch.from_numpy(g["dq_bf16_w"]).to(torch.bfloat16).to(hip)
+    for tag, scheme, is16 in (("dq_bf16", "asym", False), ("dq_bf16_sym", "sym", True)):
+        kw = dict(dtype="int", bits=4, group_size=32, scheme=scheme)
+        iw, sc, zp = quant_tensor(w.clone(), return_int=True, **kw, **DQ)
+        assert np.array_equal(iw.cpu().float().numpy(), g[f"{tag}_int"]), tag
+        assert (sc.dtype == torch.bfloat16) == is16 == bool(g["dq_bf16_sym_scale_is_bf16"] if is16 else False), tag
+        # the mean of the scales is a device reduction: allow the last bit of the working dtype on a few entries
+        ulp = 2.0 ** -7 if is16 else 4e-6
+        d = np.abs(sc.cpu().float().numpy() - g[f"{tag}_scale"]) / np.abs(g[f"{tag}_scale"])
+        assert float(d.max()) <= ulp and float((d > 0).mean()) <= (0.05 if is16 else 1.0), (tag, float(d.max()), float((d > 0).mean()))
+        qdq = quant_tensor(w.clone(), **kw, **DQ)
+        d = np.abs(qdq.cpu().float().numpy() - g[f"{tag}_qdq"]) / np.maximum(np.abs(g[f"{tag}_qdq"]), 1e-6)
+        assert float(d.max()) <= 2.0 ** -7 and float((d > 0).mean()) <= 0.05, (tag, float(d.max()), float((d > 0).mean()))
+    kw = dict(dtype="int", bits=4, group_size=32, scheme="asym")
+    wr = torch.from_numpy(g["dq_ragged_w"]).to(hip)
+    res = quant_tensor(wr.clone(), **kw, **DQ)  # (the reference returns the tuple here even without return_int)
+    assert isinstance(res, tuple)
+    assert np.array_equal(res[0].cpu().numpy().astype(np.float32), g["dq_ragged_int"])
+    assert np.array_equal(res[1].cpu().numpy(), g["dq_ragged_scale"]) and np.array_equal(res[2].cpu().numpy(), g["dq_ragged_zp"])
+
+
 def test_rtn_nf4_tiny_llama_vs_reference(hip, g):
     """RTNConfig(dtype="nf4"): the reference packs the stored integers in its NON-optimum layout (qweight [N, K/8] int32, scales
     [N, G], no zero points, modules.py:213-221) -- every packed buffer bit-identical, recover() = code-book value x scale, and
@@ -95,3 +122,27 @@ def test_rtn_nf4_tiny_llama_vs_reference(hip, g):
         y = q(calib_ids()[0].to(hip)).logits.float().cpu().numpy()
     ref = g["rtn_nf4_logits"]
     assert np.linalg.norm(y - ref) / np.linalg.norm(ref) <= 2e-2
+
+
+def test_rtn_nf4_save_load_round_trip(hip, g, tmp_path):
+    """NF4 modules live in the reference's non-optimum layout; save() keeps that layout in a side file and load() rebuilds it:
+    every packed buffer and the logits survive the round trip."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.algorithms.weight_only.save_load import load, save
+    from neural_compressor_amd.torch.quantization import RTNConfig, quantize
+
+    q = quantize(tiny_llama(), RTNConfig(dtype="nf4", group_size=32, use_layer_wise=False))
+    ids = calib_ids()[0].to(hip)
+    with torch.no_grad():
+        y0 = q(ids).logits.float().cpu()
+    save(q, str(tmp_path))
+    back = load(str(tmp_path), original_model=tiny_llama(), device=hip)
+    a = {n: m for n, m in q.named_modules() if isinstance(m, MI355XWeightOnlyLinear)}
+    b = {n: m for n, m in back.named_modules() if isinstance(m, MI355XWeightOnlyLinear)}
+    assert a.keys() == b.keys() and len(a) == 14
+    for n in a:
+        assert not b[n].use_optimum_format and b[n].dtype == "nf4"
+        assert torch.equal(a[n].qweight, b[n].qweight) and torch.equal(a[n].scales, b[n].scales)
+    with torch.no_grad():
+        y1 = back(ids).logits.float().cpu()
+    assert torch.equal(y0, y1)
