@@ -258,7 +258,8 @@ def _nibble_match(a, b):
 
 
 # (block 0, block 1) code-match budgets: measured values minus a margin (see _parity_report)
-GPTQ_CODE_BUDGET = {"sym_g32": (0.98, 0.90), "asym_g32": (0.98, 0.90)}
+# measured on MI355X (profiles/r3_parity_report.txt): 1.00000 / 1.00000 for both configurations
+GPTQ_CODE_BUDGET = {"sym_g32": (0.9995, 0.995), "asym_g32": (0.9995, 0.995)}
 
 
 def _parity_report(tag, mods, g, n_blocks=2):
@@ -320,7 +321,7 @@ def test_gptq_tiny_llama_vs_reference(tag, sym):
         match = _nibble_match(m.qweight.cpu().numpy(), g[f"{name}.qweight"])
         worst = min(worst, match)
         s, rs = m.scales.float().cpu(), torch.from_numpy(g[f"{name}.scales"].astype(np.float32))
-        assert float((s - rs).norm() / rs.norm()) <= 2e-2, name
+        assert float((s - rs).norm() / rs.norm()) <= 1e-3, name
     # block 0 sees identical inputs -> near-perfect agreement; later blocks inherit flipped codes from earlier ones.  The budget is
     # the MEASURED one (profiles/r3_parity_report.txt) with a margin, per block -- not a floor a regression could hide under
     first = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items() if ".layers.0." in n)
@@ -328,12 +329,18 @@ def test_gptq_tiny_llama_vs_reference(tag, sym):
     assert rep[0]["code_match"] >= GPTQ_CODE_BUDGET[tag][0] and rep[1]["code_match"] >= GPTQ_CODE_BUDGET[tag][1], rep
     # north_star's number: per-group scales within 1e-3 relative wherever the integer codes agree (block 0: same inputs as the reference)
     assert rep[0]["clean_channels"] > 0.5 and rep[0]["scale_rel_on_clean"] <= 1e-3, rep
-    assert first >= 0.98, first
-    assert worst >= 0.90, worst
+    assert first >= 0.999, first
+    assert worst >= 0.99, worst
     with torch.no_grad():
         y = q(ids[0].to("cuda")).logits.float().cpu()
     ref = torch.from_numpy(g["logits"])
-    assert float((y - ref).norm() / ref.norm()) <= 5e-2
+    rel = float((y - ref).norm() / ref.norm())
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "parity_report.txt"), "a") as f:
+            f.write(f"gptq_tiny_llama_{tag}: logits rel-Frobenius vs the reference's CPU model {rel:.3e}\n")
+    except OSError:
+        pass
+    assert rel <= 1e-2, rel
 
 
 @pytest.mark.parametrize("tag,kw", [
@@ -366,6 +373,7 @@ def test_gptq_options_tiny_llama_vs_reference(tag, kw):
     else:
         first = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items() if ".layers.0." in n)
         worst = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items())
+        _parity_report(f"gptq_tiny_llama_{tag}", mods, g)
         # mse: a grid argmin may land on the neighbouring point; true_sequential: the later groups of a block are calibrated
         # through the already PACKED q/k/v, whose fused kernel multiplies in fp16 where the reference's CPU module uses fp32
         assert first >= 0.95 and worst >= 0.88, (first, worst)
