@@ -278,6 +278,8 @@ class WrapperLayer(torch.nn.Module):
         self.weight_scale, self.input_scale = None, None
         self.save_q_input = save_q_input
         self.output = None
+        self.do_blockwise = False  # block-wise tuning: the weight is already fake-quantised for the candidate alpha (_bw_weight)
+        self._bw_weight = None
 
     def enable_quant(self):
         self.quant = True
@@ -305,11 +307,36 @@ class WrapperLayer(torch.nn.Module):
         bias = None if lin.bias is None else lin.bias.float()
         return torch.nn.functional.linear(x, w_qdq, bias)
 
+    def q_dq_forward_blockwise(self, x, input_scale):
+        """Reference :2731-2748: the input is fake-quantised as in q_dq_forward, the weight was prepared by the tuner."""
+        lin = self.orig_layer
+        x = x.float()
+        if input_scale is None:
+            x = quant_dequant_x_v1(x, self.input_min, self.input_max)
+        else:
+            x = input_scale * x
+            x = quant_dequant_x_v1(x, self.input_min * input_scale, self.input_max * input_scale)
+        bias = None if lin.bias is None else lin.bias.float()
+        return torch.nn.functional.linear(x, self._bw_weight, bias)
+
+    def prepare_blockwise(self):
+        """The tuner's per-alpha preparation of one layer (reference :1676-1681): weight * weight_scale, fake-quantised."""
+        w = self.orig_layer.weight.detach().float()
+        if self.weight_scale is not None:
+            w = w * self.weight_scale
+        tmp = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, device=w.device)
+        tmp.weight.data = w
+        self._bw_weight = quant_dequant_w_v1(tmp)
+        self.do_blockwise = True
+
     def forward(self, x):
         if self.quant:
             if self.save_q_input:
                 self.q_input = x
-            output = self.q_dq_forward(x, self.input_scale, self.weight_scale).to(x.dtype)
+            if self.do_blockwise:
+                output = self.q_dq_forward_blockwise(x, self.input_scale).to(x.dtype)
+            else:
+                output = self.q_dq_forward(x, self.input_scale, self.weight_scale).to(x.dtype)
         else:
             output = self.orig_layer(x)
         self.output = output
@@ -326,20 +353,18 @@ class AutoAlpha:
     re-initialised for every sample (:1776), so the "accumulated" table only ever holds the CURRENT sample's losses -- the
     alphas are updated every n_samples // 4 samples from that sample alone and the final choice is made on the last sample.
     Everything runs in HBM: forwards are torch, the fake quantisation uses inc_sq_quant_weight + elementwise torch ops.
-    do_blockwise is not implemented (it deep-copies every block per alpha and sample in the reference)."""
+    `do_blockwise=True` (reference :1821) tunes on BLOCK outputs instead: see _get_one_batch_auto_loss_blockwise."""
 
     def __init__(self, model, dataloader, absorb_to_layer, op_types, device, q_func, example_inputs, weight_clip=True,
                  alpha_min=0.3, alpha_max=0.7, alpha_step=0.1, shared_criterion="mean", init_alpha=0.5, folding=False,
                  do_blockwise=False, n_samples=32, calibration=None):
-        if do_blockwise:
-            raise NotImplementedError("SmoothQuant alpha='auto' with do_blockwise=True is not implemented on MI355X")
         self.model = model
         self.model.eval()
         self.dataloader = dataloader
         self.alpha_min, self.alpha_max, self.alpha_step = alpha_min, alpha_max, alpha_step
         self.shared_criterion = shared_criterion
         self.init_alpha = init_alpha
-        self.loss_type = "model_wise"
+        self.loss_type = "blockwise" if do_blockwise else "model_wise"
         self.calib_sample_num = n_samples if n_samples else 32
         self.op_types = op_types
         self.absorb_to_layer = absorb_to_layer
@@ -369,7 +394,33 @@ class AutoAlpha:
         if not self.folding:
             for d in set(self.absorb_to_layer.keys()).difference(self.input_mins.keys()):
                 del self.absorb_to_layer[d]
+        if self.loss_type == "blockwise":  # reference :1304-1322
+            module_names = self._get_sq_layer_names()
+            block_names, self.block_to_module = self.get_blocks(), {}
+            for block in block_names:
+                self.block_to_module[block] = []
+            for module in module_names:
+                checked = False
+                for block in block_names:
+                    if block + "." in module:
+                        self.block_to_module[block].append(module)
+                        checked = True
+                if not checked:
+                    self.block_to_module[module] = [module]
+            self.block_names = list(self.block_to_module.keys())
+            logger.info("Blockwise auto-tuning: %d blocks found", len(self.block_names))
+            return self._auto_tune_alpha_blockwise()
         return self._auto_tune_alpha()
+
+    def get_blocks(self):
+        """The children of the model's first ModuleList (reference :1326-1335)."""
+        block_names = []
+        for n, m in self.model.named_modules():
+            if "ModuleList" in type(m).__name__:
+                for nn_, _ in m.named_children():
+                    block_names.append(n + "." + nn_)
+                break
+        return block_names
 
     # -- helpers with the reference's names -------------------------------------------------------------------------------
     def _get_all_hook_module_names(self):
@@ -496,6 +547,113 @@ class AutoAlpha:
                 loss_alphas[name][str(alpha)] = self._get_auto_loss(fp32_output[name], output)
         # one device -> host copy per sample (the reference compares 0-d CPU tensors)
         return {n: {a: float(v) for a, v in d.items()} for n, d in loss_alphas.items()}
+
+    def _get_one_batch_auto_loss_blockwise(self, call, alpha_space, orig_best_alpha, input_maxes):
+        """Reference :1618-1693.  Per sample: the float outputs of every block, a fake-quant forward at the current alphas (which
+        leaves every block's INPUT under quantisation behind), then every block re-run on that input for every alpha of the grid
+        with its tuned Linears fake-quantised for that alpha; loss = block output vs float block output.  The reference deep-copies
+        the block per (alpha, sample); here the block's own wrappers are switched to the prepared weights and back (same arithmetic).
+        Like the reference the replay hands the block ONLY its hidden states (no attention mask: :1685); models whose block cannot
+        run like that get the reference's position_ids retry and then the captured call's own arguments."""
+        self._change_qdq_for_auto(enable=False)
+        block_modules = {key: get_module(self.model, key) for key in self.block_names}
+        handles, captured = [], {}
+
+        def save(name):
+            def hook(module, args, kwargs, outputs):
+                self.block_inputs[name] = args[0]
+                self.block_outputs[name] = outputs[0]
+                captured[name] = (args, kwargs)
+            return hook
+
+        for key, mod in block_modules.items():
+            handles.append(mod.register_forward_hook(save(key), with_kwargs=True))
+        try:
+            self._forward(call)  # quantisation off: float block outputs
+            fp32_output = {name: self.block_outputs[name] for name in self.block_names}
+            self._change_qdq_for_auto(enable=True)
+            absorb_input_scales, weight_scales = self._cal_scales(self.absorb_to_layer, input_maxes, orig_best_alpha)
+            self._update_scales_for_auto(absorb_input_scales, weight_scales)
+            self._forward(call)  # quantisation on at the current alphas: block inputs / outputs under quantisation
+            loss_alphas = {}
+            for block_name in self.block_names:
+                loss = self._get_auto_loss(fp32_output[block_name], self.block_outputs[block_name])
+                cur_alpha = orig_best_alpha
+                if isinstance(orig_best_alpha, dict):
+                    cur_alpha = orig_best_alpha[self.block_to_module[block_name][0]]
+                loss_alphas[block_name] = {str(cur_alpha): loss}
+            block_in = dict(self.block_inputs)
+            block_call = dict(captured)
+            for alpha in alpha_space:
+                absorb_input_scales, weight_scales = self._cal_scales(self.absorb_to_layer, input_maxes, alpha)
+                self._update_scales_for_auto(absorb_input_scales, weight_scales)
+                for block_name in self.block_names:
+                    if str(alpha) in loss_alphas[block_name]:
+                        continue
+                    block = block_modules[block_name]
+                    wrappers = [block if (name == block_name and len(self.block_to_module[block_name]) == 1) else get_module(self.model, name)
+                                for name in self.block_to_module[block_name]]
+                    for w in wrappers:
+                        w.prepare_blockwise()
+                    try:
+                        x = block_in[block_name]
+                        try:
+                            output = block(x)[0]
+                        except Exception:  # the reference's retry (:1687-1689), then the block's own captured arguments
+                            try:
+                                position_ids = torch.arange(x.size()[1], device=x.device).view(x.size()[0], -1)
+                                output = block(x, position_ids=position_ids)[0]
+                            except Exception:
+                                args, kwargs = block_call[block_name]
+                                output = block(*args, **kwargs)[0]
+                    finally:
+                        for w in wrappers:
+                            w.do_blockwise, w._bw_weight = False, None
+                    loss_alphas[block_name][str(alpha)] = self._get_auto_loss(fp32_output[block_name], output)
+        finally:
+            for h in handles:
+                h.remove()
+        return {n: {a: float(v) for a, v in d.items()} for n, d in loss_alphas.items()}
+
+    def _auto_tune_alpha_blockwise(self):
+        """Reference :1821-1892 (with its per-sample reset of the loss table, like the model-wise tuner)."""
+        logger.info("Start block-wise alpha tuning")
+        self.block_inputs, self.block_outputs = {}, {}
+        self.default_tune_setup()
+        total_cnt, tmp_cnt, alpha_update_iter, tune_cnt = 0, 0, 0, 4
+        multiply_factor = self.calib_sample_num // tune_cnt if self.calib_sample_num >= tune_cnt else self.calib_sample_num
+        best_alphas = self.init_alpha
+        loss_alphas = {}
+        for call in self.calls:
+            loss_alphas = {}  # (sic, reference :1846)
+            best_alphas_per_module = best_alphas
+            if isinstance(best_alphas, dict):
+                for key, layer_names in self.absorb_to_layer.items():
+                    for layer_name in layer_names:
+                        best_alphas_per_module[layer_name] = best_alphas_per_module[key]
+            loss_tmp = self._get_one_batch_auto_loss_blockwise(call, self.alpha_space, best_alphas_per_module, self.input_maxes_abs)
+            for block_name in self.block_names:  # every Linear of a block carries the block's losses
+                for key in self.block_to_module[block_name]:
+                    loss_alphas[key] = loss_tmp[block_name]
+            total_cnt += 1
+            tmp_cnt += 1
+            if tmp_cnt // multiply_factor >= 1:
+                alpha_update_iter += 1
+                tmp_cnt = 0
+                best_alphas = self._get_best_alpha(self.absorb_to_layer, loss_alphas, self.shared_criterion)
+                for key in best_alphas:
+                    logger.info("Auto alpha update iter: %d, %s: %s", alpha_update_iter, key, best_alphas[key])
+                absorb_input_scales, weight_scales = self._cal_scales(self.absorb_to_layer, self.input_maxes_abs, best_alphas)
+                self._update_scales_for_auto(absorb_input_scales, weight_scales)
+            if total_cnt >= self.calib_sample_num:
+                break
+        best_alphas = self._get_best_alpha(self.absorb_to_layer, loss_alphas, self.shared_criterion)
+        self.last_loss_alphas = loss_alphas
+        for key in best_alphas:
+            logger.info("Final alpha %s:%s", key, best_alphas[key])
+        self._qdq_model_unwrapper_for_auto()
+        logger.info("block-wise auto tuning done")
+        return best_alphas
 
     def default_tune_setup(self):
         import numpy

@@ -215,7 +215,7 @@ def get_default_awq_config() -> AWQConfig:
 class SmoothQuantConfig(TorchBaseConfig):
     """SmoothQuant W8A8 (reference config.py:1485-1612): same fields and defaults.  On MI355X the supported cell is
     the default one -- int8 per-channel symmetric weights, uint8 per-tensor asymmetric min/max activations; `alpha` is a
-    number or "auto" (the layer-wise tuner, reference smooth_quant/utility.py:1232 AutoAlpha; `do_blockwise` is not built)."""
+    number or "auto" (reference smooth_quant/utility.py:1232 AutoAlpha: the layer-wise tuner, or the block-wise one with `do_blockwise=True`)."""
 
     name = SMOOTH_QUANT
     supported_configs: List = []

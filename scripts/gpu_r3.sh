@@ -27,6 +27,10 @@ while [[ $# -gt 0 ]]; do
       timeout 1500 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider -k "gptq or fasterquant or column_loop or baseline" > gpurun_out/pytest_gptq.log 2>&1
       echo "pytest(gptq) exit $?" | tee -a gpurun_out/pytest_gptq.log
       grep -E "passed|failed|Error|error|assert" gpurun_out/pytest_gptq.log | tail -20 ;;
+    sq)
+      timeout 900 python -m pytest tests/test_gpu_sq.py tests/test_gpu_nf4.py -m gpu -q -s --timeout=900 -p no:cacheprovider > gpurun_out/pytest_sq.log 2>&1
+      echo "pytest(sq) exit $?" | tee -a gpurun_out/pytest_sq.log
+      grep -E "passed|failed|Error|error|assert|smoothquant" gpurun_out/pytest_sq.log | tail -30 ;;
     layer)
       timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_parity.py -m gpu -q -s --timeout=900 -p no:cacheprovider -k "layer_per_gpu or non_positive_definite" > gpurun_out/pytest_layer.log 2>&1
       echo "pytest(layer) exit $?" | tee -a gpurun_out/pytest_layer.log
