@@ -242,10 +242,21 @@ class W8A8Linear(torch.nn.Module):
 
 
 def quant_dequant_w_v1(m, num_bits=8, scheme="sym"):
-    """Per-output-channel symmetric int8 fake quantisation of a Linear's weight (reference :652-695): the codes and scales
-    come from inc_sq_quant_weight (bit-exact against the reference's golden vectors), dequantised in fp32."""
-    assert isinstance(m, torch.nn.Linear) and num_bits == 8 and scheme == "sym", "the W8A8 cell implemented on MI355X"
+    """Per-output-channel int8 fake quantisation of a Linear's weight (reference :652-695).  "sym" (what the W8A8 path uses): the
+    codes and scales come from inc_sq_quant_weight (bit-exact against the reference's golden vectors), dequantised in fp32."""
+    assert isinstance(m, torch.nn.Linear) and num_bits == 8 and scheme in ("sym", "asym")
     w = m.weight.detach().float().contiguous()
+    if scheme == "asym":
+        # the reference's per-channel uint8 cell with a zero point (:670-692).  Nothing on its W8A8 path selects it (the tuner calls
+        # the default "sym", IPEX's SmoothQuant qconfig is symmetric per-channel); restated in HBM with elementwise ops for the API
+        eps = torch.finfo(torch.float32).eps
+        zero = torch.zeros(w.shape[0], device=w.device)
+        row_min = torch.min(w, dim=1).values
+        scale = torch.clip((torch.maximum(torch.max(w, dim=1).values, zero) - torch.minimum(row_min, zero)) / (2**num_bits - 1), min=eps)
+        bias = torch.round(0 - row_min / scale).unsqueeze(-1)
+        scale = scale.unsqueeze(-1)
+        q = torch.round(w / scale + bias).clamp_(0, 2.0**num_bits - 1.0)
+        return (q - bias) * scale
     qw, scale, _ = ops.sq_quant_weight(w)
     return qw[:, : w.shape[1]].float() * scale.view(-1, 1)
 

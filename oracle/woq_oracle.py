@@ -622,6 +622,23 @@ def sq_quant_w(w, num_bits=8):
     return q.to(torch.int32), scale.squeeze(-1), q * scale
 
 
+def sq_quant_w_asym(w, num_bits=8):
+    """quant_dequant_w_v1 (:652-695), Linear, scheme "asym": per-output-channel uint8 with a zero point -> dequantised [N,K].
+    NB the range includes 0 (x_max / x_min are clamped against a zero vector) but the zero point is round(-min(row) / scale) with
+    the UNclamped row minimum (:689), as the reference writes it."""
+    eps = torch.finfo(torch.float32).eps
+    q_min, q_max = 0, 2.0**num_bits - 1.0
+    tmp = torch.zeros(w.shape[0])
+    x_max = torch.maximum(torch.max(w, dim=1).values, tmp)
+    x_min = torch.minimum(torch.min(w, dim=1).values, tmp)
+    scale = torch.clip((x_max - x_min) / (2**num_bits - 1), min=eps)
+    bias = torch.round(0 - (torch.min(w, dim=1).values) / scale).unsqueeze(dim=-1)
+    scale = scale.unsqueeze(dim=-1)
+    q = torch.round(w / scale + bias)
+    q.clamp_(q_min, q_max)
+    return (q - bias) * scale
+
+
 def sq_act_qparams(input_scale, input_min, input_max):
     """SQLinearWrapper._calculate_qparams (:2607-2631) for torch.quint8 -> (scale, zero_point) python floats."""
     min_val = torch.min(input_min * input_scale)
@@ -645,7 +662,10 @@ def sq_quant_x(x, scale, zero_point):
 def sq_quant_dequant_x(x, min_x, max_x, num_bits=8):
     """quant_dequant_x_v1 (:726-755) as written (parameters from the tensor-wide min / max)."""
     eps = torch.finfo(torch.float32).eps
-    max_x, min_x = torch.max(max_x), torch.min(min_x)
+    if max_x is None or min_x is None:  # dynamic form (:745-746)
+        max_x, min_x = torch.max(x), torch.min(x)
+    else:
+        max_x, min_x = torch.max(max_x), torch.min(min_x)
     scale = (max_x - min_x) / (2**num_bits - 1)
     scale = torch.clip(scale, min=eps)
     bias = torch.round((0 - min_x) / scale)

@@ -380,6 +380,20 @@ def test_smooth_quant_auto_alpha_blockwise_vs_reference():
         assert rel_fro(after.cpu(), torch.from_numpy(g["logits"])) <= 1e-4
 
 
+def test_fake_quant_non_default_cells_vs_reference(hip):
+    """The fake-quant cells the reference defines besides the W8A8 default: asymmetric per-channel weights and dynamic per-tensor
+    activations, on the GPU against outputs of the unmodified reference."""
+    from neural_compressor_amd.torch.algorithms.smooth_quant.utility import quant_dequant_w_v1, quant_dequant_x_v1
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sq_cells_golden.npz"))
+    lin = torch.nn.Linear(96, 48, bias=False).to(hip)
+    lin.weight.data.copy_(torch.from_numpy(g["w"]))
+    got = quant_dequant_w_v1(lin, scheme="asym").cpu().numpy()
+    assert np.array_equal(got, g["qdq_w_asym"])
+    got = quant_dequant_x_v1(torch.from_numpy(g["x"]).to(hip)).cpu().numpy()
+    np.testing.assert_allclose(got, g["qdq_x_dynamic"], rtol=0, atol=1e-6)
+
+
 def test_smooth_quant_auto_alpha_public_flow():
     """SmoothQuantConfig(alpha="auto") through prepare -> calibration -> convert: the tuner replays the calibration forwards the
     observers recorded; the W8A8 model stays close to the float one and at least as close as with the fixed default alpha."""

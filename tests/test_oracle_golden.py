@@ -267,3 +267,15 @@ def test_gptq_layer_wide_groups_and_blocks(golden_wide, tag):
     assert np.array_equal(r["Q"].numpy(), golden_wide[f"{tag}_Q"])
     ints = O.gptq_export_ints(r["Q"], r["scale"], r["zero"], kw["sym"], kw["groupsize"], r["perm"])
     assert np.array_equal(ints.numpy(), golden_wide[f"{tag}_ints"].astype(np.int32))
+
+
+def test_smoothquant_non_default_cells_vs_reference():
+    """quant_dequant_w_v1(scheme="asym") and the dynamic form of quant_dequant_x_v1 (min / max from the tensor itself): the
+    restatements against outputs of the unmodified reference (tests/golden/make_golden_sq_cells.py)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sq_cells_golden.npz"))
+    w = torch.from_numpy(g["w"])
+    assert np.array_equal(O.sq_quant_w_asym(w).numpy(), g["qdq_w_asym"])
+    x = torch.from_numpy(g["x"])
+    assert np.array_equal(O.sq_quant_dequant_x(x, None, None).numpy(), g["qdq_x_dynamic"])
