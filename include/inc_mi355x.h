@@ -108,9 +108,10 @@ int inc_dequant_ints(const int16_t* int_weight, const void* scales, int scale_dt
  * == INCWeightOnlyLinear.forward (modules.py:594-610) == F.linear(x, recover(), bias), without
  *   ever materialising the dense weight.  x [M,K] and y [M,N] of dtype `xdtype` (INC_BF16 or
  *   INC_F16), fp32 accumulate; weights dequantised to `xdtype` in registers.
- *   bias [N] of `xdtype` or NULL.  bits in {4, 8}.  g_idx must be NULL in this ABI version
- *   (act_order checkpoints: inc_woq_dequant honours g_idx; the fused kernel returns
- *   INC_ERR_UNSUPPORTED so that a caller can never get a silently wrong product).
+ *   bias [N] of `xdtype` or NULL.  bits in {4, 8}.  g_idx [K] int32 or NULL: the group of every k
+ *   (act_order / HF desc_act checkpoints, modules.py:341-344, 427-431); with a g_idx the general 128x128 tile
+ *   kernel (or the M <= 16 split-K kernel) looks scale / zero up per element.  A g_idx that permutes whole groups
+ *   is faster through a K-sorted copy of the words and a gather of x, which MI355XWeightOnlyLinear does once per module.
  *   The library picks the kernel itself: 256x256x64 LDS-DMA tile kernel (4-bit, M >= 128, K % 64 == 0,
  *   power-of-two group_size >= 32 or one group), split-K MFMA GEMV (M <= 16), or the generic 128x128
  *   tile kernel for everything else.

@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void woq_gemm_tile_kernel(
   const int bn = tid & 127;
   const int64_t ncol = n0 + bn;
 
+  int64_t fetched_k0 = 0;  // K offset of the words held in wb (per-element g_idx lookups happen when they are dequantised)
   auto fetch = [&](int kt) {
     const int64_t k0 = (int64_t)kt * GK;
+    fetched_k0 = k0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i;
@@ -125,7 +127,10 @@ __global__ __launch_bounds__(256) void woq_gemm_tile_kernel(
     for (int i = 0; i < BW; ++i) {
       const int kwl = (tid >> 7) + 2 * i;
       uint32_t d[DW];
-      dequant_word<BITS, IS_BF16>(wb[i], gq[i], d);
+      if (g_idx && ncol < N && fetched_k0 / NP + kwl < KW)
+        dequant_word_gidx<BITS, IS_BF16>(wb[i], scales, qzeros, g_idx, fetched_k0 + (int64_t)kwl * NP, K, ncol, N, NW, d);
+      else
+        dequant_word<BITS, IS_BF16>(wb[i], gq[i], d);
       if constexpr (DW == 4) {
         *reinterpret_cast<uint4*>(Bs + bn * GP + kwl * NP) = make_uint4(d[0], d[1], d[2], d[3]);
       } else if constexpr (DW == 2) {
@@ -1275,7 +1280,8 @@ __global__ __launch_bounds__(256) void woq_gemm_small_kernel(
         if (ncol + c < N && kwr < KW) gq = load_group<4>(scales, qzeros, g, ncol + c, N, NW);
         else { gq.s = 0.f; gq.z = 0; }
         uint32_t d[4];
-        dequant_word<4, IS_BF16>(w4[c], gq, d);
+        if (g_idx && ncol + c < N && kwr < KW) dequant_word_gidx<4, IS_BF16>(w4[c], scales, qzeros, g_idx, kk, K, ncol + c, N, NW, d);
+        else dequant_word<4, IS_BF16>(w4[c], gq, d);
         b[c] = make_uint4(d[0], d[1], d[2], d[3]);
       }
     } else {  // 8-bit: an octet spans two packed rows
@@ -1291,7 +1297,8 @@ __global__ __launch_bounds__(256) void woq_gemm_small_kernel(
             const int64_t g = g_idx ? (int64_t)g_idx[kk] : kk / group_size;
             const GroupQ gq = load_group<8>(scales, qzeros, g, ncol + c, N, NW);
             uint32_t dd[2];
-            dequant_word<8, IS_BF16>(word, gq, dd);
+            if (g_idx) dequant_word_gidx<8, IS_BF16>(word, scales, qzeros, g_idx, kk, K, ncol + c, N, NW, dd);
+            else dequant_word<8, IS_BF16>(word, gq, dd);
             d[2 * h] = dd[0];
             d[2 * h + 1] = dd[1];
           }
@@ -1939,7 +1946,8 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
                  int64_t workspace_bytes, inc_stream_t stream) {
   INC_CHECK_ARG(x && qweight && scales && qzeros && y && M > 0 && N > 0 && K > 0 && G > 0 && group_size > 0);
   if (!(bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
-  if (g_idx) return INC_ERR_UNSUPPORTED;  // per-element groups (act_order): not in this ABI version
+  // g_idx (per-element groups: GPTQ act_order / HF desc_act): the general tile kernels below look the group up per k; the
+  // 256-row kernels assume contiguous groups (the module sorts K by group once and calls them without g_idx, modules.py)
   if (!(xdtype == INC_BF16 || xdtype == INC_F16)) return INC_ERR_UNSUPPORTED;
   const int np = 32 / bits;
   // a packed word must not straddle two groups unless g_idx is given per element... (word-granular
@@ -1959,19 +1967,19 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   else if (group_size >= 32 && (group_size & (group_size - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < group_size) ++g_shift; }
   // 16 < M < 128 (batched decode) runs the same 256-row tile with most rows clamped: with split-K over up to 16 slabs that is
   // 30 us at 64 x 4096 x 4096 where the 128x128 register-staged kernel needed 208 us (and 615 us at 17 x 4096 x 11008)
-  const bool gemv_ok = bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && ceil_div64(N, 64) * 4 <= WS_COUNTER_BYTES &&
+  const bool gemv_ok = !g_idx && bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && ceil_div64(N, 64) * 4 <= WS_COUNTER_BYTES &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !inc_force_small_tiles() && M <= GEMV_MAX_M && inc_small_tiles_flag(-1) != 42;
-  const bool big_ok = bits == 4 && (K % TK) == 0 && g_shift != -2 && M > 16 && N >= 64 && !(gemv_ok && ceil_div64(K, 32 * 4 * 4) <= 64) &&
+  const bool big_ok = !g_idx && bits == 4 && (K % TK) == 0 && g_shift != -2 && M > 16 && N >= 64 && !(gemv_ok && ceil_div64(K, 32 * 4 * 4) <= 64) &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
   const int dbg = inc_small_tiles_flag(-1);
   // weight-only INT8 (BASELINE config #1's layers): the 3A2B kernel's 8-bit instantiation, same tiling and split-K plan
-  const bool big8_ok = bits == 8 && (K % 128) == 0 && g_shift != -2 && M > 16 && N >= 64 && dbg == 0 &&
+  const bool big8_ok = !g_idx && bits == 8 && (K % 128) == 0 && g_shift != -2 && M > 16 && N >= 64 && dbg == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 4) < (int64_t)1 << 31;
   // 64 < M <= 1024 with at most 64 tiles of 256 x 256: the strip kernel (no 256-row tiles, no slab passes).  With more tiles the
   // producer / consumer kernel fills the chip with <= 2 slabs and wins (M = 512, N = 11008: 71 vs 81 us; tools/kbench strip).
   // 32 < M <= 64 on the larger layers too (M = 64, 11008 x 4096: 21 vs 29 us for the streaming kernel, whose x fragments are
   // per-lane 16-byte gathers; at 4096^2 the streaming kernel keeps a 1 us lead).  Harness flags 42 / 40 / 4 / 6 select the tile paths, 83 this kernel for any M > 16.
-  const bool strip_ok = bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
+  const bool strip_ok = !g_idx && bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
                         ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || dbg == 83);
   if (strip_ok) {
     int splitk = strip_splitk(M, N, K);

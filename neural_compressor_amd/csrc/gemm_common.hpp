@@ -64,6 +64,29 @@ __device__ __forceinline__ void dequant_word(uint32_t word, const GroupQ& gq, ui
   }
 }
 
+// the same with a per-ELEMENT group (g_idx: GPTQ act_order / HF desc_act, modules.py:427-431): column k of the word takes the
+// scale / zero point of group g_idx[k] -- one lookup per element, the general (slow) path of the two small-tile kernels
+template <int BITS, bool IS_BF16>
+__device__ __forceinline__ void dequant_word_gidx(uint32_t word, const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
+                                                  const int32_t* __restrict__ g_idx, int64_t kk, int64_t K, int64_t n, int64_t N, int64_t NW,
+                                                  uint32_t (&out)[16 / BITS]) {
+  constexpr int NP = 32 / BITS;
+  constexpr uint32_t MASK = (1u << BITS) - 1u;
+#pragma unroll
+  for (int h = 0; h < NP / 2; ++h) {
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = 2 * h + e;
+      const int64_t k = kk + j;
+      const GroupQ gq = load_group<BITS>(scales, qzeros, k < K ? (int64_t)g_idx[k] : 0, n, N, NW);
+      const int q = (int)((word >> (BITS * j)) & MASK);
+      v[e] = (float)(int8_t)(q - gq.z) * gq.s;
+    }
+    out[h] = pack2<IS_BF16>(v[0], v[1]);
+  }
+}
+
 template <bool IS_BF16>
 __device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, f32x16 c) {
   if constexpr (IS_BF16) {

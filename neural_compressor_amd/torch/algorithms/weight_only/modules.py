@@ -290,8 +290,13 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
                 x2d.index_select(1, self._k_order), self._qweight_sorted, self.scales, self.qzeros, self.bias,
                 self.out_features, self.in_features, self.group_size, self.bits,
             )
+        elif plan == "fused_g_idx":
+            # an irregular g_idx (not a permutation of whole groups): inc_woq_gemm's general tile kernel reads scale / zero of
+            # group g_idx[k] per element (reference modules.py:427-431 semantics), still without a dense weight
+            y = ops.woq_gemm(x2d, self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features,
+                             self.group_size, self.bits, g_idx=self.g_idx)
         else:
-            # 2-bit / odd widths, non-optimum layouts, irregular g_idx: HIP dequant + dense library GEMM
+            # 2-bit / odd widths, non-optimum layouts: HIP dequant + dense library GEMM
             w = self.recover(dtype=x2d.dtype)
             b = None if self.bias is None else self.bias.to(x2d.dtype)
             y = torch.nn.functional.linear(x2d, w, b)
@@ -334,6 +339,10 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
                         self._qweight_sorted = words.to(torch.int32).contiguous()
                         self._k_order = order
                         plan = "fused_act_order"
+                    else:
+                        plan = "fused_g_idx"  # groups of uneven size: the library's general kernel looks the group up per k
+                else:
+                    plan = "fused_g_idx"
         self._plan_key, self._plan = key, plan
         return plan
 

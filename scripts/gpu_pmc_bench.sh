@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd /tmp
 for pass in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$ROOT/gpurun_out/pmc_bench/$pass" -o pmc -- python "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-gemm > "$ROOT/gpurun_out/pmc_bench/$pass.log" 2>&1
+  timeout 400 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$ROOT/gpurun_out/pmc_bench/$pass" -o pmc -- python "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-gemm --no-e2e --no-extra-configs --no-per-layer > "$ROOT/gpurun_out/pmc_bench/$pass.log" 2>&1
   echo "pass [$pass] exit $?"
 done
 python - <<'PY'

@@ -42,8 +42,16 @@ while [[ $# -gt 0 ]]; do
         echo "bench --gpus 2 ($mode) exit $?"; tail -c 1500 gpurun_out/bench_n2_$mode.log; tail -8 gpurun_out/bench_n2_$mode.err
       done
       timeout 300 python bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_n2_nccl.log 2>&1; echo "bench --gpus 2 (nccl on one GPU: must refuse) exit $?"; tail -3 gpurun_out/bench_n2_nccl.log ;;
+    gidx)
+      timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -s --timeout=600 -p no:cacheprovider -k "g_idx or fused_gemm" > gpurun_out/pytest_gidx.log 2>&1
+      echo "pytest(gidx) exit $?" | tee -a gpurun_out/pytest_gidx.log
+      grep -E "passed|failed|Error|error|assert" gpurun_out/pytest_gidx.log | tail -12 ;;
+    pmc)
+      bash scripts/gpu_pmc.sh prof > gpurun_out/pmc_kbench.log 2>&1; echo "pmc kbench exit $?"; tail -12 gpurun_out/pmc_kbench.log ;;
+    pmcbench)
+      bash scripts/gpu_pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1; echo "pmc bench exit $?"; tail -12 gpurun_out/pmc_bench.log ;;
     prof)
-      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r2 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r2 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs --no-per-layer > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
       echo "prof exit $?"; find gpurun_out/prof -name "*kernel_stats*" | head -3 ;;
   esac
   shift

@@ -160,6 +160,37 @@ def test_forward_with_act_order_g_idx_runs_fused(hip, bits, M, dt):
     assert rel_fro(ref2.cpu(), ref.cpu()) > 0.1  # the two layouts really are different matrices
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 8, 70, 300])
+def test_fused_gemm_with_irregular_g_idx_vs_oracle(hip, M):
+    """inc_woq_gemm with a g_idx that is NOT a permutation of whole groups (groups of uneven size): the general kernels look scale
+    and zero point up per element (reference modules.py:427-431); against the oracle's dense weight with the same g_idx, both through
+    the C-ABI call and through the module (plan "fused_g_idx": no dense weight, no library GEMM)."""
+    from neural_compressor_amd import ops
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    g = torch.Generator().manual_seed(5 + M)
+    N, K, gs, bits = 192, 384, 128, 4
+    G = K // gs
+    iw = torch.randint(0, 16, (N, K), generator=g, dtype=torch.int32)
+    sc = torch.rand(N, G, generator=g) * 0.02 + 0.002
+    zp = torch.randint(1, 16, (N, G), generator=g, dtype=torch.int32)
+    m = MI355XWeightOnlyLinear(K, N, bits=bits, group_size=gs, zp=True, g_idx=True, device=hip)
+    m.pack(iw.to(hip), sc.to(hip), zp.to(hip), None, g_idx=torch.arange(K).to(hip))
+    gidx = torch.randint(0, G, (K,), generator=g, dtype=torch.int32)  # every k picks any group: uneven group sizes
+    m.g_idx = gidx.to(hip)
+    m._plan_key = None
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    dense = O.woq_dense_weight(m.qweight.cpu().numpy(), m.scales.cpu().numpy(), m.qzeros.cpu().numpy(), N, K, bits, gs,
+                               compute_dtype=torch.bfloat16, g_idx=gidx.numpy())
+    ref = x.float() @ dense.float().T
+    y = ops.woq_gemm(x.to(hip), m.qweight, m.scales, m.qzeros, None, N, K, gs, bits, g_idx=m.g_idx)
+    assert rel_fro(y.float().cpu(), ref) <= 3e-3
+    y2 = m(x.to(hip))
+    assert m._plan == "fused_g_idx"
+    assert torch.equal(y2, y)
+
+
 def test_empty_batch_forward(hip):
     """A zero-row input returns a zero-row output (F.linear semantics) instead of reaching the kernels' M > 0 check."""
     from neural_compressor_amd.torch.algorithms.smooth_quant import W8A8Linear
