@@ -240,7 +240,6 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
   float gp_s0;           // group-parameter temporaries that cross a sub-region
   uint32_t gp_z;
   INC_D2R_ZERO_ACC();
-
   // ==== the K-loop's building block: ONE asm statement per sub-region = 4 MFMAs, each followed by its slot ====================
   // A single wave per SIMD issues in order, so every instruction between two MFMAs is paid for unless there are at most ~5 of
   // them (MI355X_MICROARCH.md); with C++ slots the compiler added a wait-state pad or an s_waitcnt to almost every one.  Inside a
@@ -498,7 +497,10 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     for (int i = tid; i < TM * (TN / 8); i += D2R_THREADS) {  // 16-byte chunk i: row i / 32, columns 8 (i % 32) .. +7
       const int row = i >> 5, c = i & 31;
       const uint4 v = *reinterpret_cast<const uint4*>(smem + row * D2R_CPITCH + c * 16);
-      *reinterpret_cast<uint4*>(ytile + (int64_t)row * N + c * 8) = v;
+      // write-through (sc1): the 128 KiB tile leaves the L2 as it is stored instead of staying dirty until the end-of-kernel
+      // write-back (32 MiB per 4096 x 4096 output: +1.5 % on the whole kernel, tools/kbench d2r "sc1 epilogue stores")
+      const u32x4 vv = {v.x, v.y, v.z, v.w};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ytile + (int64_t)row * N + c * 8), "v"(vv) : "memory");
     }
     return;
   }
@@ -514,29 +516,29 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     }
     static_for<0, 8>([&](auto MF) {
       constexpr int mf = MF.value, r0 = 16 * mf + 4 * rq, r1 = 16 * (8 + mf) + 4 * rq;
-      const float vv[8] = {acc_read<r0>() + bv[0],     acc_read<r1>() + bv[1],     acc_read<r0 + 1>() + bv[2], acc_read<r1 + 1>() + bv[3],
+      const float vv_[8] = {acc_read<r0>() + bv[0],     acc_read<r1>() + bv[1],     acc_read<r0 + 1>() + bv[2], acc_read<r1 + 1>() + bv[3],
                            acc_read<r0 + 2>() + bv[4], acc_read<r1 + 2>() + bv[5], acc_read<r0 + 3>() + bv[6], acc_read<r1 + 3>() + bv[7]};
       const int64_t m = m0 + mf * 32 + (lane & 31);
       if (m < M) {
         if (slab) {  // (bias and conversion happen in the finalize kernel)
           float* dst = slab + m * N + nb;
           if (nb + 8 <= N && (N % 4) == 0) {
-            *reinterpret_cast<float4*>(dst) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+            *reinterpret_cast<float4*>(dst) = make_float4(vv_[0], vv_[1], vv_[2], vv_[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(vv_[4], vv_[5], vv_[6], vv_[7]);
           } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              if (nb + j < N) dst[j] = vv[j];
+              if (nb + j < N) dst[j] = vv_[j];
           }
         } else {
           uint16_t* dst = y + m * N + nb;
           if ((y_vec_ok & 1) && nb + 8 <= N) {  // 8-byte aligned rows: two 8-byte stores
-            *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair<IS_BF16>(vv[0], vv[1]), cvt_pair<IS_BF16>(vv[2], vv[3]));
-            *reinterpret_cast<uint2*>(dst + 4) = make_uint2(cvt_pair<IS_BF16>(vv[4], vv[5]), cvt_pair<IS_BF16>(vv[6], vv[7]));
+            *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair<IS_BF16>(vv_[0], vv_[1]), cvt_pair<IS_BF16>(vv_[2], vv_[3]));
+            *reinterpret_cast<uint2*>(dst + 4) = make_uint2(cvt_pair<IS_BF16>(vv_[4], vv_[5]), cvt_pair<IS_BF16>(vv_[6], vv_[7]));
           } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-              if (nb + j < N) dst[j] = IS_BF16 ? f32_to_bf16_bits(vv[j]) : f32_to_f16_bits(vv[j]);
+              if (nb + j < N) dst[j] = IS_BF16 ? f32_to_bf16_bits(vv_[j]) : f32_to_f16_bits(vv_[j]);
           }
         }
       }
