@@ -32,6 +32,7 @@ at full layer size (one block each).
 """
 
 import argparse
+import copy
 import json
 import os
 import sys
@@ -515,24 +516,27 @@ def bench_awq_sq_blocks(device, note):
         ("awq_block", (4096, 11008, 32), 128, 512, AWQConfig(bits=4, group_size=128, use_sym=False, use_auto_scale=True, use_auto_clip=True)),
         ("smoothquant_block", (5120, 13824, 40), 32, 2048, SmoothQuantConfig(alpha=0.5, folding=False, scale_sharing=True)),
     ):
-        model = llama(*dims)
         ids = [torch.randint(0, 32000, (1, seq), generator=g) for _ in range(n)]
         if tag == "smoothquant_block":
             cfg.set_local("lm_head", SmoothQuantConfig(w_dtype="fp32"))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            model = prepare(model, cfg, example_inputs=ids[0].to(device))
-            for x in ids:
-                model(x.to(device))
-            model = convert(model)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[tag] = dict(seconds_per_block=round(dt, 3), samples=n, seq_len=seq, hidden=dims[0], ffn=dims[1],
-                        model_estimate_s=round(dt * (32 if tag == "awq_block" else 40), 1))
-        note(f"{tag}: {dt:.2f}s")
-        del model
-        torch.cuda.empty_cache()
+        times = []
+        for _ in range(2):  # the first pass pays the libraries' first-call costs for these shapes (a 32-block model pays them once)
+            model = llama(*dims)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                model = prepare(model, copy.deepcopy(cfg), example_inputs=ids[0].to(device))
+                for x in ids:
+                    model(x.to(device))
+                model = convert(model)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            del model
+            torch.cuda.empty_cache()
+        dt = times[-1]
+        out[tag] = dict(seconds_per_block=round(dt, 3), first_pass_s=round(times[0], 3), samples=n, seq_len=seq, hidden=dims[0],
+                        ffn=dims[1], model_estimate_s=round(dt * (32 if tag == "awq_block" else 40), 1))
+        note(f"{tag}: {dt:.2f}s (first pass {times[0]:.2f}s)")
     return out
 
 

@@ -41,6 +41,24 @@ from .utility import get_block_prefix, quant_tensor
 
 __all__ = ["AWQQuantizer", "ActAwareWeightQuant"]
 
+import contextlib
+import time
+
+# INC_MI355X_AWQ_TIMING=1: wall-clock per phase (device-synchronised) on the converted model as `awq_phase_s` -- diagnostics only
+PHASE_TIMING = os.environ.get("INC_MI355X_AWQ_TIMING", "0") == "1"
+
+
+@contextlib.contextmanager
+def _phase(log, name):
+    if not PHASE_TIMING:
+        yield
+        return
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    yield
+    torch.cuda.synchronize()
+    log[name] = log.get(name, 0.0) + time.perf_counter() - t0
+
 
 # ---------------------------------------------------------------------------------------------------
 # model plumbing (reference utility.py:636 fetch_module, :1036 replace_forward, :1079 recover_forward,
@@ -342,9 +360,11 @@ class ActAwareWeightQuant:
     @torch.no_grad()
     def quantize(self, use_auto_scale=True, use_mse_search=True, folding=False, return_int=False):
         self.absorb_of = {}
+        ph = self.phase_s = {}
         for i in range(self.block_num):
             logger.info("Processing block: %d/%d", i + 1, self.block_num)
-            module_list, inverse = self._absorb_for_block(i, folding if use_auto_scale else False)
+            with _phase(ph, "absorb_discovery"):
+                module_list, inverse = self._absorb_for_block(i, folding if use_auto_scale else False)
             self.absorb_of.update(inverse)
             if len(module_list) == 0:
                 logger.info("No need to process this block.")
@@ -359,16 +379,23 @@ class ActAwareWeightQuant:
                 for args, kwargs in zip(self.total_block_args, self.total_block_kwargs):
                     m(*args, **kwargs)
 
-            input_values = get_module_input_output(block, hook_cfg, calib_func=block_calibration)
-            scale_info = self.search_scale(block, block_name, module_list, input_values) if use_auto_scale else {}
-            out_list = self.block_inference(block)  # inputs of the next block come from the UNSCALED float block (:246-249)
-            self.update_block_input(out_list)
+            with _phase(ph, "capture"):
+                input_values = get_module_input_output(block, hook_cfg, calib_func=block_calibration)
+            with _phase(ph, "search_scale"):
+                scale_info = self.search_scale(block, block_name, module_list, input_values) if use_auto_scale else {}
+            with _phase(ph, "block_inference"):
+                out_list = self.block_inference(block)  # inputs of the next block come from the UNSCALED float block (:246-249)
+                self.update_block_input(out_list)
             if use_auto_scale:
                 self.apply_scale(scale_info)
             if use_mse_search:
-                self.search_clip(block_name, module_list, input_values)
-        self.apply_quantize_with_clip(return_int)
+                with _phase(ph, "search_clip"):
+                    self.search_clip(block_name, module_list, input_values)
+        with _phase(ph, "final_rtn"):
+            self.apply_quantize_with_clip(return_int)
         self.model.awq_search_log = self.search_log
+        if PHASE_TIMING:
+            self.model.awq_phase_s = {k: round(v, 4) for k, v in ph.items()}
         return self.model
 
     # -- scale search (reference :264-361) ---------------------------------------------------------------
@@ -381,6 +408,9 @@ class ActAwareWeightQuant:
                 continue
             logger.info("[SCALE] Processing module: %s", module_tuple)
             names = [n.split(block_name + ".")[1] for n in module_tuple]
+            if PHASE_TIMING:
+                torch.cuda.synchronize()
+                t_tuple = time.perf_counter()
             mods = OrderedDict((n, fetch_module(block, n)) for n in names)
             weight = torch.cat([m.weight for m in mods.values()], dim=0)
             w_max = _get_weight_scale(weight, q_group_size=cur_group_size)
@@ -390,7 +420,9 @@ class ActAwareWeightQuant:
             org_w = {n: m.weight.detach().clone() for n, m in mods.items()}
             multi = len(module_tuple) > 1
             evaluate = (lambda: self._search_block_outputs(block)) if multi else (lambda: self._search_module_outputs(mods[names[0]], input_val))
-            org_out = evaluate()
+            # (all tuples of a block are searched on the same float block: its outputs are computed once, :304-310 / :246-249)
+            org_out = self._float_block_outputs(block) if multi else evaluate()
+            replay = self._prefix_replay(block, list(mods.values())) if multi else None
             n_grid = 20
             losses, cand = [], []
             for step in range(n_grid):
@@ -405,13 +437,19 @@ class ActAwareWeightQuant:
                                       full_range=self.use_full_range)
                     m.weight.data = wq / scales.view(1, -1)
                 loss = _Loss(self.device)
-                for (o1, n1), (o2, _) in zip(org_out, evaluate()):
+                outs = replay.run(evaluate) if replay is not None else evaluate()
+                for (o1, n1), (o2, _) in zip(org_out, outs):
                     loss.add(o1, o2, n1)
+                del outs
                 losses.append(loss.val)
                 cand.append(scales)
                 for n, m in mods.items():
                     m.weight.data = org_w[n].clone()
+            if replay is not None:
+                replay.close()
             hist = torch.cat(losses).tolist()  # one device->host copy per module tuple
+            if PHASE_TIMING:
+                self.phase_s["scale:" + "|".join(names)] = time.perf_counter() - t_tuple
             best, best_i = float("inf"), None
             for i_, v in enumerate(hist):
                 if v < best:  # first strict minimum, like the reference's scan
@@ -509,6 +547,7 @@ class ActAwareWeightQuant:
     # -- forwards ------------------------------------------------------------------------------------------
     def update_block_input(self, input_list):
         self._block_chunks = None  # the stacked copies used by the batched search belong to the previous block
+        self._float_block = None
         for i, inp in enumerate(input_list):
             if len(self.total_block_args[i]) > 0:
                 self.total_block_args[i][0] = inp
@@ -578,7 +617,7 @@ class ActAwareWeightQuant:
                 return False
         return True
 
-    def _search_block_outputs(self, block):
+    def _block_chunk_list(self, block):
         chunks = getattr(self, "_block_chunks", None)
         if chunks is None:
             args0, kw0 = self.total_block_args[0], self.total_block_kwargs[0]
@@ -606,8 +645,15 @@ class ActAwareWeightQuant:
             if not stackable:
                 chunks = [("single", i, 1) for i in range(len(self.total_block_args))]
             self._block_chunks = chunks
+        return chunks
+
+    _chunk_cursor = -1  # index of the chunk whose forward is running (read by the hooks of _float_block_outputs / _PrefixReplay)
+
+    def _search_block_outputs(self, block):
+        chunks = self._block_chunk_list(block)
         outs = []
-        for kind, x, n in chunks:
+        for ci, (kind, x, n) in enumerate(chunks):
+            self._chunk_cursor = ci
             if kind == "single":
                 args, kwargs = self.total_block_args[x], self.total_block_kwargs[x]
             else:
@@ -620,7 +666,82 @@ class ActAwareWeightQuant:
                 kwargs["layer_past"] = None
             out = block(*args, **kwargs)
             outs.append((out[0] if isinstance(out, tuple) else out, n))
+        self._chunk_cursor = -1
         return outs
+
+    # -- float outputs of the block, once per block; replay of the part of the block in front of the searched Linears ------
+    # Reference: every module tuple's search first runs the float block (`org_out`, :304-310) and then the whole block once
+    # per grid point (:337).  The float block is the same for every tuple of a block (scales are applied after all searches,
+    # :236-252), so its outputs are computed once; and the direct children of the block that finish BEFORE the first searched
+    # Linear starts (for gate/up: input_layernorm, self_attn, post_attention_layernorm) see the same inputs and weights at
+    # every grid point, so their recorded float outputs are replayed instead of being recomputed -- the same kernels on the
+    # same data would reproduce them bit for bit (checked once per set of replayed children against a full forward).
+    # INC_MI355X_AWQ_PREFIX_REPLAY=0 runs every forward in full.
+    def _float_block_outputs(self, block):
+        fb = getattr(self, "_float_block", None)
+        if fb is not None and fb["block"] is block:
+            return fb["outs"]
+        self._block_chunk_list(block)  # (its one-off stacking check runs forwards of its own: before the hooks go on)
+        events, rec, handles = [], {}, []
+        children = dict(block.named_children())
+        leaves = {n: m for n, m in block.named_modules() if n and len(list(m.children())) == 0}
+
+        def child_pre(name):
+            def hook(mod, args, kwargs):
+                if self._chunk_cursor == 0:
+                    events.append(("start", name))
+            return hook
+
+        def child_post(name):
+            def hook(mod, args, kwargs, output):
+                if self._chunk_cursor == 0:
+                    events.append(("end", name))
+                rec.setdefault(name, []).append((output, _versions(output)))
+            return hook
+
+        def leaf_pre(name):
+            def hook(mod, args):
+                if self._chunk_cursor == 0:
+                    events.append(("leaf", name))
+            return hook
+
+        for n, m in children.items():
+            handles.append(m.register_forward_pre_hook(child_pre(n), with_kwargs=True))
+            handles.append(m.register_forward_hook(child_post(n), with_kwargs=True))
+        for n, m in leaves.items():
+            if n not in children:
+                handles.append(m.register_forward_pre_hook(leaf_pre(n)))
+        try:
+            outs = self._search_block_outputs(block)
+        finally:
+            for h in handles:
+                h.remove()
+        # a child whose output was modified in place later in the forward cannot be replayed
+        rec = {n: [o for o, _ in lst] for n, lst in rec.items() if all(_versions(o) == v for o, v in lst)}
+        self._float_block = dict(block=block, outs=outs, events=events, rec=rec, leaves={id(m): n for n, m in leaves.items()})
+        return outs
+
+    def _prefix_replay(self, block, changed):
+        fb = getattr(self, "_float_block", None)
+        if os.environ.get("INC_MI355X_AWQ_PREFIX_REPLAY", "1") != "1" or fb is None or fb["block"] is not block:
+            return None
+        changed_names = {fb["leaves"].get(id(m)) for m in changed}
+        if None in changed_names:
+            return None
+        first = next((i for i, (kind, n) in enumerate(fb["events"])
+                      if (kind == "leaf" and n in changed_names) or (kind == "start" and n in changed_names)), None)
+        if first is None:
+            return None
+        n_chunks = len(self._block_chunks)
+        started = [n for kind, n in fb["events"][:first] if kind == "start"]
+        ended = [n for kind, n in fb["events"][:first] if kind == "end"]
+        names = [n for n in ended if started.count(n) == 1 and ended.count(n) == 1 and len(fb["rec"].get(n, ())) == n_chunks
+                 and sum(1 for k, nn in fb["events"] if k == "start" and nn == n) == 1]
+        # replaying a child makes the children nested in front of it irrelevant; keep only children with real work
+        names = [n for n in names if any(True for _ in getattr(block, n).parameters())]
+        if not names:
+            return None
+        return _PrefixReplay(self, block, names, fb["rec"])
 
     def _stacked_block_is_faithful(self, block, chunk, hidden_in_args):
         """The first stacked forward against the per-batch forwards of the same batches (guards against blocks that are
@@ -656,6 +777,79 @@ class ActAwareWeightQuant:
                 out = out[0]
             total_out.append(out)
         return total_out
+
+
+def _tensors_of(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            yield from _tensors_of(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors_of(o)
+
+
+def _versions(obj):
+    return tuple(t._version for t in _tensors_of(obj))
+
+
+class _PrefixReplay:
+    """Replays the recorded float outputs of `names` (direct children of `block`) during the grid forwards of one module tuple."""
+
+    _verified = set()  # (block class, replayed children): checked once per process against full forwards
+
+    def __init__(self, owner, block, names, rec):
+        self.owner, self.block, self.names, self.rec = owner, block, names, rec
+        self.key = (type(block).__qualname__, tuple(names))
+        self.versions = {n: [_versions(o) for o in rec[n]] for n in names}
+        self.saved = None
+        self.broken = False
+
+    def _patch(self):
+        self.saved = {}
+        for n in self.names:
+            mod = getattr(self.block, n)
+            self.saved[n] = mod.__dict__.get("forward")
+            mod.forward = (lambda lst: (lambda *a, **k: lst[self.owner._chunk_cursor]))(self.rec[n])
+
+    def _unpatch(self):
+        if self.saved is None:
+            return
+        for n, old in self.saved.items():
+            mod = getattr(self.block, n)
+            if old is None:
+                mod.__dict__.pop("forward", None)
+            else:
+                mod.forward = old
+        self.saved = None
+
+    def _intact(self):
+        return all(_versions(o) == v for n in self.names for o, v in zip(self.rec[n], self.versions[n]))
+
+    def run(self, evaluate):
+        if self.broken:
+            return evaluate()
+        self._patch()
+        try:
+            outs = evaluate()
+        finally:
+            self._unpatch()
+        ok = self._intact()
+        if ok and self.key not in _PrefixReplay._verified:
+            full = evaluate()
+            ok = len(full) == len(outs) and all(torch.equal(a, b) for (a, _), (b, _) in zip(full, outs))
+            if ok:
+                _PrefixReplay._verified.add(self.key)
+        if not ok:
+            logger.warning("AWQ: replaying %s does not reproduce the full forward of %s; running the grid forwards in full",
+                           self.names, self.key[0])
+            self.broken = True
+            return evaluate()
+        return outs
+
+    def close(self):
+        self._unpatch()
 
 
 class AWQQuantizer(Quantizer):

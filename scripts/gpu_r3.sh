@@ -50,6 +50,22 @@ while [[ $# -gt 0 ]]; do
       bash scripts/gpu_pmc.sh prof > gpurun_out/pmc_kbench.log 2>&1; echo "pmc kbench exit $?"; tail -12 gpurun_out/pmc_kbench.log ;;
     pmcbench)
       bash scripts/gpu_pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1; echo "pmc bench exit $?"; tail -12 gpurun_out/pmc_bench.log ;;
+    awqtests)
+      timeout 1200 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider -k "awq" > gpurun_out/pytest_awq.log 2>&1
+      echo "pytest(awq) exit $?" | tee -a gpurun_out/pytest_awq.log
+      grep -E "passed|failed|Error|error|assert" gpurun_out/pytest_awq.log | tail -12 ;;
+    awq)
+      timeout 600 python tools/awq_block_prof.py 2 > gpurun_out/awq_phases.log 2> gpurun_out/awq_phases.err; echo "awq phases exit $?"; cat gpurun_out/awq_phases.log; tail -3 gpurun_out/awq_phases.err
+      ( cd /tmp && INC_MI355X_AWQ_TIMING=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_awq" -o awq -- python "$R/tools/awq_block_prof.py" 1 > "$R/gpurun_out/prof_awq.log" 2>&1 )
+      echo "awq prof exit $?"; f=$(find gpurun_out/prof_awq -name "*kernel_stats*" | head -1); python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel ms", round(tot / 1e6, 1))
+for r in rows[:25]:
+    print(f'{float(r["TotalDurationNs"])/1e6:9.1f} ms {int(r["Calls"]):6d} calls  {float(r["AverageNs"])/1e3:9.1f} us  {r["Name"][:110]}')
+PY
+      ;;
     prof)
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r2 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs --no-per-layer > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
       echo "prof exit $?"; find gpurun_out/prof -name "*kernel_stats*" | head -3 ;;
