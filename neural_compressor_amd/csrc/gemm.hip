@@ -874,10 +874,11 @@ __global__ __launch_bounds__(512) void woq_gemm_w4_3a2b_kernel(
 // One s_barrier per K-step for all 12 waves: step t multiplies x stage t % 3 and W stage t & 1 while the producers dequantise
 // tile t+1 into W stage (t+1) & 1 (read last in step t-1) and the DMA of x tile t+2 fills stage (t+2) % 3 (read last in
 // step t-1).  A wave's 128 fp32 accumulators + one fragment set fit the 168-register budget of three waves per SIMD.
-constexpr int PC_THREADS = 768;
-
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#ifdef INC_KBENCH  // superseded by the direct-to-register kernel (gemm_d2r.hip); kept in the harness build as its bitwise A/B partner (tools/kbench d2r)
+constexpr int PC_THREADS = 768;
 
 // Epilogue of the producer / consumer kernel for a FULL 256 x 256 tile: the accumulator layout (a lane owns 4 consecutive
 // columns of 32 different rows) would leave as 8-byte pieces scattered over 32 rows per store instruction -- 1024 partial-line
@@ -1191,6 +1192,7 @@ __global__ __launch_bounds__(PC_THREADS) void woq_gemm_w4_pc_kernel(
     }
   }
 }
+#endif  // INC_KBENCH
 
 template <bool IS_BF16>
 __global__ void splitk_slab_reduce_kernel(const float* __restrict__ partial, const uint16_t* __restrict__ bias,
@@ -2046,6 +2048,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
       if (bf) splitk_slab_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
       else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
     }
+#ifdef INC_KBENCH
   } else if (big_ok && (K % 128) == 0 && (g_shift == -1 || g_shift >= 6) && (dbg == 0 || dbg == 42 || (dbg >= 51 && dbg <= 74)) && INC_GEMM_DEFAULT_PC) {
     // producer / consumer specialisation of the 3A2B tile (one scale per column and K-step: group_size >= 64)
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
@@ -2070,7 +2073,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     dim3 g2(grid, (unsigned)splits);
 #define INC_PC(B, A) woq_gemm_w4_pc_kernel<B, A><<<g2, PC_THREADS, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps)
     if (!bf) INC_PC(false, 0);
-#ifdef INC_KBENCH  // timing-only ablations of the producer / consumer step (tools/kbench pcablate)
+    // timing-only ablations of the producer / consumer step (tools/kbench pcablate)
 #define INC_PC_ABL(A) { INC_ALLOW_PC(A); INC_PC(true, A); }
 #define INC_ALLOW_PC(A) (void)hipFuncSetAttribute((const void*)woq_gemm_w4_pc_kernel<true, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
     else if (dbg == 51) INC_PC_ABL(1)
@@ -2099,7 +2102,6 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     else if (dbg == 74) INC_PC_ABL(2048)     // correct results: single v_cvt_f32_fp8 conversions
 #undef INC_PC_ABL
 #undef INC_ALLOW_PC
-#endif
     else INC_PC(true, 0);
 #undef INC_PC
     if (part) {
@@ -2108,6 +2110,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
       if (bf) splitk_slab_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
       else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
     }
+#endif  // INC_KBENCH
   } else if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 40 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 30) || (dbg >= 31 && dbg <= 37))) {
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
     static std::atomic<uint64_t> a3_attr_set{0};

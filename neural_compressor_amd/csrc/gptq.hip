@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256) void hessian_syrk_16bit_kernel(const uint16_t*
     }
 }
 
+constexpr int H2 = 256;  // H tile edge of the 256 x 256 kernels
+
+#ifdef INC_KBENCH  // first 256 x 256 generation (operands transposed in registers): harness flag 45, A/B partner of the kernel below
 // ---- 16-bit inputs, 256x256 tile of H per workgroup (K >= 256) --------------------------------------
 // 512 threads = 8 waves as 2 (i) x 4 (j); a wave owns 128 x 64 of H = 4 x 2 MFMA 32x32x16 tiles.
 // Per 64-token step each thread fetches ONE 8(token) x 8(feature) block (eight 16-byte loads, the wave
@@ -215,7 +218,6 @@ __global__ __launch_bounds__(256) void hessian_syrk_16bit_kernel(const uint16_t*
 // (rows lane&31, pitch 9 x 16 B) hit 16 distinct bank slots per lane group -> both conflict-free.
 // Software pipeline: the block for step s+1 is fetched during step s-1/s, transposed and written to the
 // other LDS stage between the first and second MFMA group of step s; one barrier per step.
-constexpr int H2 = 256;
 constexpr int H2_OPER = H2 * HPITCH;       // elements per operand per stage
 constexpr int H2_STAGE = 2 * H2_OPER;      // elements per stage
 
@@ -343,6 +345,7 @@ __device__ __forceinline__ void hessian_syrk_256_tile(const uint16_t* __restrict
       }
     }
 }
+#endif  // INC_KBENCH
 
 // ---- 256x256 syrk tile, transpose-read generation (round 2) --------------------------------------------------------
 // The kernel above moves X through registers: per 64-token step every thread issues eight 16-byte loads, transposes an 8x8
@@ -503,12 +506,14 @@ __global__ __launch_bounds__(512) void hessian_syrk_tr_256_kernel(const uint16_t
   hessian_syrk_tr_tile<IS_BF16, TOK, NST, ABL>(x, T, K, ldx, H, beta, alpha, nt, (int)blockIdx.x, (int)gridDim.x);
 }
 
+#ifdef INC_KBENCH
 template <bool IS_BF16, bool TAIL>
 __global__ __launch_bounds__(512) void hessian_syrk_16bit_256_kernel(const uint16_t* __restrict__ x, int64_t T,
                                                                      int64_t K, int64_t ldx, float* __restrict__ H,
                                                                      float beta, float alpha, int nt) {
   hessian_syrk_256_tile<IS_BF16, TAIL>(x, T, K, ldx, H, beta, alpha, nt, (int)blockIdx.x, (int)gridDim.x);
 }
+#endif
 
 // Several Hessians of ONE calibration forward in a single launch (same token count T): the three K = 4096 Hessians of a Llama
 // block have 136 tiles each -- alone they leave 120 of the 256 CUs idle for the whole launch (0.395 of peak by the 2*T*K^2
@@ -541,6 +546,7 @@ __global__ __launch_bounds__(512) void hessian_syrk_tr_256_multi_kernel(HessianB
                                 b - args.first[p], args.first[p + 1] - args.first[p]);
 }
 
+#ifdef INC_KBENCH
 template <bool IS_BF16, bool TAIL>
 __global__ __launch_bounds__(512) void hessian_syrk_16bit_256_multi_kernel(HessianBatch args, int64_t T) {
   const int b = (int)blockIdx.x;
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(512) void hessian_syrk_16bit_256_multi_kernel(Hessi
   hessian_syrk_256_tile<IS_BF16, TAIL>(args.x[p], T, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p], args.nt[p],
                                        b - args.first[p], args.first[p + 1] - args.first[p]);
 }
+#endif
 
 // ---- fp32 inputs: exact fp32 MFMA 32x32x2 ------------------------------------------------------
 constexpr int FK = 32;  // tokens per step
@@ -1157,18 +1164,23 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
     if (K >= H2 && vec_ok && (K % 8) == 0 && !inc_force_small_tiles()) {
       const int nt2 = (int)ceil_div64(K, H2);
       const int ntiles2 = nt2 * (nt2 + 1) / 2;
-      const size_t smem2 = (size_t)2 * H2_STAGE * sizeof(uint16_t);  // 144 KiB
-      static std::atomic<uint64_t> attr2_set{0};
-      if (inc_attr_needed(attr2_set)) {
+      const uint16_t* xp = (const uint16_t*)x;
+#ifdef INC_KBENCH
+      if (inc_small_tiles_flag(-1) == 45) {  // harness flag 45: the register-transposing generation
+        const size_t smem2 = (size_t)2 * H2_STAGE * sizeof(uint16_t);  // 144 KiB
+        const bool tail = (T % HK) != 0;
         (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-        inc_attr_done(attr2_set);
+#define INC_H2(B, TL) hessian_syrk_16bit_256_kernel<B, TL><<<ntiles2, 512, smem2, s>>>(xp, T, K, ldx, H, beta, alpha, nt2)
+        if (xdtype == INC_BF16) { if (tail) INC_H2(true, true); else INC_H2(true, false); }
+        else { if (tail) INC_H2(false, true); else INC_H2(false, false); }
+#undef INC_H2
+        INC_LAUNCH_RETURN();
       }
-      const uint16_t* xp = (const uint16_t*)x;
-      const bool tail = (T % HK) != 0;
-      if (inc_small_tiles_flag(-1) != 45) {  // transpose-read generation (harness flag 45: the register-transposing kernel)
+#endif
+      {  // transpose-read generation
         const size_t smem3 = (size_t)TR_NST * TR_STAGE;  // 132 KiB
         static std::atomic<uint64_t> attr3_set{0};
         if (inc_attr_needed(attr3_set)) {
@@ -1195,10 +1207,6 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
         else hessian_syrk_tr_256_kernel<false><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);
         INC_LAUNCH_RETURN();
       }
-#define INC_H2(B, TL) hessian_syrk_16bit_256_kernel<B, TL><<<ntiles2, 512, smem2, s>>>(xp, T, K, ldx, H, beta, alpha, nt2)
-      if (xdtype == INC_BF16) { if (tail) INC_H2(true, true); else INC_H2(true, false); }
-      else { if (tail) INC_H2(false, true); else INC_H2(false, false); }
-#undef INC_H2
     } else if (xdtype == INC_BF16)
       hessian_syrk_16bit_kernel<true><<<ntiles, 256, smem, s>>>((const uint16_t*)x, T, K, ldx, H, beta, alpha, nt, vec_ok);
     else
@@ -1232,18 +1240,23 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
   for (int i = n; i <= HESSIAN_MAX_BATCH; ++i) a.first[i] = first;
   for (int i = n; i < HESSIAN_MAX_BATCH; ++i) { a.x[i] = a.x[0]; a.H[i] = a.H[0]; a.K[i] = a.K[0]; a.ldx[i] = a.ldx[0]; a.beta[i] = 1.f; a.alpha[i] = 0.f; a.nt[i] = a.nt[0]; }
   a.n = n;
-  const size_t smem2 = (size_t)2 * H2_STAGE * sizeof(uint16_t);  // 144 KiB
-  static std::atomic<uint64_t> attr_set{0};
-  if (inc_attr_needed(attr_set)) {
+  hipStream_t s = inc_s(stream);
+#ifdef INC_KBENCH
+  if (inc_small_tiles_flag(-1) == 45) {  // harness flag 45: the register-transposing generation
+    const size_t smem2 = (size_t)2 * H2_STAGE * sizeof(uint16_t);  // 144 KiB
+    const bool tail = (T % HK) != 0;
     (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
     (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
     (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
     (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-    inc_attr_done(attr_set);
+#define INC_HM(B, TL) hessian_syrk_16bit_256_multi_kernel<B, TL><<<first, 512, smem2, s>>>(a, T)
+    if (xdtype == INC_BF16) { if (tail) INC_HM(true, true); else INC_HM(true, false); }
+    else { if (tail) INC_HM(false, true); else INC_HM(false, false); }
+#undef INC_HM
+    INC_LAUNCH_RETURN();
   }
-  hipStream_t s = inc_s(stream);
-  const bool tail = (T % HK) != 0;
-  if (inc_small_tiles_flag(-1) != 45) {  // transpose-read generation
+#endif
+  {  // transpose-read generation
     const size_t smem3 = (size_t)TR_NST * TR_STAGE;
     static std::atomic<uint64_t> attr3_set{0};
     if (inc_attr_needed(attr3_set)) {
@@ -1262,11 +1275,6 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
     else hessian_syrk_tr_256_multi_kernel<false><<<first, 512, smem3, s>>>(a, T);
     INC_LAUNCH_RETURN();
   }
-#define INC_HM(B, TL) hessian_syrk_16bit_256_multi_kernel<B, TL><<<first, 512, smem2, s>>>(a, T)
-  if (xdtype == INC_BF16) { if (tail) INC_HM(true, true); else INC_HM(true, false); }
-  else { if (tail) INC_HM(false, true); else INC_HM(false, false); }
-#undef INC_HM
-  INC_LAUNCH_RETURN();
 }
 
 int inc_gptq_hessian_finalize(float* H, int64_t K, float percdamp, uint8_t* dead, void* workspace,
