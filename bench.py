@@ -554,6 +554,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--no-per-layer", action="store_true")
     ap.add_argument("--mgpu-mode", choices=("layer", "exact"), default="layer", help="N > 1: one block per GPU on float activations (north_star) | exact reference semantics")
+    ap.add_argument("--layer-on-one-gpu", action="store_true", help="N = 1: time the layer-per-GPU mode's round (float forward + quantise, no exchange)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain script: launch the N ranks ourselves (one process per GPU, RCCL) and hand their output through
@@ -584,7 +585,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the process group has {world} rank(s): refusing to report a number for another job size")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    layer_mode = world > 1 and args.mgpu_mode == "layer"
+    # --layer-on-one-gpu: the layer-per-GPU mode with a "world" of one rank (no exchange) -- the per-round terms of the N-GPU projection
+    layer_mode = args.mgpu_mode == "layer" and (world > 1 or args.layer_on_one_gpu)
     if world > 1:
         # ONE model, N ranks.  layer: one block per rank on the float model's activations; exact: samples sharded, Hessians reduced to
         # their owner rank, factors broadcast, row-sharded solves
@@ -610,6 +612,7 @@ def main():
     if layer_mode:
         rq.independent_setup()
     blocks = rq.gptq_related_blocks["transformers"]
+    round_timing = {}
 
     clock = KernelClock()
     clock.wrap(ops, "gptq_hessian_accum", lambda H, x, b, a: f"hessian_K{x.shape[1]}", lambda H, x, b, a: 2.0 * x.shape[0] * x.shape[1] ** 2)
@@ -642,6 +645,8 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         clock.enabled = True
+        if layer_mode and os.environ.get("INC_MI355X_BENCH_ROUND_TIMING", "1" if world == 1 else "0") == "1":
+            rq._layer_state["timing"] = round_timing  # device-synchronised phase times of every round (three extra syncs per round)
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
             step(i)
@@ -698,7 +703,8 @@ def main():
                                   "behind it only feed the output the reference computes and discards, gptq.py:690-702); "
                                   "INC_MI355X_GPTQ_CAPTURE_EARLY_STOP=0 runs it in full; the quantised model is bit-identical either way"),
                     arithmetic="bf16 activations/weights (MFMA, fp32 accumulate), fp32 Hessian + Cholesky + column loop, int4 codes",
-                    parallelism=("single GPU" if world == 1 else
+                    parallelism=(("single GPU" if not layer_mode else "single GPU running the layer-per-GPU mode's round (float forward of the "
+                                  "block, then its quantisation on those inputs, no second forward): the terms of the N-GPU projection") if world == 1 else
                                  (f"ONE model on {world} ranks, one transformer block per rank (step = one round of {world} blocks): samples sharded "
                                   f"{world}-way for the float forwards, block inputs sent to the block's owner over RCCL ({os.environ.get('INC_MI355X_GPTQ_ACT_EXCHANGE', 'scatter')}), "
                                   "each block calibrated on the FLOAT model's activations (north_star's layer-per-GPU mode; deviates from the reference's "
@@ -708,6 +714,8 @@ def main():
                     steps_per_model=steps_per_model),
         roofline=roofline, kernel_breakdown=breakdown,
     )
+    if round_timing:
+        result["layer_round_ms"] = {k.replace("_s", ""): round(v * 1e3 / args.steps, 2) for k, v in round_timing.items() if k != "_"}
     del model, rq, blocks
     torch.cuda.empty_cache()
     if not args.no_e2e:

@@ -1124,6 +1124,17 @@ class RAWGPTQuantizer(object):
         st = self._layer_state
         ctx, world, rank = self.layer_ctx, st["world"], st["rank"]
         t0 = time.time()
+        timing = st.get("timing")  # {"forward_s", "exchange_s", "quantize_s"} accumulated when the caller put a dict there (bench.py)
+
+        def mark(key, since):
+            if timing is None:
+                return since
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            timing[key] = timing.get(key, 0.0) + now - since
+            return now
+
+        tp = mark("_", time.perf_counter()) if timing is not None else 0.0
         round_blocks = list(range(start, min(start + world, len(blocks))))
         # 1. float forwards of this rank's samples; block b's inputs are kept (the list entries are replaced, not overwritten)
         kept = {}
@@ -1135,6 +1146,7 @@ class RAWGPTQuantizer(object):
                     self._hidden_list()[j] = out
 
                 self._run_block(blocks[b], on_output=replace)
+        tp = mark("forward_s", tp)
         # 2. the inputs of block b -> rank b % world
         mine = next((b for b in round_blocks if owner_of_block(b, world) == rank), None)
         if ctx is None:
@@ -1142,6 +1154,7 @@ class RAWGPTQuantizer(object):
         else:
             full = self._exchange_block_inputs(ctx, round_blocks, kept, st["counts"], st["shape"], st["dtype"], st["exchange"], mine)
         del kept
+        tp = mark("exchange_s", tp)
         # 3. quantise the own block on the whole calibration set
         if mine is not None:
             saved = (self._hidden_list(), self.cache_key_arguments["batch_num"], getattr(self, "_fgroups", None), self._stacks,
@@ -1162,6 +1175,7 @@ class RAWGPTQuantizer(object):
                 self.cache_key_arguments["batch_num"] = batch_num
                 self._fgroups, self._stacks = fgroups, stacks
         del full
+        mark("quantize_s", tp)
         logger.info("Quantized blocks %d..%d of %d (one per rank) in %.2fs", round_blocks[0] + 1, round_blocks[-1] + 1, len(blocks), time.time() - t0)
 
     def independent_finish(self, blocks):

@@ -50,6 +50,9 @@ while [[ $# -gt 0 ]]; do
       bash scripts/gpu_pmc.sh prof > gpurun_out/pmc_kbench.log 2>&1; echo "pmc kbench exit $?"; tail -12 gpurun_out/pmc_kbench.log ;;
     pmcbench)
       bash scripts/gpu_pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1; echo "pmc bench exit $?"; tail -12 gpurun_out/pmc_bench.log ;;
+    benchlayer1)
+      timeout 600 python bench.py --steps 3 --warmup 1 --layer-on-one-gpu --no-cpu-baseline --no-gemm --no-extra-configs --no-e2e --no-per-layer > gpurun_out/bench_layer1.log 2> gpurun_out/bench_layer1.err
+      echo "bench layer-on-one-gpu exit $?"; tail -c 2500 gpurun_out/bench_layer1.log; tail -5 gpurun_out/bench_layer1.err ;;
     awqtests)
       timeout 1200 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider -k "awq" > gpurun_out/pytest_awq.log 2>&1
       echo "pytest(awq) exit $?" | tee -a gpurun_out/pytest_awq.log
