@@ -785,6 +785,7 @@ __global__ __launch_bounds__(64) void gptq_quant_block_kernel(
 // costs ~16 updates instead of 128.  The arithmetic per element is unchanged (true divisions, mul-then-sub,
 // contraction off), so results are bit-identical to the one-lane-per-row kernel and to the reference's ops.
 constexpr int Q4R = 16;  // rows per wave
+constexpr int Q4W = 4;   // waves per workgroup
 // compile-time loop: f(integral_constant<int, I>) for I in [BEGIN, END) -- every register index in the step
 // body is then a literal (a `#pragma unroll` loop this size is only partly unrolled and falls back to
 // s_set_gpr_idx register indexing)
@@ -813,26 +814,34 @@ __device__ __forceinline__ float quad_bcast(float v, int src) {
 // PARAMS: the kernel first computes the (scale, zero) of the block's own groups from the weights it has just loaded --
 // Quantizer.find_params (gptq.py:1501-1571, perchannel, weight=True, no mse search) on W "as it is now" (gptq.py:1266-1272) --
 // and writes them to scale / zero [N, G]: one launch less per 128 columns of the serial chain.  sym_flag as in find_params.
-template <int QDT, int GPB, bool PARAMS = false>
-__global__ __launch_bounds__(64) void gptq_quant_block_q4_kernel(
+// WPW waves per workgroup share ONE Hinv1 tile in LDS (64 KiB): with a wave per workgroup the tile was fetched by every wave and
+// LDS alone limited a CU to two of them -- 768 / 1376 single-wave workgroups for the stacked q/k/v and gate/up solves ran in
+// 1.5 / 2.7 rounds, and the 256 of a 4096-row layer sat on every CU of the chip, where their 64 KiB + 304 registers kept the
+// look-ahead loop's trailing update (two 64 KiB workgroups per CU) off the CU.  Four waves per workgroup: 64 / 192 / 344
+// workgroups, one round, and the other CUs are free for the trailing update that runs underneath the chain.
+template <int QDT, int GPB, bool PARAMS = false, int WPW = 4>
+__global__ __launch_bounds__(64 * WPW) void gptq_quant_block_q4_kernel(
     const float* __restrict__ w, const float* __restrict__ Hinv, float* __restrict__ scale,
     float* __restrict__ zero, uint8_t* __restrict__ codes, void* __restrict__ q_out,
     float* __restrict__ err, int64_t N, int64_t K, int64_t G, int64_t i1, int64_t g0, float maxq, int sym_flag) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* hs = reinterpret_cast<float*>(smem_raw);  // [QB][QB] Hinv1 tile, later reused as the output stage
-  const int lane = threadIdx.x, r = lane >> 2, q = lane & 3;
-  const int64_t n0 = (int64_t)blockIdx.x * Q4R;
+  float* hs = reinterpret_cast<float*>(smem_raw);  // [QB][QB] Hinv1 tile, later reused as the waves' output stages
+  const int lane = threadIdx.x & 63, r = lane >> 2, q = lane & 3;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t n0 = ((int64_t)blockIdx.x * WPW + wave) * Q4R;
   const int64_t row = n0 + r, rowc = row < N ? row : N - 1;
 
-  // Hinv1 tile -> LDS by LDS-DMA: 64 instructions of 1 KiB (two 512-byte rows each), all in flight at once
+  // Hinv1 tile -> LDS by LDS-DMA: 64 instructions of 1 KiB (two 512-byte rows each) shared out over the waves, all in flight at once
   {
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
     const float* hb = Hinv + i1 * K + i1;
     const uint32_t v0 = (uint32_t)(((lane >> 5) * K + 4 * (lane & 31)) * 4);
     const uint32_t step = (uint32_t)(2 * K * 4);
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int jj = 0; jj < 16 / WPW; ++jj) {
+      const int j = jj * WPW + wave;
       lds_dma_4x1k(hb, lds0 + j * 4096, v0 + (4 * j) * step, v0 + (4 * j + 1) * step, v0 + (4 * j + 2) * step, v0 + (4 * j + 3) * step);
+    }
   }
   // this lane's 32 columns of its row: block columns 4c + q
   float wr[32], ev[32];
@@ -925,8 +934,8 @@ __global__ __launch_bounds__(64) void gptq_quant_block_q4_kernel(
     step(std::integral_constant<int, 2 * p + 1>{}, hb2);
   });
   __syncthreads();
-  // stage the three outputs through LDS (rows of 128) for coalesced stores: Err1, Q, codes
-  float* st = hs;  // [Q4R][QB] floats
+  // stage the three outputs through LDS (rows of 128) for coalesced stores: Err1, Q, codes -- every wave in its own 10 KiB
+  float* st = reinterpret_cast<float*>(smem_raw + wave * (Q4R * QB * 5));  // [Q4R][QB] floats, then [Q4R][QB] bytes
 #pragma unroll
   for (int c = 0; c < 32; ++c) st[r * QB + 4 * c + q] = ev[c];
   __syncthreads();
@@ -1140,6 +1149,195 @@ __global__ __launch_bounds__(256) void gptq_lazy_update_v2_kernel(float* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// lazy update, third generation: ONE [128 rows x CW columns] tile per workgroup, two workgroups per CU
+// ---------------------------------------------------------------------------------------------
+// The second generation parks a 128 KiB double buffer per workgroup: one workgroup of four waves per CU, one wave per SIMD, and
+// each of them runs its phases back to back -- Err slice in, Hinv tile in, W tile in, 256 dependent-by-four fp32 MFMAs (7.5 us),
+// W tile out -- so the matrix pipe idles through every load and the loads idle through every MFMA: 40 TFLOP/s of the 157 the
+// exact-fp32 MFMA has at 4096^2 (tools/kbench colloop), and the 128 KiB exclude the quantisation chain's workgroups (64 KiB) from
+// the CU, which serialised the look-ahead loop's two streams (kernel trace profiles/r3d: the "rest" update of block b-1 ran for
+// 110-130 us and the chain of block b+1 could not start under it).  Here a workgroup owns one tile and stages only that tile's
+// slice of Hinv ([128 k][CW] fp32: 64 KiB at CW = 128, 16 KiB at CW = 32): two workgroups share a CU (<= 256 registers per wave), one
+// multiplies while the other loads or stores, and a chain workgroup still fits next to one of them.  CW = 32 serves the
+// look-ahead loop's "next 128 columns" update, which sits on the critical path with only N / 128 row tiles to spread: four times
+// the workgroups, a quarter of the dependent MFMAs each.  Per output element the products are added in the order of the
+// second generation (k = 2s + (lane >> 5), s ascending, acc from 0, then W - acc): bit-identical W.
+template <int CW, int ABL = 0>  // ABL (harness build, timing only): 1 = no MFMAs, 2 = no loads / LDS-DMA, 4 = no stores
+__global__ __launch_bounds__(256, 2) void gptq_lazy_update_v3_kernel(float* __restrict__ w, const float* __restrict__ Hinv,
+                                                                     const float* __restrict__ err, int64_t N, int64_t K,
+                                                                     int64_t i1, int64_t c_begin) {
+  constexpr int NF = CW / 32;
+  // LDS: [0, 64 KiB) the four waves' Err1 slices (16 KiB each), then the Hinv slice [128 k][CW].  At CW = 128 the Hinv slice
+  // REUSES the first 64 KiB: wave w's share of it (k rows 32w .. 32w + 31) lands exactly on wave w's own Err1 slice, which that
+  // wave has finished reading by then -- no workgroup barrier in between.
+  constexpr uint32_t HS_OFF = CW == 128 ? 0u : 65536u;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r0 = (int64_t)blockIdx.y * L2T + wave * 32;  // first row of this wave
+  const int64_t c0 = c_begin + (int64_t)blockIdx.x * CW;
+  const float* const hbase = Hinv + i1 * K;
+
+  // Hinv[i1 + k][c0 .. c0 + CW) -> LDS [k][CW]; this wave moves rows wave * 32 .. + 31 (16 KiB / 4 KiB)
+  auto dma_hinv = [&]() {
+    if constexpr (CW == 128) {
+      int64_t col = c0 + 4 * (lane & 31);
+      if (col > K - 4) col = K - 4;  // partial last tile: clamped columns are never stored
+      const uint32_t v = (uint32_t)(((wave * 32 + (lane >> 5)) * K + col) * 4);
+      const uint32_t step = (uint32_t)(2 * K * 4);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + HS_OFF + wave * 16384);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        lds_dma_4x1k(hbase, dst + q4 * 4096, v + (4 * q4) * step, v + (4 * q4 + 1) * step, v + (4 * q4 + 2) * step, v + (4 * q4 + 3) * step);
+    } else {
+      int64_t col = c0 + 4 * (lane & 7);
+      if (col > K - 4) col = K - 4;
+      const uint32_t v = (uint32_t)(((wave * 32 + (lane >> 3)) * K + col) * 4);
+      const uint32_t step = (uint32_t)(8 * K * 4);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + HS_OFF + wave * 4096);
+      lds_dma_4x1k(hbase, dst, v, v + step, v + 2 * step, v + 3 * step);
+    }
+  };
+  // Err1 slice of this wave (32 rows x 512 B) -> LDS by LDS-DMA, two full rows per instruction.  A lane of the MFMA wants ONE row
+  // (A operand: row lane & 31, k = 2s + (lane >> 5)); fetched that way from global memory every load instruction touches 32
+  // different lines and the 16 KiB slice costs 128 KiB of L2 -> CU traffic per wave (four times the tile's Hinv and W bytes
+  // together; the second generation did exactly that).  Through LDS the global side is coalesced, and the 16-byte chunk index is
+  // XOR-ed with (row & 7) on the SOURCE side so that the row-per-lane ds_read_b128 below is conflict-free.
+  {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 16384);
+    const int64_t rows_here = N - r0 < 32 ? N - r0 : 32;  // >= 1: the grid has no workgroup without rows; a wave may have none
+    const float* ebase = err + (rows_here > 0 ? r0 : N - 1) * QB;
+    uint32_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int R = 2 * j + (lane >> 5);
+      const int Rc = rows_here > 0 ? (R < rows_here ? R : (int)rows_here - 1) : 0;  // rows past N: a valid row's bytes, never stored
+      v[j] = (uint32_t)(Rc * (QB * 4)) + (uint32_t)(((lane & 31) ^ (R & 7)) * 16);
+    }
+    if constexpr ((ABL & 2) == 0) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) lds_dma_4x1k(ebase, dst + q4 * 4096, v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+    }
+  }
+  if constexpr (CW != 128 && (ABL & 2) == 0) dma_hinv();  // separate LDS region: both transfers in flight together
+  // W tile -> registers (D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); rows / columns past the edge clamped
+  float wt[NF][16];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    int64_t col = c0 + nf * 32 + (lane & 31);
+    if (col > K - 1) col = K - 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row > N - 1) row = N - 1;
+      if constexpr ((ABL & 2) == 0) wt[nf][r] = w[row * K + col];  // (stays between the DMA asm statements around it: they are compiler memory barriers)
+      else wt[nf][r] = (float)(row + col);
+    }
+  }
+  f32x16 acc[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
+  // the Err1 DMA is the oldest part of the in-order queue: what was issued after it (the Hinv slice at CW = 32, the W loads) may stay out
+  if constexpr ((ABL & 2) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (CW == 128) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  float a[64];
+  {
+    const int R = lane & 31;
+    const char* eb = smem_raw + wave * 16384 + R * 512;
+    const bool hi = (lane >> 5) != 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float4 v4 = *reinterpret_cast<const float4*>(eb + ((j ^ (R & 7)) * 16));
+      a[2 * j] = hi ? v4.y : v4.x;
+      a[2 * j + 1] = hi ? v4.w : v4.z;
+    }
+  }
+  if constexpr (CW == 128) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's slice is in registers: its LDS space takes the wave's Hinv rows
+    if constexpr ((ABL & 2) == 0) dma_hinv();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float* hs = reinterpret_cast<const float*>(smem_raw + HS_OFF) + (lane >> 5) * CW + (lane & 31);
+  constexpr int BS = NF == 4 ? 4 : 8;  // k-pairs per batch: the B operands of a batch are read together, then multiplied
+#pragma unroll
+  for (int g = 0; g < 64 / BS; ++g) {
+    float b[BS * NF];
+#pragma unroll
+    for (int sb = 0; sb < BS; ++sb)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) b[sb * NF + nf] = hs[(2 * (BS * g + sb)) * CW + nf * 32];
+#pragma unroll
+    for (int sb = 0; sb < BS; ++sb)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        if constexpr ((ABL & 1) == 0) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[BS * g + sb], b[sb * NF + nf], acc[nf], 0, 0, 0);
+        else acc[nf][(sb * NF + nf) & 15] += a[BS * g + sb] * b[sb * NF + nf];
+      }
+  }
+  if constexpr ((ABL & 4) != 0) {
+    float keep = 0.f;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep += wt[nf][r] - acc[nf][r];
+    if (keep == 12345.678f) w[0] = keep;
+    return;
+  }
+  if (r0 + 32 <= N && c0 + CW <= K) {  // wave-uniform: interior tile, unguarded stores
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float* wp = w + (r0 + 4 * (lane >> 5)) * K + c0 + nf * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wp[((r & 3) + 8 * (r >> 2)) * K] = wt[nf][r] - acc[nf][r];
+    }
+  } else {
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int64_t col = c0 + nf * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < N && col < K) w[row * K + col] = wt[nf][r] - acc[nf][r];
+      }
+    }
+  }
+}
+
+// launch of the third generation over the columns [c_begin, c_end) of the trailing matrix (c_begin on the 128-column tile grid that
+// starts at i2): quarter tiles when whole tiles would leave most CUs without a workgroup
+static void launch_lazy_update_v3(float* w, const float* Hinv, const float* err, int64_t N, int64_t K, int64_t i1, int64_t c_begin,
+                                  int64_t c_end, hipStream_t s) {
+  static std::atomic<uint64_t> attr_set{0};
+  if (inc_attr_needed(attr_set)) {
+    (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + L2T * 32 * 4);
+    inc_attr_done(attr_set);
+  }
+  const int64_t row_tiles = ceil_div64(N, L2T);
+  const int64_t col_tiles = ceil_div64(c_end - c_begin, L2T);
+#ifdef INC_KBENCH
+  const int abl = inc_small_tiles_flag(-1) - 86;  // 87 / 88 / 90: timing-only (no MFMAs / no loads / no stores)
+  if (abl == 1 || abl == 2 || abl == 4) {
+#define INC_L3A(A) { (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v3_kernel<128, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+                     gptq_lazy_update_v3_kernel<128, A><<<dim3((unsigned)col_tiles, (unsigned)row_tiles), 256, 65536, s>>>(w, Hinv, err, N, K, i1, c_begin); }
+    if (abl == 1) INC_L3A(1) else if (abl == 2) INC_L3A(2) else INC_L3A(4)
+#undef INC_L3A
+    return;
+  }
+#endif
+  if (row_tiles * col_tiles <= 128)
+    gptq_lazy_update_v3_kernel<32><<<dim3((unsigned)ceil_div64(c_end - c_begin, 32), (unsigned)row_tiles), 256, 65536 + L2T * 32 * 4, s>>>(w, Hinv, err, N, K, i1, c_begin);
+  else
+    gptq_lazy_update_v3_kernel<128><<<dim3((unsigned)col_tiles, (unsigned)row_tiles), 256, 65536, s>>>(w, Hinv, err, N, K, i1, c_begin);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1331,9 +1529,9 @@ int inc_gptq_quant_block(const float* w, const float* Hinv, const float* scale, 
       inc_attr_done(attr4_set);
     }
 #undef INC_Q4_ATTR
-    const unsigned blocks4 = (unsigned)ceil_div64(N, Q4R);
+    const unsigned blocks4 = (unsigned)ceil_div64(N, Q4R * Q4W);
     const int64_t g0 = group_size > 0 ? i1 / group_size : 0;
-#define INC_Q4(GP) gptq_quant_block_q4_kernel<DT, GP><<<blocks4, 64, smem4, s>>>(w, Hinv, const_cast<float*>(scale), const_cast<float*>(zero), codes, q_out, err, N, K, G, i1, g0, maxq, 0)
+#define INC_Q4(GP) gptq_quant_block_q4_kernel<DT, GP><<<blocks4, 64 * Q4W, smem4, s>>>(w, Hinv, const_cast<float*>(scale), const_cast<float*>(zero), codes, q_out, err, N, K, G, i1, g0, maxq, 0)
     INC_DISPATCH_DTYPE(q_dtype, DT, {
       if (gpb == 1) INC_Q4(1); else if (gpb == 2) INC_Q4(2); else INC_Q4(4);
     })
@@ -1372,8 +1570,8 @@ int inc_gptq_quant_block_params(const float* w, const float* Hinv, float* scale,
     inc_attr_done(attr_set);
   }
 #undef INC_Q4P_ATTR
-  const unsigned blocks4 = (unsigned)ceil_div64(N, Q4R);
-#define INC_Q4P(GP) gptq_quant_block_q4_kernel<DT, GP, true><<<blocks4, 64, smem4, s>>>(w, Hinv, scale, zero, codes, q_out, err, N, K, G, i1, g0, maxq, sym)
+  const unsigned blocks4 = (unsigned)ceil_div64(N, Q4R * Q4W);
+#define INC_Q4P(GP) gptq_quant_block_q4_kernel<DT, GP, true><<<blocks4, 64 * Q4W, smem4, s>>>(w, Hinv, scale, zero, codes, q_out, err, N, K, G, i1, g0, maxq, sym)
   INC_DISPATCH_DTYPE(q_dtype, DT, {
     if (gpb == 1) INC_Q4P(1); else if (gpb == 2) INC_Q4P(2); else INC_Q4P(4);
   })
@@ -1386,7 +1584,11 @@ int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t 
   INC_CHECK_ARG(w && Hinv && err && N > 0 && K > 0 && i1 >= 0 && count > 0 && count <= QB);
   const int64_t i2 = i1 + count;
   if (i2 >= K) return INC_OK;  // nothing to the right of the block
-  if (count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles()) {
+  if (count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles() && inc_small_tiles_flag(-1) != 86) {
+    launch_lazy_update_v3(w, Hinv, err, N, K, i1, i2, K, inc_s(stream));
+    INC_LAUNCH_RETURN();
+  }
+  if (count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles()) {  // harness flag 86: second generation
     const int ncol_tiles = (int)ceil_div64(K - i2, L2T);
     const int row_tiles = (int)ceil_div64(N, L2T);
     int nchunks = (int)ceil_div64(512, row_tiles);  // ~512 workgroups when the trailing matrix is wide enough
@@ -1422,6 +1624,10 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
                 (col_end == K || ((col_end - col_begin) % L2T) == 0));
   if (col_begin == col_end) return INC_OK;
   if (!(count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32))) return INC_ERR_UNSUPPORTED;
+  if (inc_small_tiles_flag(-1) != 86) {
+    launch_lazy_update_v3(w, Hinv, err, N, K, i1, col_begin, col_end, inc_s(stream));
+    INC_LAUNCH_RETURN();
+  }
   const int ncol_tiles = (int)ceil_div64(col_end - col_begin, L2T);
   const int row_tiles = (int)ceil_div64(N, L2T);
   int nchunks = (int)ceil_div64(512, row_tiles);
@@ -1501,11 +1707,13 @@ int inc_gptq_quantize_layer(float* w, const float* Hinv, float* scale, float* ze
       if (!lookahead) {
         INC_TRY(inc_gptq_lazy_update(w, Hinv, e, N, K, i1, count, stream))
       } else if (i2 < K) {
-        if (rest_pending) (void)hipStreamWaitEvent(main, rest_done, 0);  // rest(b-1) wrote the columns next(b) updates (and read Err of b-1)
         const int64_t nxt_end = std::min<int64_t>(i2 + QB, K);
+        // Err1 of this block is complete once the chain is: rest(b) may follow rest(b-1) on the side stream at once, next to
+        // next(b) (disjoint columns) -- when the remainder is the longer pole (wide layers) the side stream then never idles
+        if (nxt_end < K) (void)hipEventRecord(ready, main);
+        if (rest_pending) (void)hipStreamWaitEvent(main, rest_done, 0);  // rest(b-1) wrote the columns next(b) updates (and read Err of b-1)
         INC_TRY(inc_gptq_lazy_update_cols(w, Hinv, e, N, K, i1, count, i2, nxt_end, stream))
         if (nxt_end < K) {
-          (void)hipEventRecord(ready, main);
           (void)hipStreamWaitEvent(side, ready, 0);
           INC_TRY(inc_gptq_lazy_update_cols(w, Hinv, e, N, K, i1, count, nxt_end, K, aux_stream))
           (void)hipEventRecord(rest_done, side);

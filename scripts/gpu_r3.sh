@@ -53,6 +53,9 @@ while [[ $# -gt 0 ]]; do
     benchlayer1)
       timeout 600 python bench.py --steps 3 --warmup 1 --layer-on-one-gpu --no-cpu-baseline --no-gemm --no-extra-configs --no-e2e --no-per-layer > gpurun_out/bench_layer1.log 2> gpurun_out/bench_layer1.err
       echo "bench layer-on-one-gpu exit $?"; tail -c 2500 gpurun_out/bench_layer1.log; tail -5 gpurun_out/bench_layer1.err ;;
+    qtrace)
+      ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_qlayer" -o q -- "$R/tools/kbench" qlayer > "$R/gpurun_out/prof_qlayer.log" 2>&1 )
+      echo "qtrace exit $?"; ls gpurun_out/prof_qlayer | head ;;
     awqtests)
       timeout 1200 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider -k "awq" > gpurun_out/pytest_awq.log 2>&1
       echo "pytest(awq) exit $?" | tee -a gpurun_out/pytest_awq.log

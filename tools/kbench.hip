@@ -695,63 +695,153 @@ static int run_hessian_multi_case(int64_t T) {
   return 0;
 }
 
-// ---- GPTQ column loop: quad-per-row quant block + register-resident lazy update vs the first generation --------
-static int run_colloop_case(int64_t N, int64_t K, int gs, int nblocks, bool time_it) {
-  std::vector<float> hw((size_t)N * K), hh((size_t)K * K, 0.f);
+// ---- GPTQ column loop: quad-per-row quant block + lazy update generations (3rd = default, 2nd = flag 86, 1st = flag 1) --------
+static void colloop_inputs(int64_t N, int64_t K, int gs, std::vector<float>& hw, std::vector<float>& hh, std::vector<float>& hs, std::vector<float>& hz) {
+  hw.resize((size_t)N * K); hh.assign((size_t)K * K, 0.f);
   for (auto& v : hw) v = 0.02f * rnd_normal();
   for (int64_t i = 0; i < K; ++i) {  // upper-triangular "Cholesky factor of H^-1": positive diagonal, small off-diagonal
     hh[i * K + i] = 0.5f + (float)(rnd() & 0xffff) / 65536.f;
     for (int64_t j = i + 1; j < K; ++j) hh[i * K + j] = 0.02f * rnd_normal();
   }
   const int64_t G = (K + gs - 1) / gs;
-  std::vector<float> hs((size_t)N * G), hz((size_t)N * G, 8.f);
+  hs.resize((size_t)N * G); hz.assign((size_t)N * G, 8.f);
   for (auto& v : hs) v = 0.01f + 0.005f * (float)(rnd() & 0xffff) / 65536.f;
+}
+
+static int run_colloop_case(int64_t N, int64_t K, int gs, int nblocks, bool time_it) {
+  std::vector<float> hw, hh, hs, hz;
+  colloop_inputs(N, K, gs, hw, hh, hs, hz);
+  const int64_t G = (K + gs - 1) / gs;
   DevBuf<float> Hinv((size_t)K * K), sc(hs.size()), ze(hz.size());
   Hinv.upload(hh); sc.upload(hs); ze.upload(hz);
-  DevBuf<float> W[2] = {DevBuf<float>((size_t)N * K), DevBuf<float>((size_t)N * K)};
-  DevBuf<float> E[2] = {DevBuf<float>((size_t)N * 128), DevBuf<float>((size_t)N * 128)};
-  DevBuf<uint8_t> C[2] = {DevBuf<uint8_t>((size_t)N * K), DevBuf<uint8_t>((size_t)N * K)};
-  DevBuf<uint16_t> Q[2] = {DevBuf<uint16_t>((size_t)N * K), DevBuf<uint16_t>((size_t)N * K)};
-  for (int m = 0; m < 2; ++m) { W[m].upload(hw); C[m].zero(); Q[m].zero(); }
+  constexpr int NV = 3;
+  const int flag[NV] = {0, 86, 1};
+  const char* label[NV] = {"third generation", "second generation", "first generation"};
+  std::vector<DevBuf<float>*> W, E;
+  std::vector<DevBuf<uint8_t>*> C;
+  std::vector<DevBuf<uint16_t>*> Q;
+  for (int m = 0; m < NV; ++m) {
+    W.push_back(new DevBuf<float>((size_t)N * K)); E.push_back(new DevBuf<float>((size_t)N * 128));
+    C.push_back(new DevBuf<uint8_t>((size_t)N * K)); Q.push_back(new DevBuf<uint16_t>((size_t)N * K));
+    W[m]->upload(hw); C[m]->zero(); Q[m]->zero();
+  }
   const int nb = (int)(nblocks < K / 128 ? nblocks : K / 128);
-  for (int m = 0; m < 2; ++m) {
-    inc_debug_set_small_tiles(m);
+  for (int m = 0; m < NV; ++m) {
+    inc_debug_set_small_tiles(flag[m]);
     for (int b = 0; b < nb; ++b) {
-      INCCHECK(inc_gptq_quant_block(W[m].p, Hinv.p, sc.p, ze.p, C[m].p, Q[m].p, INC_BF16, E[m].p, N, K, G, (int64_t)b * 128, 128, gs, 4, nullptr));
-      INCCHECK(inc_gptq_lazy_update(W[m].p, Hinv.p, E[m].p, N, K, (int64_t)b * 128, 128, nullptr));
+      INCCHECK(inc_gptq_quant_block(W[m]->p, Hinv.p, sc.p, ze.p, C[m]->p, Q[m]->p, INC_BF16, E[m]->p, N, K, G, (int64_t)b * 128, 128, gs, 4, nullptr));
+      if (m == 0 && (b & 1) && (int64_t)(b + 2) * 128 < K) {  // every other block in the look-ahead loop's two pieces
+        INCCHECK(inc_gptq_lazy_update_cols(W[m]->p, Hinv.p, E[m]->p, N, K, (int64_t)b * 128, 128, (int64_t)(b + 1) * 128, (int64_t)(b + 2) * 128, nullptr));
+        INCCHECK(inc_gptq_lazy_update_cols(W[m]->p, Hinv.p, E[m]->p, N, K, (int64_t)b * 128, 128, (int64_t)(b + 2) * 128, K, nullptr));
+      } else {
+        INCCHECK(inc_gptq_lazy_update(W[m]->p, Hinv.p, E[m]->p, N, K, (int64_t)b * 128, 128, nullptr));
+      }
     }
   }
   inc_debug_set_small_tiles(0);
   HIPCHECK(hipDeviceSynchronize());
-  std::vector<float> w0 = W[0].download(), w1 = W[1].download(), e0 = E[0].download(), e1 = E[1].download();
-  std::vector<uint8_t> c0 = C[0].download(), c1 = C[1].download();
-  std::vector<uint16_t> q0 = Q[0].download(), q1 = Q[1].download();
-  int64_t dw = 0, de = 0, dc = 0, dq = 0;
-  for (size_t i = 0; i < w0.size(); ++i) { dw += memcmp(&w0[i], &w1[i], 4) != 0; dc += c0[i] != c1[i]; dq += q0[i] != q1[i]; }
-  for (size_t i = 0; i < e0.size(); ++i) de += memcmp(&e0[i], &e1[i], 4) != 0;
-  const bool ok = dw == 0 && de == 0 && dc == 0 && dq == 0;
-  printf("COLLOOP N=%ld K=%ld gs=%d blocks=%d: differing W=%ld Err=%ld codes=%ld Q=%ld (second vs first generation, bitwise)  %s\n", (long)N,
-         (long)K, gs, nb, (long)dw, (long)de, (long)dc, (long)dq, ok ? "OK" : "FAIL");
+  bool ok = true;
+  std::vector<float> w0 = W[0]->download(), e0 = E[0]->download();
+  std::vector<uint8_t> c0 = C[0]->download();
+  std::vector<uint16_t> q0 = Q[0]->download();
+  for (int m = 1; m < NV; ++m) {
+    std::vector<float> w1 = W[m]->download(), e1 = E[m]->download();
+    std::vector<uint8_t> c1 = C[m]->download();
+    std::vector<uint16_t> q1 = Q[m]->download();
+    int64_t dw = 0, de = 0, dc = 0, dq = 0;
+    for (size_t i = 0; i < w0.size(); ++i) { dw += memcmp(&w0[i], &w1[i], 4) != 0; dc += c0[i] != c1[i]; dq += q0[i] != q1[i]; }
+    for (size_t i = 0; i < e0.size(); ++i) de += memcmp(&e0[i], &e1[i], 4) != 0;
+    const bool okm = dw == 0 && de == 0 && dc == 0 && dq == 0;
+    ok = ok && okm;
+    printf("COLLOOP N=%ld K=%ld gs=%d blocks=%d: differing W=%ld Err=%ld codes=%ld Q=%ld (third vs %s, bitwise)  %s\n", (long)N,
+           (long)K, gs, nb, (long)dw, (long)de, (long)dc, (long)dq, label[m], okm ? "OK" : "FAIL");
+  }
   if (time_it) {
     Timer t;
-    for (int m = 0; m < 2; ++m) {
-      inc_debug_set_small_tiles(m);
-      float tq = 0, tl = 0;
+    for (int m = 0; m < NV; ++m) {
+      inc_debug_set_small_tiles(flag[m]);
+      float tq = 0, tl = 0, tn = 0;
+      int nn = 0;
       for (int b = 0; b < nb; ++b) {
         t.start();
-        INCCHECK(inc_gptq_quant_block(W[m].p, Hinv.p, sc.p, ze.p, C[m].p, Q[m].p, INC_BF16, E[m].p, N, K, G, (int64_t)b * 128, 128, gs, 4, nullptr));
+        INCCHECK(inc_gptq_quant_block(W[m]->p, Hinv.p, sc.p, ze.p, C[m]->p, Q[m]->p, INC_BF16, E[m]->p, N, K, G, (int64_t)b * 128, 128, gs, 4, nullptr));
         tq += t.stop_ms();
         t.start();
-        INCCHECK(inc_gptq_lazy_update(W[m].p, Hinv.p, E[m].p, N, K, (int64_t)b * 128, 128, nullptr));
+        INCCHECK(inc_gptq_lazy_update(W[m]->p, Hinv.p, E[m]->p, N, K, (int64_t)b * 128, 128, nullptr));
         tl += t.stop_ms();
+        if (m < 2 && (int64_t)(b + 2) * 128 <= K) {  // the look-ahead loop's "next 128 columns" piece alone
+          t.start();
+          INCCHECK(inc_gptq_lazy_update_cols(W[m]->p, Hinv.p, E[m]->p, N, K, (int64_t)b * 128, 128, (int64_t)(b + 1) * 128, (int64_t)(b + 2) * 128, nullptr));
+          tn += t.stop_ms();
+          ++nn;
+        }
       }
       double fl = 0;
       for (int b = 0; b < nb; ++b) fl += 2.0 * N * 128 * (double)(K - (b + 1) * 128);
-      printf("  %-22s quant_block %8.3f ms/block   lazy_update %8.3f ms/block (%7.1f TFLOP/s fp32)\n", m ? "first generation" : "second generation",
-             tq / nb, tl / nb, fl / (tl * 1e9));
+      printf("  %-22s quant_block %8.3f ms/block   lazy_update %8.3f ms/block (%7.1f TFLOP/s fp32)   next-128 piece %8.3f ms\n", label[m],
+             tq / nb, tl / nb, fl / (tl * 1e9), nn ? tn / nn : 0.f);
+    }
+    // timing-only variants of the third generation's whole-tile kernel
+    const int afl[3] = {87, 88, 90};
+    const char* alab[3] = {"3rd gen - MFMAs", "3rd gen - loads / DMA", "3rd gen - stores"};
+    for (int v = 0; v < 3; ++v) {
+      inc_debug_set_small_tiles(afl[v]);
+      float tl = 0;
+      for (int b = 0; b < nb; ++b) {
+        t.start();
+        INCCHECK(inc_gptq_lazy_update(W[0]->p, Hinv.p, E[0]->p, N, K, (int64_t)b * 128, 128, nullptr));
+        tl += t.stop_ms();
+      }
+      printf("  %-22s lazy_update %8.3f ms/block (timing only)\n", alab[v], tl / nb);
     }
     inc_debug_set_small_tiles(0);
   }
+  for (int m = 0; m < NV; ++m) { delete W[m]; delete E[m]; delete C[m]; delete Q[m]; }
+  return ok ? 0 : 1;
+}
+
+// ---- inc_gptq_quantize_layer end to end (two streams, look-ahead): us per column; third vs second lazy-update generation bitwise ----
+static int run_qlayer_case(int64_t N, int64_t K, int gs) {
+  std::vector<float> hw, hh, hs, hz;
+  colloop_inputs(N, K, gs, hw, hh, hs, hz);
+  const int64_t G = (K + gs - 1) / gs;
+  DevBuf<float> Hinv((size_t)K * K);
+  Hinv.upload(hh);
+  hipStream_t aux;
+  HIPCHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+  const int flag[2] = {0, 86};
+  std::vector<uint8_t> codes[2];
+  std::vector<float> scales[2];
+  float ms[2] = {0, 0};
+  for (int m = 0; m < 2; ++m) {
+    inc_debug_set_small_tiles(flag[m]);
+    DevBuf<float> W((size_t)N * K), sc((size_t)N * G), ze((size_t)N * G), ews((size_t)2 * N * 128);
+    DevBuf<uint8_t> C((size_t)N * K);
+    DevBuf<uint16_t> Q((size_t)N * K);
+    std::vector<float> t_all;
+    for (int rep = 0; rep < 4; ++rep) {
+      W.upload(hw);
+      HIPCHECK(hipDeviceSynchronize());
+      Timer t;
+      t.start();
+      INCCHECK(inc_gptq_quantize_layer(W.p, Hinv.p, sc.p, ze.p, G, nullptr, nullptr, 0, C.p, Q.p, INC_BF16, ews.p, N, K, gs, gs, 128, 4, 1,
+                                       INC_GPTQ_DYNAMIC_GROUPS, nullptr, aux));
+      t_all.push_back(t.stop_ms());
+    }
+    HIPCHECK(hipDeviceSynchronize());
+    std::sort(t_all.begin() + 1, t_all.end());
+    ms[m] = t_all[2];
+    codes[m] = C.download();
+    scales[m] = sc.download();
+  }
+  inc_debug_set_small_tiles(0);
+  HIPCHECK(hipStreamDestroy(aux));
+  int64_t dc = 0, ds = 0;
+  for (size_t i = 0; i < codes[0].size(); ++i) dc += codes[0][i] != codes[1][i];
+  for (size_t i = 0; i < scales[0].size(); ++i) ds += memcmp(&scales[0][i], &scales[1][i], 4) != 0;
+  const bool ok = dc == 0 && ds == 0;
+  printf("QLAYER N=%ld K=%ld gs=%d: %.3f ms = %.3f us/column (lazy update 2nd generation: %.3f ms = %.3f us/column); differing codes=%ld scales=%ld  %s\n",
+         (long)N, (long)K, gs, ms[0], ms[0] * 1e3 / K, ms[1], ms[1] * 1e3 / K, (long)dc, (long)ds, ok ? "OK" : "FAIL");
   return ok ? 0 : 1;
 }
 
@@ -878,6 +968,13 @@ int main(int argc, char** argv) {
     fails += run_hessian_case(16384, 11008, true);
     fails += run_hessian_case(1000, 520, false);      // 40-token tail, feature chunks clamped at K
     fails += run_hessian_multi_case(16384);
+  }
+  if (what == "qlayer" || what == "all") {
+    fails += run_qlayer_case(300, 640, 64);
+    fails += run_qlayer_case(4096, 4096, 128);
+    fails += run_qlayer_case(12288, 4096, 128);
+    fails += run_qlayer_case(22016, 4096, 128);
+    fails += run_qlayer_case(4096, 11008, 128);
   }
   if (what == "colloop" || what == "all") {
     fails += run_colloop_case(200, 512, 32, 4, false);      // ragged rows, 4 groups per block
