@@ -244,6 +244,79 @@ def woq_gemm(x2d, qweight, scales, qzeros, bias, N, K, group_size, bits, g_idx=N
     return y
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream  # (device index) -> hipStream_t of torch's current stream, no Stream object
+_cur_device = torch._C._cuda_getDevice
+
+
+def _none():
+    return None
+
+
+class WoqGemmCall:
+    """inc_woq_gemm with everything that does not change between calls resolved once (the decode path: the kernel is ~6 us,
+    so the host side counts).  Built by MI355XWeightOnlyLinear for its packed buffers; per call only the activation pointer,
+    the output, the stream and the (device, stream) workspace are looked up.  Holds references to the tensors whose addresses
+    it caches; the owner rebuilds it when a buffer is replaced."""
+
+    __slots__ = ("dev", "dev_index", "dtype", "dt", "N", "K", "G", "gs", "bits", "qw", "sc", "qz", "gi", "bi", "keep", "need", "fn",
+                 "bias_conv", "versions")
+
+    def __init__(self, qweight, scales, qzeros, bias, N, K, group_size, bits, dtype, g_idx=None):
+        dev = _dev(qweight, scales, qzeros, bias, g_idx)
+        if dtype is not torch.bfloat16 and dtype is not torch.float16:
+            raise TypeError("woq_gemm computes in bf16 or fp16")
+        self.keep = (qweight, scales, qzeros, bias, g_idx)
+        self.versions = tuple(None if t is None else t._version for t in self.keep)
+        if bias is not None and bias.dtype != dtype:
+            bias = bias.to(dtype)  # converted once (the packed module stores fp16, a bf16 model multiplies in bf16)
+        self.bias_conv = bias
+        self.dev, self.dev_index, self.dtype = dev, dev.index if dev.index is not None else torch.cuda.current_device(), dtype
+        self.dt = INC_BF16 if dtype is torch.bfloat16 else INC_F16
+        self.N, self.K, self.G, self.gs, self.bits = N, K, scales.shape[0], group_size, bits
+        self.qw, self.sc, self.qz, self.gi, self.bi = qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), _ptr(g_idx), _ptr(bias)
+        self.need = {}
+        self.fn = lib.inc_woq_gemm
+
+    # a cache, not state: copies and pickles of the owning module start without it
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_none, ())
+
+    def current(self, qweight, scales, qzeros, bias):
+        """Still describes these tensors (same objects, not written to since)?"""
+        k, v = self.keep, self.versions
+        return (k[0] is qweight and k[1] is scales and k[2] is qzeros and k[3] is bias and qweight._version == v[0]
+                and scales._version == v[1] and qzeros._version == v[2] and (bias is None or bias._version == v[3]))
+
+    def __call__(self, x2d):
+        """x2d: contiguous [M, K] of the call's dtype on the call's device (the owner checks)."""
+        M = x2d.shape[0]
+        y = torch.empty((M, self.N), dtype=self.dtype, device=self.dev)
+        need = self.need.get(M)
+        if need is None:
+            need = self.need[M] = lib.inc_woq_gemm_workspace_bytes(M, self.N, self.K)
+        idx = self.dev_index
+        stream = _raw_stream(idx)
+        wp, wn = None, 0
+        if need > 0:
+            buf = _ws_cache.get((idx, stream))
+            if buf is None or buf.numel() < need:
+                buf = _workspace(self.dev, need)
+            wp, wn = buf.data_ptr(), buf.numel()
+        if _cur_device() == idx:
+            rc = self.fn(x2d.data_ptr(), self.dt, self.qw, self.sc, self.qz, self.gi, self.bi, y.data_ptr(), M, self.N, self.K, self.G,
+                         self.gs, self.bits, wp, wn, stream)
+        else:
+            with torch.cuda.device(self.dev):
+                rc = self.fn(x2d.data_ptr(), self.dt, self.qw, self.sc, self.qz, self.gi, self.bi, y.data_ptr(), M, self.N, self.K,
+                             self.G, self.gs, self.bits, wp, wn, stream)
+        if rc != 0:
+            check(rc, "inc_woq_gemm")
+        return y
+
+
 # ---------------------------------------------------------------------------------------------------
 # K7 group-wise RTN
 # ---------------------------------------------------------------------------------------------------

@@ -112,6 +112,19 @@ def _lookahead_stream(device):
     return st
 
 
+CHOL_LOOKAHEAD = os.environ.get("INC_MI355X_CHOL_LOOKAHEAD", "1") != "0"  # trailing-update chunks of outer block b under the factorisation of b+1
+_CHOL_SIDE_STREAMS = {}
+
+
+def _chol_side_stream(device):
+    """Second stream of a factorisation: one per (device, calling stream) -- concurrent factorisations do not share one."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    st = _CHOL_SIDE_STREAMS.get(key)
+    if st is None:
+        st = _CHOL_SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 CHOL_OUTER = int(os.environ.get("INC_MI355X_CHOL_OUTER", "1024"))  # outer block of the two-level factorisation (columns)
 TRI_DEPTH = int(os.environ.get("INC_MI355X_CHOL_TRI_DEPTH", "2"))    # levels of 2 x 2 splitting in the triangular products
 TRI_MIN = 512                                                        # do not split below this half size
@@ -201,6 +214,15 @@ def inverse_cholesky_upper(H, check=True):
     outer = max(nb, (CHOL_OUTER // nb) * nb)
     tag = 0
     top = []
+    # Look-ahead over the outer blocks (INC_MI355X_CHOL_LOOKAHEAD, default on): the next outer block needs only the FIRST column
+    # chunk of this block's trailing update (it holds that block's diagonal block and its whole panel).  The other chunks run on
+    # a second stream underneath the next block's factorisation -- a chain of one-workgroup diagonal kernels and small GEMMs that
+    # leaves the chip idle (kernel trace at K = 11008: 9.9 ms of chol_diag_block + 13.7 ms of GEMMs back to back) -- and are
+    # awaited before the next trailing update, which accumulates into the same columns.  Same GEMMs, same operands: same bits.
+    main = torch.cuda.current_stream(dev) if H.is_cuda else None
+    side = _chol_side_stream(dev) if (CHOL_LOOKAHEAD and H.is_cuda and Kp > 2 * outer) else None
+    pending = None  # event: the remaining chunks of the previous trailing update are done
+    keep = []       # operands still read by the side stream
     for B in range(0, Kp, outer):
         n2 = min(outer, Kp - B)
         D = A[B:B + n2, B:B + n2]
@@ -220,10 +242,30 @@ def inverse_cholesky_upper(H, check=True):
             panel.copy_(lp)
             M = Kp - (B + n2)
             chunk = max(outer, -(-M // 6 // nb) * nb)                # lower triangle only: <= 6 column chunks, each from its diagonal down
+            if pending is not None:
+                main.wait_event(pending)                            # the previous update's remaining chunks wrote these columns
+                pending = None
+            first = True
             for c0 in range(0, M, chunk):
                 c1 = min(c0 + chunk, M)
-                A[B + n2 + c0:, B + n2 + c0:B + n2 + c1].addmm_(lp[c0:], lp[c0:c1].t(), alpha=-1.0)
+                if side is not None and not first:
+                    if c0 == chunk:
+                        ready = torch.cuda.Event()
+                        ready.record(main)                          # lp and the first chunk are complete
+                        side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        A[B + n2 + c0:, B + n2 + c0:B + n2 + c1].addmm_(lp[c0:], lp[c0:c1].t(), alpha=-1.0)
+                else:
+                    A[B + n2 + c0:, B + n2 + c0:B + n2 + c1].addmm_(lp[c0:], lp[c0:c1].t(), alpha=-1.0)
+                first = False
+            if side is not None and M > chunk:
+                pending = torch.cuda.Event()
+                pending.record(side)
+                keep.append(lp)
+    if pending is not None:
+        main.wait_event(pending)
     invert_by_doubling(top)
+    del keep
     U = torch.flip(X[:K, :K], (0, 1)).contiguous()
     if not check:
         return U, info

@@ -270,6 +270,14 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         running after some of its layers are packed (true_sequential re-runs the block mid-way).
         """
         x = input
+        # decode path: a prepared call for the plain fused plan (ops.WoqGemmCall); the 6-us kernel makes the host side count
+        d = self.__dict__
+        call = d.get("_call")
+        if call is not None and x.dtype is call.dtype and x.device == call.dev and x.is_contiguous() and x.numel() > 0:
+            bufs = self._buffers
+            if call.current(bufs["qweight"], bufs["scales"], bufs["qzeros"], bufs.get("bias", d.get("bias"))):
+                y = call(x if x.dim() == 2 else x.view(-1, call.K))
+                return y if x.dim() == 2 else y.view(*x.shape[:-1], call.N)
         if x.dtype not in (torch.bfloat16, torch.float16):
             x = x.to(torch.float16)
         lead = x.shape[:-1]
@@ -279,11 +287,11 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
         plan = self._forward_plan()
+        d["_call"] = None
         if plan == "fused":
-            y = ops.woq_gemm(
-                x2d, self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features,
-                self.group_size, self.bits,
-            )
+            call = d["_call"] = ops.WoqGemmCall(self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features,
+                                                self.group_size, self.bits, x2d.dtype)
+            y = call(x2d)
         elif plan == "fused_act_order":
             # act_order: the K axis is sorted by group once (below); per call only the activations are gathered
             y = ops.woq_gemm(

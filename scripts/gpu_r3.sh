@@ -56,6 +56,42 @@ while [[ $# -gt 0 ]]; do
     qtrace)
       ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_qlayer" -o q -- "$R/tools/kbench" qlayer > "$R/gpurun_out/prof_qlayer.log" 2>&1 )
       echo "qtrace exit $?"; ls gpurun_out/prof_qlayer | head ;;
+    chol)
+      timeout 300 python scripts/chol_trace.py 11008 > gpurun_out/chol_plain.log 2>&1; tail -7 gpurun_out/chol_plain.log
+      timeout 300 python scripts/chol_trace.py 4096 > gpurun_out/chol_plain4096.log 2>&1; tail -4 gpurun_out/chol_plain4096.log
+      timeout 900 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider -k "chol" > gpurun_out/pytest_chol.log 2>&1
+      echo "pytest(chol) exit $?"; grep -E "passed|failed|Error|error|assert" gpurun_out/pytest_chol.log | tail -8 ;;
+    choltrace)
+      timeout 300 python scripts/chol_trace.py 11008 > gpurun_out/chol_plain.log 2>&1; tail -6 gpurun_out/chol_plain.log
+      ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_chol" -o c -- python "$R/scripts/chol_trace.py" 11008 > "$R/gpurun_out/prof_chol.log" 2>&1 )
+      echo "choltrace exit $?"; tail -6 gpurun_out/prof_chol.log
+      python3 - gpurun_out/prof_chol/c_kernel_trace.csv <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the last run = after the last big gap: split on chol_diag sequences of 86
+diag = [i for i, r in enumerate(rows) if "chol_diag" in r["Kernel_Name"]]
+last = diag[-86]
+# extend to the end of that run: up to the last kernel before the residual GEMMs (take until 40 kernels after the last diag)
+run = rows[last - 3 : diag[-1] + 120]
+t0, t1 = int(run[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in run)
+busy = collections.Counter(); cnt = collections.Counter()
+for r in run:
+    n = r["Kernel_Name"]
+    k = "chol_diag" if "chol_diag" in n else ("gemm" if ("Cijk" in n or "gemm" in n.lower()) else n[:40])
+    busy[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[k] += 1
+# union of busy intervals
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in run)
+tot = 0; cs, ce = iv[0]
+for s, e in iv[1:]:
+    if s > ce: tot += ce - cs; cs, ce = s, e
+    else: ce = max(ce, e)
+tot += ce - cs
+print(f"span {(t1 - t0) / 1e6:.2f} ms, device busy {tot / 1e6:.2f} ms, idle {(t1 - t0 - tot) / 1e6:.2f} ms, kernels {len(run)}")
+for k, v in busy.most_common(12):
+    print(f"  {v / 1e6:8.2f} ms {cnt[k]:5d} x {k}")
+PY
+      ;;
     awqtests)
       timeout 1200 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider -k "awq" > gpurun_out/pytest_awq.log 2>&1
       echo "pytest(awq) exit $?" | tee -a gpurun_out/pytest_awq.log

@@ -296,3 +296,16 @@ def test_accelerator_registry_selection_order(monkeypatch):
         A.accelerator_registry.registered_accelerators.clear()
         A.accelerator_registry.registered_accelerators.update(saved)
         A._select.cache_clear()
+
+
+def test_prepared_gemm_call_is_a_cache_not_state():
+    """ops.WoqGemmCall (the decode path's prepared inc_woq_gemm call kept in the module's __dict__) must not travel with copies or
+    pickles of the module."""
+    import copy
+    import pickle
+
+    from neural_compressor_amd.ops import WoqGemmCall
+
+    obj = WoqGemmCall.__new__(WoqGemmCall)
+    assert copy.deepcopy({"_call": obj})["_call"] is None
+    assert pickle.loads(pickle.dumps({"_call": obj}))["_call"] is None
