@@ -112,7 +112,10 @@ def _lookahead_stream(device):
     return st
 
 
-CHOL_LOOKAHEAD = os.environ.get("INC_MI355X_CHOL_LOOKAHEAD", "1") != "0"  # trailing-update chunks of outer block b under the factorisation of b+1
+# trailing-update chunks of outer block b under the factorisation of b+1, on a second stream.  OFF by default: alone on the chip a
+# K = 11008 factorisation gains 5 % (29.9 -> 28.3 ms, scripts/chol_trace.py), but inside a GPTQ step, where four factorisations and
+# the column loops already share the chip, the extra streams cost more than they hide (336-338 vs 327-328 ms per block, A/B on one box)
+CHOL_LOOKAHEAD = os.environ.get("INC_MI355X_CHOL_LOOKAHEAD", "0") == "1"
 _CHOL_SIDE_STREAMS = {}
 
 
@@ -214,7 +217,7 @@ def inverse_cholesky_upper(H, check=True):
     outer = max(nb, (CHOL_OUTER // nb) * nb)
     tag = 0
     top = []
-    # Look-ahead over the outer blocks (INC_MI355X_CHOL_LOOKAHEAD, default on): the next outer block needs only the FIRST column
+    # Look-ahead over the outer blocks (INC_MI355X_CHOL_LOOKAHEAD=1): the next outer block needs only the FIRST column
     # chunk of this block's trailing update (it holds that block's diagonal block and its whole panel).  The other chunks run on
     # a second stream underneath the next block's factorisation -- a chain of one-workgroup diagonal kernels and small GEMMs that
     # leaves the chip idle (kernel trace at K = 11008: 9.9 ms of chol_diag_block + 13.7 ms of GEMMs back to back) -- and are

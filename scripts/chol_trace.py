@@ -9,6 +9,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import neural_compressor_amd.torch.algorithms.weight_only.gptq as G  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 11008
+G.CHOL_LOOKAHEAD = True
 dev = torch.device("cuda")
 torch.manual_seed(K)
 X = torch.randn(2 * K, K, device=dev)

@@ -92,6 +92,17 @@ for k, v in busy.most_common(12):
     print(f"  {v / 1e6:8.2f} ms {cnt[k]:5d} x {k}")
 PY
       ;;
+    benchab)
+      for v in 1 0 1 0; do
+        INC_MI355X_CHOL_LOOKAHEAD=$v timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-gemm --no-extra-configs --no-e2e --no-per-layer > gpurun_out/bench_ab.log 2> gpurun_out/bench_ab.err
+        python3 - $v <<'PY'
+import json, sys
+for line in open("gpurun_out/bench_ab.log"):
+    if line.startswith("{"):
+        d = json.loads(line)
+        print("chol lookahead", sys.argv[1], "ms/step", d["ms_per_step"], {k.replace("quantize_layer_", "ql_"): v["avg_ms"] for k, v in d["kernel_breakdown"].items()})
+PY
+      done ;;
     awqtests)
       timeout 1200 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider -k "awq" > gpurun_out/pytest_awq.log 2>&1
       echo "pytest(awq) exit $?" | tee -a gpurun_out/pytest_awq.log
