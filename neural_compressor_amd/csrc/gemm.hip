@@ -2041,7 +2041,14 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     }
     static const int d2r_abl[10] = {0, 0, 4, 8, 12, 76, 128, 0, 0, 0};  // harness flags 90..96 (91: three x stages; 92..96 timing-only)
     const int abl = dbg >= 90 ? d2r_abl[dbg - 90] : 0;
-    (void)inc_launch_woq_gemm_d2r(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps, splits, bf, dbg == 91 ? 3 : 4, abl, s);
+#ifdef INC_KBENCH
+    // harness flag 97: the eight-wave form (gemm_d2r8.hip, two waves per SIMD with redundant dequantisation): bit-identical and 6 %
+    // SLOWER (1203 vs 1284 TFLOP/s at 4096^3, profiles/r3h_kbench_d2r8.log) -- built into the harness library only
+    if (dbg == 97)
+      (void)inc_launch_woq_gemm_d2r8(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps, splits, bf, s);
+    else
+#endif
+      (void)inc_launch_woq_gemm_d2r(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps, splits, bf, dbg == 91 ? 3 : 4, abl, s);
     if (part) {
       int64_t rb = ceil_div64(M * N / 4, 256);
       if (rb > 4096) rb = 4096;

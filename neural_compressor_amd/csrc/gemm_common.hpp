@@ -7,6 +7,10 @@
 int inc_launch_woq_gemm_d2r(const uint16_t* x, const uint32_t* qw, const uint16_t* scales, const uint32_t* qz, const uint16_t* bias,
                             uint16_t* y, int64_t M, int64_t N, int64_t K, int64_t NW, int g_shift, int y_vec_ok, float* part, int steps,
                             int splits, bool bf, int ns, int abl, hipStream_t s);
+// the same tile with eight waves, two per SIMD (gemm_d2r8.hip)
+int inc_launch_woq_gemm_d2r8(const uint16_t* x, const uint32_t* qw, const uint16_t* scales, const uint32_t* qz, const uint16_t* bias,
+                             uint16_t* y, int64_t M, int64_t N, int64_t K, int64_t NW, int g_shift, int y_vec_ok, float* part, int steps,
+                             int splits, bool bf, hipStream_t s);
 
 namespace {
 

@@ -285,9 +285,9 @@ static int run_d2r_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool 
   run(42, y.p);
   HIPCHECK(hipDeviceSynchronize());
   int fails = 0;
-  const int chk[2] = {90, 91};
+  const int chk[3] = {90, 91, 97};
   std::vector<uint16_t> h1 = y.download();
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < 3; ++c) {
     HIPCHECK(hipMemset(y2.p, 0xee, y2.n * 2));
     run(chk[c], y2.p);
     HIPCHECK(hipDeviceSynchronize());
@@ -300,9 +300,9 @@ static int run_d2r_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool 
     if (diff) { printf(" (first at row %zu col %zu: %04x vs %04x)  FAIL\n", first / N, first % N, h2[first], h1[first]); ++fails; }
   }
   if (time_it) {
-    const int nv_all = 8;
-    const int modes[nv_all] = {42, 90, 91, 92, 93, 94, 95, 96};
-    const char* labels[nv_all] = {"PC producer/consumer", "D2R 4 x-stages", "D2R 3 x-stages", "D2R - x LDS-DMA", "D2R - W loads", "D2R - all global traffic",
+    const int nv_all = 9;
+    const int modes[nv_all] = {42, 90, 97, 91, 92, 93, 94, 95, 96};
+    const char* labels[nv_all] = {"PC producer/consumer", "D2R 4 x-stages", "D2R8 two waves per SIMD", "D2R 3 x-stages", "D2R - x LDS-DMA", "D2R - W loads", "D2R - all global traffic",
                                   "D2R - global - barrier", "D2R - epilogue stores"};
     const int nv = ablate ? nv_all : 3, rounds = 5, iters = 8;
     std::vector<std::vector<float>> ms(nv);
