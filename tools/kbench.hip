@@ -971,6 +971,7 @@ int main(int argc, char** argv) {
   }
   if (what == "qlayer" || what == "all") {
     fails += run_qlayer_case(300, 640, 64);
+    fails += run_qlayer_case(260, 520, 64);        // K not a multiple of 128: one stream, partial last tile, ragged last block
     fails += run_qlayer_case(4096, 4096, 128);
     fails += run_qlayer_case(12288, 4096, 128);
     fails += run_qlayer_case(22016, 4096, 128);
@@ -978,6 +979,8 @@ int main(int argc, char** argv) {
   }
   if (what == "colloop" || what == "all") {
     fails += run_colloop_case(200, 512, 32, 4, false);      // ragged rows, 4 groups per block
+    fails += run_colloop_case(260, 520, 64, 4, false);      // partial last column tile (8 columns), ragged rows
+    fails += run_colloop_case(4100, 1288, 128, 10, false);  // a row tile with 4 rows, partial last tile, whole and quarter tiles
     fails += run_colloop_case(4096, 4096, 128, 32, true);
     fails += run_colloop_case(11008, 4096, 128, 8, true);
     fails += run_colloop_case(4096, 11008, 128, 8, true);
