@@ -136,9 +136,9 @@ def bench_dequant_gemm(device, shapes, iters=20):
         m.bias = None
         del w, iw
         x = torch.randn(M, K, device=device, dtype=torch.bfloat16)
-        # steady state: the chip needs a few milliseconds of matrix work to settle its clocks after the (VALU-only) packing above;
-        # median of three timed batches
-        for _ in range(20 if M >= 1024 else 3):
+        # steady state: the chip needs some tens of milliseconds of matrix work to settle its clocks after the (VALU-only) packing
+        # above -- the first large shape of the list read 10 % low with 20 warm-up calls (2 ms); median of three timed batches
+        for _ in range(150 if M >= 1024 else 3):
             m(x)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1024,6 +1024,9 @@ __global__ __launch_bounds__(256) void gptq_lazy_update_kernel(float* __restrict
     }
 }
 
+constexpr int L2T = 128;  // rows / columns of a lazy-update tile
+
+#ifdef INC_KBENCH  // superseded by the third generation below; harness flag 86, its bitwise A/B partner (tools/kbench colloop / qlayer)
 // ---------------------------------------------------------------------------------------------
 // lazy update, second generation: W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] with Err1 held in registers
 // ---------------------------------------------------------------------------------------------
@@ -1033,7 +1036,6 @@ __global__ __launch_bounds__(256) void gptq_lazy_update_kernel(float* __restrict
 // Hinv arrives by LDS-DMA into one of two 64 KiB LDS buffers while the previous tile is being multiplied
 // (exact fp32 v_mfma_f32_32x32x2_f32: 256 per wave per tile), the W tile is fetched into registers at the
 // start of the tile and written back as W - acc at its end (same "sum, then subtract" order as before).
-constexpr int L2T = 128;
 template <bool UNUSED>
 __global__ __launch_bounds__(256) void gptq_lazy_update_v2_kernel(float* __restrict__ w, const float* __restrict__ Hinv,
                                                                   const float* __restrict__ err, int64_t N, int64_t K,
@@ -1148,7 +1150,7 @@ __global__ __launch_bounds__(256) void gptq_lazy_update_v2_kernel(float* __restr
     __syncthreads();
   }
 }
-
+#endif  // INC_KBENCH
 
 // ---------------------------------------------------------------------------------------------
 // lazy update, third generation: ONE [128 rows x CW columns] tile per workgroup, two workgroups per CU
@@ -1588,6 +1590,7 @@ int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t 
     launch_lazy_update_v3(w, Hinv, err, N, K, i1, i2, K, inc_s(stream));
     INC_LAUNCH_RETURN();
   }
+#ifdef INC_KBENCH
   if (count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles()) {  // harness flag 86: second generation
     const int ncol_tiles = (int)ceil_div64(K - i2, L2T);
     const int row_tiles = (int)ceil_div64(N, L2T);
@@ -1603,6 +1606,7 @@ int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t 
         w, Hinv, err, N, K, i1, i2, nchunks, ncol_tiles);
     INC_LAUNCH_RETURN();
   }
+#endif
   const size_t smem = (size_t)LT * LAP * 4 + (size_t)QB * LT * 4;
   static std::atomic<uint64_t> attr_set{0};
   if (inc_attr_needed(attr_set)) {
@@ -1628,6 +1632,7 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
     launch_lazy_update_v3(w, Hinv, err, N, K, i1, col_begin, col_end, inc_s(stream));
     INC_LAUNCH_RETURN();
   }
+#ifdef INC_KBENCH  // harness flag 86: second generation
   const int ncol_tiles = (int)ceil_div64(col_end - col_begin, L2T);
   const int row_tiles = (int)ceil_div64(N, L2T);
   int nchunks = (int)ceil_div64(512, row_tiles);
@@ -1640,6 +1645,7 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
   }
   gptq_lazy_update_v2_kernel<true><<<dim3((unsigned)nchunks, (unsigned)row_tiles), 256, smem2, inc_s(stream)>>>(
       w, Hinv, err, N, K, i1, col_begin, nchunks, ncol_tiles);
+#endif
   INC_LAUNCH_RETURN();
 }
 
