@@ -259,7 +259,7 @@ class WoqGemmCall:
     it caches; the owner rebuilds it when a buffer is replaced."""
 
     __slots__ = ("dev", "dev_index", "dtype", "dt", "N", "K", "G", "gs", "bits", "qw", "sc", "qz", "gi", "bi", "keep", "need", "fn",
-                 "bias_conv", "versions")
+                 "bias_conv", "versions", "tag")
 
     def __init__(self, qweight, scales, qzeros, bias, N, K, group_size, bits, dtype, g_idx=None):
         dev = _dev(qweight, scales, qzeros, bias, g_idx)
@@ -275,6 +275,7 @@ class WoqGemmCall:
         self.N, self.K, self.G, self.gs, self.bits = N, K, scales.shape[0], group_size, bits
         self.qw, self.sc, self.qz, self.gi, self.bi = qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), _ptr(g_idx), _ptr(bias)
         self.need = {}
+        self.tag = (None, None)  # (the owner's g_idx buffer, its version) when the owner's plan was chosen
         self.fn = lib.inc_woq_gemm
 
     # a cache, not state: copies and pickles of the owning module start without it
@@ -284,11 +285,13 @@ class WoqGemmCall:
     def __reduce__(self):
         return (_none, ())
 
-    def current(self, qweight, scales, qzeros, bias):
-        """Still describes these tensors (same objects, not written to since)?"""
+    def current(self, qweight, scales, qzeros, bias, owner_g_idx=None):
+        """Still describes these tensors (same objects, not written to since)?  `owner_g_idx`: the owner's g_idx buffer as it is now --
+        the call was built for the owner's plan at that time (`tag`), which a new or rewritten g_idx invalidates."""
         k, v = self.keep, self.versions
         return (k[0] is qweight and k[1] is scales and k[2] is qzeros and k[3] is bias and qweight._version == v[0]
-                and scales._version == v[1] and qzeros._version == v[2] and (bias is None or bias._version == v[3]))
+                and scales._version == v[1] and qzeros._version == v[2] and (bias is None or bias._version == v[3])
+                and self.tag[0] is owner_g_idx and (owner_g_idx is None or owner_g_idx._version == self.tag[1]))
 
     def __call__(self, x2d):
         """x2d: contiguous [M, K] of the call's dtype on the call's device (the owner checks)."""

@@ -275,7 +275,7 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         call = d.get("_call")
         if call is not None and x.dtype is call.dtype and x.device == call.dev and x.is_contiguous() and x.numel() > 0:
             bufs = self._buffers
-            if call.current(bufs["qweight"], bufs["scales"], bufs["qzeros"], bufs.get("bias", d.get("bias"))):
+            if call.current(bufs["qweight"], bufs["scales"], bufs["qzeros"], bufs.get("bias", d.get("bias")), bufs.get("g_idx", d.get("g_idx"))):
                 y = call(x if x.dim() == 2 else x.view(-1, call.K))
                 return y if x.dim() == 2 else y.view(*x.shape[:-1], call.N)
         if x.dtype not in (torch.bfloat16, torch.float16):
@@ -291,6 +291,8 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         if plan == "fused":
             call = d["_call"] = ops.WoqGemmCall(self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features,
                                                 self.group_size, self.bits, x2d.dtype)
+            gi = self.g_idx
+            call.tag = (gi, None if gi is None else gi._version)
             y = call(x2d)
         elif plan == "fused_act_order":
             # act_order: the K axis is sorted by group once (below); per call only the activations are gathered

@@ -782,3 +782,58 @@ def test_gptq_layer_wide_groups_and_blocks_vs_reference(hip, tag):
     if not kw["sym"]:
         assert float((zero.cpu() != torch.from_numpy(golden[f"{tag}_zero"])).float().mean()) <= 0.01
     assert rel_fro(Q.cpu(), torch.from_numpy(golden[f"{tag}_Q"])) <= 3e-2
+
+
+@pytest.mark.gpu
+def test_prepared_forward_call_follows_the_module(hip):
+    """The decode path's prepared call (ops.WoqGemmCall, kept by the module after its first fused forward) must give what the plain
+    entry gives, and must be rebuilt when a buffer is replaced or rewritten: bias swapped / removed, weights re-packed in place,
+    a g_idx appearing, another dtype."""
+    from neural_compressor_amd import ops
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    torch.manual_seed(0)
+    N, K, gs = 256, 512, 128
+
+    def pack_into(m, seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        w = (torch.randn(N, K, generator=g) * 0.02).to(hip)
+        iw, sc, zp = quant_tensor(w, bits=4, group_size=gs, scheme="asym", return_int=True)
+        m.pack(iw, sc, zp, torch.arange(N, device=hip, dtype=torch.float32) * 1e-3)
+
+    m = MI355XWeightOnlyLinear(K, N, bits=4, group_size=gs, zp=True, bias=True, device=hip)
+    pack_into(m, 1)
+    x = torch.randn(3, K, device=hip, dtype=torch.bfloat16)
+
+    def plain(xx):
+        return ops.woq_gemm(xx.reshape(-1, K), m.qweight, m.scales, m.qzeros, m.bias, N, K, gs, 4).reshape(*xx.shape[:-1], N)
+
+    y0 = m(x)
+    call = m.__dict__["_call"]
+    assert call is not None and torch.equal(y0, plain(x))
+    assert torch.equal(m(x), y0) and m.__dict__["_call"] is call                 # reused
+    x3 = torch.randn(2, 5, K, device=hip, dtype=torch.bfloat16)
+    assert torch.equal(m(x3), plain(x3)) and m.__dict__["_call"] is call         # leading dimensions are a view
+    # the weights are re-packed in place: same tensors, new versions
+    pack_into(m, 2)
+    y1 = m(x)
+    assert not torch.equal(y1, y0) and torch.equal(y1, plain(x)) and m.__dict__["_call"] is not call
+    # bias replaced, then removed
+    call = m.__dict__["_call"]
+    m.bias = torch.full((N,), 0.25, device=hip, dtype=torch.float16)
+    assert torch.equal(m(x), plain(x)) and m.__dict__["_call"] is not call
+    m.bias = None
+    assert torch.equal(m(x), plain(x))
+    # another activation dtype
+    xh = x.to(torch.float16)
+    assert torch.equal(m(xh), plain(xh)) and m.__dict__["_call"].dtype is torch.float16
+    # an fp32 input is computed in fp16 and returned in fp32 (no prepared call for it: the cast happens first)
+    assert m(x.float()).dtype == torch.float32
+    # a g_idx that is not the contiguous one switches the plan: the prepared call must not survive it
+    assert torch.equal(m(xh), plain(xh))
+    perm = torch.randperm(K, device=hip)
+    m.g_idx = ((perm // gs).to(torch.int32))
+    y_g = m(xh)
+    ref = torch.nn.functional.linear(xh, m.recover(dtype=torch.float16))
+    assert (y_g.float() - ref.float()).norm() <= 2e-3 * ref.float().norm()
