@@ -142,3 +142,15 @@ def test_layer_mode_activation_exchange_gloo_world2(exchange):
         out = mgr.dict()
         mp.spawn(_layer_exchange_worker, args=(world, port, exchange, out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("exchange", ["scatter", "broadcast"])
+def test_layer_mode_activation_exchange_gloo_world3_with_an_empty_rank(exchange):
+    """Three ranks, one of them without calibration samples (3 + 2 + 0), partial rounds only: the rank without samples still
+    receives the complete inputs of the block it owns and sends nothing."""
+    world, port = 3, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_layer_exchange_worker, args=(world, port, exchange, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True, 2: True}
