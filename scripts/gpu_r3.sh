@@ -94,13 +94,13 @@ PY
       ;;
     benchab)
       for v in 1 0 1 0; do
-        INC_MI355X_CHOL_LOOKAHEAD=$v timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-gemm --no-extra-configs --no-e2e --no-per-layer > gpurun_out/bench_ab.log 2> gpurun_out/bench_ab.err
+        env "${ABVAR:-INC_MI355X_CHOL_LOOKAHEAD}=$v" timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-gemm --no-extra-configs --no-e2e --no-per-layer > gpurun_out/bench_ab.log 2> gpurun_out/bench_ab.err
         python3 - $v <<'PY'
 import json, sys
 for line in open("gpurun_out/bench_ab.log"):
     if line.startswith("{"):
         d = json.loads(line)
-        print("chol lookahead", sys.argv[1], "ms/step", d["ms_per_step"], {k.replace("quantize_layer_", "ql_"): v["avg_ms"] for k, v in d["kernel_breakdown"].items()})
+        print("variant", sys.argv[1], "ms/step", d["ms_per_step"], {k.replace("quantize_layer_", "ql_"): v["avg_ms"] for k, v in d["kernel_breakdown"].items()})
 PY
       done ;;
     awqtests)
