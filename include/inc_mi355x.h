@@ -174,13 +174,18 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
 
 /* The same update for up to 8 Hessians in ONE launch: the distinct layer inputs of one calibration forward of a block
  * (add_batch runs once per hooked layer per forward, gptq.py:670-688) -- xs[i] [T,Ks[i]] 16-bit with row stride
- * ldxs[i], Hs[i] [Ks[i],Ks[i]] fp32, all with the same token count T.  Every tile is computed exactly as by
- * inc_gptq_hessian_accum (bit-identical H); what changes is that the small Hessians no longer leave half of the CUs idle.
+ * ldxs[i], Hs[i] [Ks[i],Ks[i]] fp32, all with the same token count T.  The small Hessians no longer leave half of the
+ * CUs idle, and -- given `workspace` (>= inc_gptq_hessian_accum_multi_workspace_bytes(), 16-byte aligned; NULL = off) --
+ * the tiles of the launch's last, partly filled round are cut into token ranges computed by otherwise idle CUs and added
+ * into H in range order by a second small launch (deterministic).  Every other tile is computed exactly as by
+ * inc_gptq_hessian_accum (bit-identical); a tile of the split tail differs from it by the fp32 rounding of adding two to four
+ * partial sums instead of one.
  * INC_ERR_UNSUPPORTED (nothing launched) for fp32 inputs, K < 256, unaligned rows or more than 8 problems: call the
  * single-problem entry instead.  The pointer / size arrays are HOST arrays, read before the call returns.             */
+int64_t inc_gptq_hessian_accum_multi_workspace_bytes(void);
 int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64_t T, const int64_t* Ks,
                                  const int64_t* ldxs, float* const* Hs, const float* betas, const float* alphas,
-                                 inc_stream_t stream);
+                                 void* workspace, int64_t workspace_bytes, inc_stream_t stream);
 
 /* == GPTQ.fasterquant prologue (gptq.py:1186-1189, 1221-1227): mirror the upper triangle to the
  *   lower, dead[i] = (H[i,i]==0) -> H[i,i]=1, damp = percdamp*mean(diag(H)), H[i,i] += damp.

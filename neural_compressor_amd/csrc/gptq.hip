@@ -374,9 +374,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // ABL (harness build only, timing-only, WRONG results): bit 0 no LDS-DMA, bit 1 no fragment reads and no MFMA
+// `slab` != nullptr: the raw sums of this token range go to slab[256][256] instead of into H (a tile of the launch's last, partly
+// filled round computed by several workgroups: hessian_tail_finalize_kernel adds the ranges in order)
 template <bool IS_BF16, int TOK, int NST, int ABL = 0>
 __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
-                                                     float* __restrict__ H, float beta, float alpha, int nt, int block, int nblocks) {
+                                                     float* __restrict__ H, float beta, float alpha, int nt, int block, int nblocks,
+                                                     float* __restrict__ slab = nullptr) {
   static_assert((NST & (NST - 1)) == 0 && NST >= 2 && NST <= 4 && TOK % 32 == 0, "stage ring");
   constexpr int D = NST - 1;        // steps the DMA runs ahead
   constexpr int RPW = TOK / 8;      // DMA requests (token rows) per wave and step
@@ -484,6 +487,16 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
   }
 
   // epilogue: D[row i][col j] of a 16x16 fragment: col = lane & 15, row = 4 * (lane >> 4) + r
+  if (slab) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          slab[(wm * 128 + m * 16 + 4 * (lane >> 4) + r) * H2 + wn * 64 + n * 16 + (lane & 15)] = acc[m][n][r];
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < 8; ++m)
 #pragma unroll
@@ -522,6 +535,7 @@ __global__ __launch_bounds__(512) void hessian_syrk_16bit_256_kernel(const uint1
 // XCD-local super-tile order (the decode only needs the block's index modulo 8 to be constant per XCD, which a shifted range
 // preserves).  Each tile is computed exactly as in the single-problem launch: bit-identical H.
 constexpr int HESSIAN_MAX_BATCH = 8;
+constexpr int HESSIAN_TAIL_UNITS = 256;  // workgroups of a split tail at most (= the workspace: 64 MiB of 256 x 256 fp32 tiles)
 struct HessianBatch {
   const uint16_t* x[HESSIAN_MAX_BATCH];
   float* H[HESSIAN_MAX_BATCH];
@@ -530,20 +544,82 @@ struct HessianBatch {
   float beta[HESSIAN_MAX_BATCH];
   float alpha[HESSIAN_MAX_BATCH];
   int nt[HESSIAN_MAX_BATCH];
-  int first[HESSIAN_MAX_BATCH + 1];  // first block of every problem, then the grid size
+  int first[HESSIAN_MAX_BATCH + 1];  // first block of every problem, then the number of tiles
   int n;
+  // the launch's last, partly filled round: tiles [full, first[n]) are computed by `nseg` workgroups each (token ranges, raw sums into
+  // `slab`), hessian_tail_finalize_kernel folds them into H.  nseg == 1: every tile is one workgroup (full == first[n]).
+  int full, nseg;
+  float* slab;
 };
+
+// token range of segment `seg` of `nseg`: whole TOK-token steps, the first (steps % nseg) segments one step longer
+__device__ __forceinline__ void hessian_segment(int64_t T, int tok, int seg, int nseg, int64_t& t0, int64_t& tcount) {
+  const int steps = (int)((T + tok - 1) / tok), q = steps / nseg, r = steps % nseg;
+  const int s0 = seg * q + min(seg, r), s1 = s0 + q + (seg < r ? 1 : 0);
+  t0 = (int64_t)s0 * tok;
+  const int64_t t1 = min((int64_t)s1 * tok, T);
+  tcount = t1 > t0 ? t1 - t0 : 0;
+}
 
 template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST>
 __global__ __launch_bounds__(512) void hessian_syrk_tr_256_multi_kernel(HessianBatch args, int64_t T) {
-  const int b = (int)blockIdx.x;
+  int b = (int)blockIdx.x, seg = 0;
+  const bool split = b >= args.full;
+  if (split) {  // a unit of the split tail: tile full + u / nseg, token range u % nseg
+    const int u = b - args.full;
+    seg = u % args.nseg;
+    b = args.full + u / args.nseg;
+  }
   int p = 0;
 #pragma unroll
   for (int i = 1; i < HESSIAN_MAX_BATCH; ++i)
     if (i < args.n && b >= args.first[i]) p = i;
   p = __builtin_amdgcn_readfirstlane(p);
-  hessian_syrk_tr_tile<IS_BF16, TOK, NST>(args.x[p], T, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p], args.nt[p],
-                                b - args.first[p], args.first[p + 1] - args.first[p]);
+  if (!split) {
+    hessian_syrk_tr_tile<IS_BF16, TOK, NST>(args.x[p], T, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p], args.nt[p],
+                                  b - args.first[p], args.first[p + 1] - args.first[p]);
+  } else {
+    int64_t t0, tc;
+    hessian_segment(T, TOK, seg, args.nseg, t0, tc);
+    float* slab = args.slab + ((int64_t)((int)blockIdx.x - args.full)) * (H2 * H2);
+    if (tc > 0)
+      hessian_syrk_tr_tile<IS_BF16, TOK, NST>(args.x[p] + t0 * args.ldx[p], tc, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p],
+                                    args.nt[p], b - args.first[p], args.first[p + 1] - args.first[p], slab);
+    else
+      for (int i = threadIdx.x; i < H2 * H2; i += 512) slab[i] = 0.f;
+  }
+}
+
+// H tile <- beta * H + alpha * (range 0 + range 1 + ...), ranges added in order: the tiles of the split tail
+__global__ __launch_bounds__(512) void hessian_tail_finalize_kernel(HessianBatch args) {
+  const int b = args.full + (int)blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < HESSIAN_MAX_BATCH; ++i)
+    if (i < args.n && b >= args.first[i]) p = i;
+  p = __builtin_amdgcn_readfirstlane(p);
+  int ti, tj;
+  xcd_supertile_decode(b - args.first[p], args.first[p + 1] - args.first[p], args.nt[p], ti, tj);
+  const int64_t K = args.K[p], i0 = (int64_t)ti * H2, j0 = (int64_t)tj * H2;
+  float* __restrict__ H = args.H[p];
+  const float beta = args.beta[p], alpha = args.alpha[p];
+  const float* __restrict__ sl = args.slab + (int64_t)blockIdx.x * args.nseg * (H2 * H2);
+  for (int idx = threadIdx.x * 4; idx < H2 * H2; idx += 512 * 4) {
+    const int r = idx / H2, c = idx % H2;
+    float4 sum = *reinterpret_cast<const float4*>(sl + idx);
+    for (int s2 = 1; s2 < args.nseg; ++s2) {
+      const float4 v = *reinterpret_cast<const float4*>(sl + (int64_t)s2 * (H2 * H2) + idx);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const int64_t row = i0 + r, col = j0 + c;
+    if (row < K) {
+      float* hp = H + row * K + col;
+      const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < K) hp[e] = beta * hp[e] + alpha * sv[e];
+    }
+  }
 }
 
 #ifdef INC_KBENCH
@@ -1417,8 +1493,13 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
   INC_LAUNCH_RETURN();
 }
 
+// Bytes of scratch with which inc_gptq_hessian_accum_multi can split the tiles of its last, partly filled round over idle CUs
+// (at most one round of 256 x 256 fp32 tiles).
+int64_t inc_gptq_hessian_accum_multi_workspace_bytes(void) { return (int64_t)HESSIAN_TAIL_UNITS * H2 * H2 * 4; }
+
 int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64_t T, const int64_t* Ks, const int64_t* ldxs,
-                                 float* const* Hs, const float* betas, const float* alphas, inc_stream_t stream) {
+                                 float* const* Hs, const float* betas, const float* alphas, void* workspace, int64_t workspace_bytes,
+                                 inc_stream_t stream) {
   INC_CHECK_ARG(n > 0 && xs && Ks && ldxs && Hs && betas && alphas && T > 0);
   if (n > HESSIAN_MAX_BATCH || !(xdtype == INC_BF16 || xdtype == INC_F16) || inc_force_small_tiles()) return INC_ERR_UNSUPPORTED;
   HessianBatch a;
@@ -1440,9 +1521,37 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
   for (int i = n; i <= HESSIAN_MAX_BATCH; ++i) a.first[i] = first;
   for (int i = n; i < HESSIAN_MAX_BATCH; ++i) { a.x[i] = a.x[0]; a.H[i] = a.H[0]; a.K[i] = a.K[0]; a.ldx[i] = a.ldx[0]; a.beta[i] = 1.f; a.alpha[i] = 0.f; a.nt[i] = a.nt[0]; }
   a.n = n;
+  a.full = first;
+  a.nseg = 1;
+  a.slab = nullptr;
   hipStream_t s = inc_s(stream);
+  // Tile quantisation: `first` equal tiles on `cus` CUs (one workgroup per CU: 132 KiB of LDS) run in ceil(first / cus) rounds; when the
+  // last round fills less than half of the chip its tiles are cut into nseg = cus / tail token ranges, one workgroup each (a Llama
+  // block's launch: 1354 tiles = 5 rounds + 74 tiles -> 222 units of a third: 5.4 rounds instead of 6).  The ranges' raw sums go to
+  // the caller's workspace and a second, small launch adds them into H in range order: deterministic, and every tile outside the tail
+  // is computed exactly as before.
+  {
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int tail = cus > 0 ? first % cus : 0;
+    const int steps = (int)ceil_div64(T, TR_TOK);
+    if (workspace && first > cus && tail > 0 && 2 * tail <= cus && inc_small_tiles_flag(-1) != 44) {
+      int nseg = cus / tail;
+      if (nseg > 4) nseg = 4;
+      if (nseg > steps / 16) nseg = steps / 16;  // a range is at least 16 steps long
+      if (nseg >= 2 && tail * nseg <= HESSIAN_TAIL_UNITS && workspace_bytes >= (int64_t)tail * nseg * H2 * H2 * 4 &&
+          (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+        a.full = first - tail;
+        a.nseg = nseg;
+        a.slab = (float*)workspace;
+      }
+    }
+  }
+  const int grid = a.full + (first - a.full) * a.nseg;
 #ifdef INC_KBENCH
   if (inc_small_tiles_flag(-1) == 45) {  // harness flag 45: the register-transposing generation
+    a.full = first; a.nseg = 1;
     const size_t smem2 = (size_t)2 * H2_STAGE * sizeof(uint16_t);  // 144 KiB
     const bool tail = (T % HK) != 0;
     (void)hipFuncSetAttribute((const void*)hessian_syrk_16bit_256_multi_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
@@ -1466,13 +1575,15 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
     }
 #ifdef INC_KBENCH
     if (inc_small_tiles_flag(-1) == 46 && xdtype == INC_BF16) {  // timing A/B: four 32-token stages
+      a.full = first; a.nseg = 1;
       (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_multi_kernel<true, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
       hessian_syrk_tr_256_multi_kernel<true, 32, 4><<<first, 512, smem3, s>>>(a, T);
       INC_LAUNCH_RETURN();
     }
 #endif
-    if (xdtype == INC_BF16) hessian_syrk_tr_256_multi_kernel<true><<<first, 512, smem3, s>>>(a, T);
-    else hessian_syrk_tr_256_multi_kernel<false><<<first, 512, smem3, s>>>(a, T);
+    if (xdtype == INC_BF16) hessian_syrk_tr_256_multi_kernel<true><<<grid, 512, smem3, s>>>(a, T);
+    else hessian_syrk_tr_256_multi_kernel<false><<<grid, 512, smem3, s>>>(a, T);
+    if (a.nseg > 1) hessian_tail_finalize_kernel<<<first - a.full, 512, 0, s>>>(a);
     INC_LAUNCH_RETURN();
   }
 }

@@ -425,6 +425,21 @@ def gptq_hessian_accum(H, x2d, beta, alpha):
     return H
 
 
+# INC_MI355X_HESSIAN_TAIL_SPLIT=0: every tile of the batched Hessian launch is one workgroup (the last round of a launch then runs on a
+# fraction of the CUs)
+HESSIAN_TAIL_SPLIT = __import__("os").environ.get("INC_MI355X_HESSIAN_TAIL_SPLIT", "1") == "1"
+_hessian_ws_cache = {}
+
+
+def _hessian_workspace(dev):
+    """Scratch of the batched Hessian launch's split tail: one per (device, stream), never shared by concurrent launches."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _hessian_ws_cache.get(key)
+    if buf is None:
+        buf = _hessian_ws_cache[key] = torch.empty(lib.inc_gptq_hessian_accum_multi_workspace_bytes(), dtype=torch.uint8, device=dev)
+    return buf
+
+
 def gptq_hessian_accum_multi(items):
     """One launch for several Hessians of the same forward: items = [(H [K,K] fp32, x2d [T,K] 16-bit, beta, alpha), ...],
     all x2d with the same dtype and token count.  Returns False (nothing launched) when the library declines the batch
@@ -447,8 +462,10 @@ def gptq_hessian_accum_multi(items):
     ld = (ctypes.c_int64 * n)(*[x.stride(0) for _, x, _, _ in items])
     be = (ctypes.c_float * n)(*[float(b) for _, _, b, _ in items])
     al = (ctypes.c_float * n)(*[float(a) for _, _, _, a in items])
+    ws = _hessian_workspace(dev) if HESSIAN_TAIL_SPLIT else None
     with torch.cuda.device(dev):
-        rc = lib.inc_gptq_hessian_accum_multi(n, xs, dtype_code(x0.dtype), T, Ks, ld, Hs, be, al, _stream())
+        rc = lib.inc_gptq_hessian_accum_multi(n, xs, dtype_code(x0.dtype), T, Ks, ld, Hs, be, al, _ptr(ws), 0 if ws is None else ws.numel(),
+                                              _stream())
     if rc == -2:  # INC_ERR_UNSUPPORTED: nothing was launched
         return False
     check(rc, "inc_gptq_hessian_accum_multi")

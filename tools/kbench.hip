@@ -677,22 +677,53 @@ static int run_hessian_multi_case(int64_t T) {
     flops += 2.0 * T * Ks[i] * Ks[i];
   }
   printf("HESSIAN multi T=%ld K=4096+4096+4096+11008 (one launch)\n", (long)T);
+  DevBuf<char> hws((size_t)inc_gptq_hessian_accum_multi_workspace_bytes());
+  int bad = 0;
+  {  // the split tail against the unsplit launch (harness flag 44): identical outside the tail tiles, fp32 rounding inside
+    std::vector<std::vector<float>> ref;
+    for (int pass = 0; pass < 2; ++pass) {
+      inc_debug_set_small_tiles(pass == 0 ? 44 : 0);
+      for (int i = 0; i < 4; ++i) Hs[i]->zero();
+      float b0[4] = {0.f, 0.f, 0.f, 0.f};
+      INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, b0, alphas, hws.p, (int64_t)hws.n, nullptr));
+      INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, hws.p, (int64_t)hws.n, nullptr));  // beta != 0 too
+      HIPCHECK(hipDeviceSynchronize());
+      for (int i = 0; i < 4; ++i) {
+        std::vector<float> h = Hs[i]->download();
+        if (pass == 0) { ref.push_back(h); continue; }
+        size_t ndiff = 0;
+        double worst = 0, norm = 0;
+        for (int64_t r = 0; r < Ks[i]; ++r)
+          for (int64_t c = r; c < Ks[i]; ++c) {  // (upper-triangular tiles are what the kernel writes; the strict lower part of a diagonal tile too)
+            const float a = h[r * Ks[i] + c], b = ref[i][r * Ks[i] + c];
+            if (memcmp(&a, &b, 4) != 0) { ++ndiff; worst = std::max(worst, (double)fabsf(a - b)); }
+            norm = std::max(norm, (double)fabsf(b));
+          }
+        const bool ok = worst <= 5e-6 * norm;
+        printf("  split tail vs one workgroup per tile, K=%ld: %zu elements differ, worst |diff| %.3g (largest |H| %.3g)  %s\n", (long)Ks[i], ndiff, worst,
+               norm, ok ? "OK" : "FAIL");
+        bad += ok ? 0 : 1;
+      }
+    }
+    inc_debug_set_small_tiles(0);
+  }
   Timer t;
-  const int modes[3] = {0, 46, 45};
-  const char* labels[3] = {"transpose-read 2x64", "transpose-read 4x32", "register transpose"};
-  for (int mi = 0; mi < 3; ++mi) {
+  const int nm = 4;
+  const int modes[nm] = {0, 44, 46, 45};
+  const char* labels[nm] = {"transpose-read 2x64", "  - tail split", "transpose-read 4x32", "register transpose"};
+  for (int mi = 0; mi < nm; ++mi) {
     inc_debug_set_small_tiles(modes[mi]);
-    for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, nullptr));
+    for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, hws.p, (int64_t)hws.n, nullptr));
     const int iters = 10;
     t.start();
-    for (int i = 0; i < iters; ++i) INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, nullptr));
+    for (int i = 0; i < iters; ++i) INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, hws.p, (int64_t)hws.n, nullptr));
     const float ms = t.stop_ms() / iters;
     printf("  %-28s %9.4f ms  %8.1f TFLOP/s (2*T*K^2 convention)\n", labels[mi], ms, flops / ms / 1e9);
   }
   inc_debug_set_small_tiles(0);
   for (auto* b : xs) delete b;
   for (auto* b : Hs) delete b;
-  return 0;
+  return bad;
 }
 
 // ---- GPTQ column loop: quad-per-row quant block + lazy update generations (3rd = default, 2nd = flag 86, 1st = flag 1) --------
