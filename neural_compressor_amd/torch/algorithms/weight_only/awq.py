@@ -570,12 +570,12 @@ class ActAwareWeightQuant:
     # -- batched evaluation for the grid searches ----------------------------------------------------------------------
     # The searches only compare losses, and a Linear (or a whole decoder block whose keyword arguments are the same for
     # every calibration batch) treats the rows of a stacked input independently, so the ~20 forwards per grid are run on
-    # stacks of `search_batch` calibration batches (INC_MI355X_AWQ_SEARCH_BATCH, default 16; 1 = the reference's
-    # one-batch-at-a-time loop): larger GEMMs, 16x fewer launches, same sums.  The activations handed to the next block
+    # stacks of `search_batch` calibration batches (INC_MI355X_AWQ_SEARCH_BATCH, default 32; 1 = the reference's
+    # one-batch-at-a-time loop): larger GEMMs, 32x fewer launches, same sums.  The activations handed to the next block
     # still come from the per-batch `block_inference`.
     @property
     def search_batch(self):
-        return max(1, int(os.environ.get("INC_MI355X_AWQ_SEARCH_BATCH", "16")))
+        return max(1, int(os.environ.get("INC_MI355X_AWQ_SEARCH_BATCH", "32")))
 
     def _stack(self, tensors):
         B = self.search_batch
