@@ -352,13 +352,14 @@ def bench_per_layer(device, cpu):
     torch.manual_seed(0)
     Hs = {}
     for K in (4096, 11008):
-        x = torch.randn(16384, K, device=device, dtype=torch.bfloat16)
+        TOK = G.HessianAccumulator.STAGE_TOKENS  # one launch of the driver: a stage of tokens (32 samples of 2048)
+        x = torch.randn(TOK, K, device=device, dtype=torch.bfloat16)
         H = torch.zeros(K, K, device=device)
         t = timed(lambda: ops.gptq_hessian_accum(H, x, 0.5, 0.5), reps=5, warm=2)
-        out[f"hessian_K{K}"] = dict(gpu_s_per_sample=round(t / 8, 6), cpu_s_per_sample=c(f"t_add_{K}"), tokens_per_launch=16384,
-                                    tflops=round(2.0 * 16384 * K * K / t / 1e12, 1), frac=round(2.0 * 16384 * K * K / t / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4))
+        out[f"hessian_K{K}"] = dict(gpu_s_per_sample=round(t / (TOK / 2048), 6), cpu_s_per_sample=c(f"t_add_{K}"), tokens_per_launch=TOK,
+                                    tflops=round(2.0 * TOK * K * K / t / 1e12, 1), frac=round(2.0 * TOK * K * K / t / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4))
         acc = G.HessianAccumulator(K, device)
-        acc.add_batch(x.view(8, 2048, K))
+        acc.add_batch(x.view(TOK // 2048, 2048, K))
         Hs[K] = acc
         del x, H
     for N, K in ((4096, 4096), (11008, 4096), (4096, 11008)):

@@ -298,7 +298,10 @@ class HessianAccumulator:
     on the math (profiles/r1_pmc).  The staging copy is immediate, so later in-place edits of the activation are harmless.
     """
 
-    STAGE_TOKENS = int(os.environ.get("INC_MI355X_HESSIAN_STAGE_TOKENS", "16384"))
+    # 65536: at 16384 tokens per launch a GPTQ step of the BASELINE shape was 5 % slower (318-324 vs 305 ms, A/B on one box): the
+    # read-modify-write of H and the launch's last partial round are paid a quarter as often, and the model's own forward runs
+    # larger GEMMs (see RAWGPTQuantizer._run_block, which stacks a stage's worth of calibration batches per forward)
+    STAGE_TOKENS = int(os.environ.get("INC_MI355X_HESSIAN_STAGE_TOKENS", "65536"))
     # an input that already holds a full stage of tokens (the driver's stacked forwards) is read in place instead of being
     # copied into the staging buffer -- once the accumulator has SEEN that the model leaves such an input alone: the first
     # eligible batch is still copied, and its version counter is compared when the update is launched (after the forward);
@@ -914,11 +917,11 @@ class RAWGPTQuantizer(object):
         """One forward of `block` over every cached calibration batch (reference :690-702 / :749-762).
 
         Cached batches that differ only in their hidden states (same shape, leading dimension 1, every other argument
-        the same tensor values) are stacked `forward_batch` at a time (INC_MI355X_GPTQ_FORWARD_BATCH, default 8; 1 = one
-        batch per forward as the reference does): a decoder block treats the rows of a stacked input independently, the
+        the same tensor values) are stacked `forward_batch` at a time (INC_MI355X_GPTQ_FORWARD_BATCH, default "auto" = one Hessian stage
+        of tokens, 32 batches of 2048 tokens; 1 = one batch per forward as the reference does): a decoder block treats the rows of a stacked input independently, the
         running-mean Hessian update is the same sum either way (`add_batch` counts the leading dimension, gptq.py:1117),
         and the per-batch outputs are handed on as slices.  What changes is the size of the GEMMs the model's own
-        forward runs (M = 16384 instead of 2048 at the BASELINE calibration shape) and 8x fewer elementwise launches."""
+        forward runs (M = 65536 instead of 2048 at the BASELINE calibration shape) and 32x fewer elementwise launches."""
         batch_num = self.cache_key_arguments.pop("batch_num")
         in_kwargs = "hidden_states" in self.cache_key_arguments
         for group in self._forward_groups(batch_num, in_kwargs, block):
@@ -987,7 +990,13 @@ class RAWGPTQuantizer(object):
         cached = getattr(self, "_fgroups", None)
         if cached is not None and cached[0] == batch_num:
             return cached[1]
-        fb = max(1, int(os.environ.get("INC_MI355X_GPTQ_FORWARD_BATCH", "8")))
+        fb_env = os.environ.get("INC_MI355X_GPTQ_FORWARD_BATCH", "auto")
+        if fb_env == "auto":  # as many batches as make one Hessian stage (65536 tokens: 32 samples of 2048 tokens), at most 64
+            h0 = (self.cache_key_arguments["hidden_states"] if in_kwargs else self.cache_positional_arguments[0])[0] if batch_num > 0 else None
+            tokens = int(h0.numel() // h0.shape[-1]) if isinstance(h0, torch.Tensor) and h0.dim() >= 2 else 0
+            fb = max(1, min(64, HessianAccumulator.STAGE_TOKENS // tokens)) if tokens > 0 else 8
+        else:
+            fb = max(1, int(fb_env))
 
         def same(a, b):
             if a is b:
