@@ -1030,7 +1030,17 @@ class RAWGPTQuantizer(object):
         if cur:
             groups.append(cur)
         multi = next((g for g in groups if len(g) > 1), None)
-        if multi is not None and block is not None and not self._stacking_is_faithful(block, multi, in_kwargs):
+        if multi is not None and block is not None:
+            # whether a block of this class treats the rows of a stacked input independently is decided once per run and group size
+            # (mode "layer" regroups every round: the check is two forwards of the group)
+            verdicts = self.__dict__.setdefault("_faithful_verdicts", {})
+            vkey = (type(block), len(multi))
+            if vkey not in verdicts:
+                verdicts[vkey] = self._stacking_is_faithful(block, multi, in_kwargs)
+            faithful = verdicts[vkey]
+        else:
+            faithful = True
+        if not faithful:
             logger.warning("GPTQ: a stacked forward of this block does not reproduce its per-batch outputs; "
                            "running one calibration batch per forward")
             groups = [[j] for j in range(batch_num)]
