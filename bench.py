@@ -648,15 +648,27 @@ def main():
         clock.enabled = True
         if layer_mode and os.environ.get("INC_MI355X_BENCH_ROUND_TIMING", "1" if world == 1 else "0") == "1":
             rq._layer_state["timing"] = round_timing  # device-synchronised phase times of every round (three extra syncs per round)
+        trace = os.environ.get("INC_MI355X_TRACE_RANGES", "0") == "1"  # phase markers for scripts/step_timeline.py
+        mem0 = torch.cuda.memory_stats(device)
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
+            if trace:
+                ops.trace_marker(1)
             step(i)
+        if trace:
+            ops.trace_marker(1)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
         clock.enabled = False
     note(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
+    mem1 = torch.cuda.memory_stats(device)
+    # caching-allocator activity inside the timed region: hipMalloc / hipFree calls reach the driver only through "segment" events
+    allocator = {k: int(mem1.get(v, 0) - mem0.get(v, 0)) for k, v in (("hipMalloc_calls", "num_device_alloc"), ("hipFree_calls", "num_device_free"),
+                                                                   ("alloc_retries", "num_alloc_retries"), ("block_allocations", "allocation.all.allocated"))}
+    allocator["reserved_GiB"] = round(mem1.get("reserved_bytes.all.current", 0) / 2**30, 2)
+    allocator["per"] = f"{args.steps} timed steps"
     elapsed = D.barrier_max_time(elapsed, device=device)
     ms_per_step = elapsed * 1e3 / args.steps
     # whole job = a 32-block model.  exact / single GPU: 32 steps (N ranks work on the SAME block); layer: ceil(32 / N) rounds
@@ -713,7 +725,7 @@ def main():
                                  f"ONE model on {world} ranks: samples sharded {world}-way, Hessians reduced to owner ranks + factor broadcast "
                                  "(RCCL), row-sharded column loop + all-gather; exact reference semantics"),
                     steps_per_model=steps_per_model),
-        roofline=roofline, kernel_breakdown=breakdown,
+        roofline=roofline, kernel_breakdown=breakdown, allocator=allocator,
     )
     if round_timing:
         result["layer_round_ms"] = {k.replace("_s", ""): round(v * 1e3 / args.steps, 2) for k, v in round_timing.items() if k != "_"}

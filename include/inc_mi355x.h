@@ -353,6 +353,9 @@ int inc_w8a8_gemm(const int8_t* xq, const int8_t* wq, const float* alpha, const 
  *   (>= 64 KiB, any non-zero data); *flops_out (host pointer, may be NULL) receives the flops of the launch.            */
 int inc_probe_hbm_triad(float* a, const float* b, const float* c, float s, int64_t n, inc_stream_t stream);
 int inc_probe_mfma_bf16(const void* src, float* sink, int blocks, int iters, double* flops_out, inc_stream_t stream);
+/* inc_trace_marker: an EMPTY launch of `id` (1..4096) workgroups of 64 threads on `stream`: a phase boundary that a
+ *   `rocprofv3 --kernel-trace` timeline shows as inc_trace_marker_kernel with Grid_Size_X = 64 * id (scripts/step_timeline.py). */
+int inc_trace_marker(int id, inc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -2039,7 +2039,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
         part = (float*)((char*)workspace + WS_COUNTER_BYTES);
       else { splits = 1; steps = (int)(K / TK); }
     }
-    static const int d2r_abl[10] = {0, 0, 4, 8, 12, 76, 128, 0, 0, 0};  // harness flags 90..96 (91: three x stages; 92..96 timing-only)
+    static const int d2r_abl[10] = {0, 0, 4, 8, 12, 76, 128, 0, 256, 0};  // harness flags 90..96 (91: three x stages; 92..96 timing-only), 98: time stamps
     const int abl = dbg >= 90 ? d2r_abl[dbg - 90] : 0;
 #ifdef INC_KBENCH
     // harness flag 97: the eight-wave form (gemm_d2r8.hip, two waves per SIMD with redundant dequantisation): bit-identical and 6 %

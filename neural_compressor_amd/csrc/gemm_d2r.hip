@@ -78,6 +78,33 @@ __device__ __forceinline__ void acc_zero() {
   static_for<0, 256>([&](auto R) { acc_zero<R.value>(); })
 #define INC_SB() __builtin_amdgcn_sched_barrier(0)
 
+#ifdef INC_KBENCH
+// harness build only (tools/kbench d2rtl, ABL bit 8 = 256): per-workgroup time stamps of wave 0 -- [0..3] s_memrealtime (100 MHz) at
+// entry / first K-step / after the K-loop / after the last store was acknowledged, [4..7] s_memtime (shader clock) at the same
+// points, [8] XCC id, [9] HW_ID
+__device__ unsigned long long* g_d2r_timeline = nullptr;
+#define INC_D2R_STAMP(SLOT)                                                                                   \
+  if constexpr ((ABL & 256) != 0) {                                                                            \
+    /* no divergent branch (it broke the scalar-register bookkeeping of the asm statements): EVERY thread stores, threads other  \
+       than 0 into a scratch area behind the records (the buffer holds 10 * workgroups + 256 words) */                           \
+    const unsigned long long rt_ = __builtin_amdgcn_s_memrealtime(), ct_ = __builtin_amdgcn_s_memtime();        \
+    unsigned xcc_, hw_;                                                                                         \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                         \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                           \
+    unsigned long long* const tl_ = g_d2r_timeline;                                                             \
+    const size_t rec_ = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 10, scratch_ = (size_t)gridDim.x * gridDim.y * 10 + threadIdx.x; \
+    const bool first_ = threadIdx.x == 0;                                                                       \
+    tl_[first_ ? rec_ + (SLOT) : scratch_] = rt_;                                                               \
+    tl_[first_ ? rec_ + 4 + (SLOT) : scratch_] = ct_;                                                           \
+    if ((SLOT) == 0) {                                                                                          \
+      tl_[first_ ? rec_ + 8 : scratch_] = xcc_ & 15u;                                                           \
+      tl_[first_ ? rec_ + 9 : scratch_] = hw_;                                                                  \
+    }                                                                                                           \
+  }
+#else
+#define INC_D2R_STAMP(SLOT)
+#endif
+
 // ABL (harness build only, timing-only, WRONG results): bit 2 no x LDS-DMA, 3 no W loads, 6 no per-step barrier, 7 no epilogue stores
 template <bool IS_BF16, int NS, int ABL>
 __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
@@ -85,6 +112,7 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int64_t M, int64_t N,
     int64_t K, int64_t NW, int g_shift, int y_vec_ok, float* __restrict__ partial, int steps_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  INC_D2R_STAMP(0)
   constexpr int D = NS - 1;                   // the x DMA runs D steps ahead
   constexpr int VM_STEADY = D >= 3 ? 22 : 14;  // see "counted waits" below
   const int tiles_n = (int)((N + TN - 1) / TN);
@@ -447,6 +475,7 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     rd_off = rd_nxt;                                                                                                              \
     INC_SB();                                                                                                                     \
   }
+  INC_D2R_STAMP(1)
   for (int t0 = 0; t0 < nk; t0 += 3) {
     INC_D2R_STEP(0)
     if (t0 + 1 >= nk) break;
@@ -465,6 +494,7 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
 #undef INC_PIN1
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results: nothing the compiler emits may read them early
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail requests
+  INC_D2R_STAMP(2)
   if constexpr ((ABL & 128) != 0) return;
 
   // ---- epilogue.  Accumulator j = 8 nf + mf, register r = 4 rq + e of it: D row i = e + 8 rq + 4 (lane >> 5), column (m) = lane & 31;
@@ -502,6 +532,8 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
       const u32x4 vv = {v.x, v.y, v.z, v.w};
       asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ytile + (int64_t)row * N + c * 8), "v"(vv) : "memory");
     }
+    if constexpr ((ABL & 256) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    INC_D2R_STAMP(3)
     return;
   }
   float* const slab = partial ? partial + (int64_t)blockIdx.y * M * N : nullptr;  // split-K: raw fp32 tile into this split's slab
@@ -544,10 +576,19 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
       }
     });
   });
+  if constexpr ((ABL & 256) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  INC_D2R_STAMP(3)
 }
 #undef INC_SB
 
 }  // namespace
+
+#ifdef INC_KBENCH
+extern "C" int inc_debug_set_d2r_timeline(void* dev_buffer) {  // harness only: where ABL 256 writes (10 x u64 per workgroup)
+  unsigned long long* p = (unsigned long long*)dev_buffer;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_d2r_timeline), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 // Launcher used by inc_woq_gemm (gemm.hip).  `abl` selects a timing-only ablation in the harness build (0 in the product).
 int inc_launch_woq_gemm_d2r(const uint16_t* x, const uint32_t* qw, const uint16_t* scales, const uint32_t* qz, const uint16_t* bias,
@@ -575,6 +616,7 @@ int inc_launch_woq_gemm_d2r(const uint16_t* x, const uint32_t* qw, const uint16_
   else if (abl == 12) INC_D2R(true, 4, 12)   /* no global traffic */
   else if (abl == 76) INC_D2R(true, 4, 76)   /* no global traffic, no barrier */
   else if (abl == 128) INC_D2R(true, 4, 128) /* no epilogue stores */
+  else if (abl == 256) INC_D2R(true, 4, 256) /* per-workgroup time stamps */
 #endif
   else INC_D2R(true, 4, 0)
 #undef INC_D2R

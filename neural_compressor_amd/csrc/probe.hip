@@ -44,9 +44,19 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(const uint4* __restrict
   if (s == 12345.678f) sink[blockIdx.x * 256 + threadIdx.x] = s + lane;  // keeps the MFMAs alive, (almost) never stores
 }
 
+// empty kernel whose GRID SIZE is the message: rocprofv3 --kernel-trace lists Grid_Size_X = 64 * id for it, on the stream it was launched on
+__global__ __launch_bounds__(64) void inc_trace_marker_kernel() {}
+
 }  // namespace
 
 extern "C" {
+
+// phase marker for kernel-trace timelines (scripts/step_timeline.py): an empty launch of `id` workgroups of 64 threads on `stream`
+int inc_trace_marker(int id, inc_stream_t stream) {
+  INC_CHECK_ARG(id > 0 && id <= 4096);
+  inc_trace_marker_kernel<<<id, 64, 0, inc_s(stream)>>>();
+  INC_LAUNCH_RETURN();
+}
 
 // a <- b + s * c on n fp32 elements (n % 4 == 0, 16-byte aligned): HBM traffic 12 n bytes
 int inc_probe_hbm_triad(float* a, const float* b, const float* c, float s, int64_t n, inc_stream_t stream) {

@@ -585,6 +585,12 @@ def probe_mfma_bf16(src, sink, blocks, iters):
     return flops.value
 
 
+def trace_marker(marker_id, device=None):
+    """Phase boundary for kernel-trace timelines: an empty launch with Grid_Size_X = 64 * marker_id on the current stream."""
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(lib.inc_trace_marker(int(marker_id), _stream()), "inc_trace_marker")
+
+
 GPTQ_DYNAMIC_GROUPS, GPTQ_MSE, GPTQ_NO_LOOKAHEAD, GPTQ_NO_FUSED_PARAMS = 1, 2, 4, 8
 
 

@@ -101,11 +101,42 @@ _LOOKAHEAD_STREAMS = {}
 
 
 ONE_CALL = os.environ.get("INC_MI355X_GPTQ_ONE_CALL", "1") != "0"  # the column loop through inc_gptq_quantize_layer
+# The solve of the block's LAST Linear(s) in forward order (Llama: down_proj, whose K = 11008 factorisation is the critical path of
+# the solve phase) runs on a stream of its own and the second forward starts without it: a pre-hook on those modules makes the
+# forward's stream wait for the solve when it gets there (attention + gate / up run underneath the factorisation).  Same launches,
+# same operands: bit-identical results.  INC_MI355X_GPTQ_LATE_SOLVE=0 keeps every solve in front of the second forward.
+LATE_SOLVE = os.environ.get("INC_MI355X_GPTQ_LATE_SOLVE", "1") == "1"
+_TRACE_RANGES = os.environ.get("INC_MI355X_TRACE_RANGES", "0") == "1"  # roctx ranges around the phases of a block (scripts/step_timeline.py)
+
+
+PHASE_IDS = {"gptq.capture_forward": 2, "gptq.solve_issue": 3, "gptq.second_forward": 4, "gptq.solve_wait": 5, "gptq.pack": 6}
+
+
+class _phase:
+    """One phase of quantize_block for a kernel-trace timeline (scripts/step_timeline.py): a roctx range on the host side and an
+    inc_trace_marker launch (Grid_Size_X = 64 * (2 * id) at the start, 64 * (2 * id + 1) at the end) on the current stream; free
+    when INC_MI355X_TRACE_RANGES is unset."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _TRACE_RANGES:
+            torch.cuda.nvtx.range_push(self.name)
+            ops.trace_marker(2 * PHASE_IDS[self.name])
+
+    def __exit__(self, *exc):
+        if _TRACE_RANGES:
+            ops.trace_marker(2 * PHASE_IDS[self.name] + 1)
+            torch.cuda.nvtx.range_pop()
+        return False
 
 
 def _lookahead_stream(device):
-    """Second stream of the column loop (one per device, created on first use)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Second stream of the column loop: one per (device, calling stream), so that solves issued on different streams (the late
+    solve below) do not serialise on a shared one."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     st = _LOOKAHEAD_STREAMS.get(key)
     if st is None:
         st = _LOOKAHEAD_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -767,6 +798,7 @@ class RAWGPTQuantizer(object):
         self.share_hessians = kwargs.get("share_hessians", True)
         self.factor_streams = int(os.environ.get("INC_MI355X_GPTQ_FACTOR_STREAMS", "4"))
         self._fstreams = []
+        self._late_stream = None  # stream of the block's last solve (LATE_SOLVE)
         self._block_writes_input = None  # decided by the first block forward (see _run_block)
         self._stacks = {}  # first batch index of a forward group -> (stacked hidden states, the list entries that are its slices)
         self.block_callback = kwargs.get("block_callback", None)  # used by the multi-GPU driver
@@ -1488,8 +1520,9 @@ class RAWGPTQuantizer(object):
                     if CAPTURE_EARLY_STOP and len(fired) == len(layers) and set(fired) == set(layers):
                         capture["stop"] = fired[-1]
 
-            self._run_block(block, on_output=after_forward, capture=True)
-            HessianAccumulator.flush_many(accs)
+            with _phase("gptq.capture_forward"):
+                self._run_block(block, on_output=after_forward, capture=True)
+                HessianAccumulator.flush_many(accs)
             for acc in accs:
                 acc.defer = False
             for h in handles:
@@ -1544,7 +1577,18 @@ class RAWGPTQuantizer(object):
                     if key is not None:
                         index[key] = len(batches)
                     batches.append([name])
-            for names in batches:
+            # The batch whose Linears run LAST in the block's forward (known from the probe forward of the capture pass) is solved
+            # on `self._late_stream`; the second forward below starts without it (see LATE_SOLVE).
+            late = None
+            if (LATE_SOLVE and propagate and self.dist_ctx is None and len(batches) > 1 and len(fired) == len(layers)
+                    and set(fired) == set(layers) and torch.cuda.is_available()):
+                tail = next(names for names in batches if fired[-1] in names)
+                if set(tail) == set(fired[len(fired) - len(tail):]):
+                    late = tail
+            late_event = None
+            main = torch.cuda.current_stream(self.device) if late is not None else None
+
+            def solve(names):
                 sv = solvers[names[0]]
                 cfg = sv.cfg
                 if len(names) == 1:
@@ -1568,11 +1612,35 @@ class RAWGPTQuantizer(object):
                                       zero=None if cfg["sym"] else (zp if one else zp[sl].contiguous()), perm=perm,
                                       codes=codes if one else codes[sl].contiguous())
                     solvers[n].perm = perm
-            for acc, _, _ in distinct:
-                acc.check()  # deferred "not positive definite" checks of this group's factorisations (one sync each)
-            for n in list(solvers):
-                solvers[n].free()
-            del solvers, distinct
+
+            with _phase("gptq.solve_issue"):
+                if late is not None:
+                    # issued FIRST (its factorisation is the longest chain), on its own stream; everything it allocates there and
+                    # that the main stream reads later (the new weight, codes, scales) is handed over with record_stream
+                    if self._late_stream is None:
+                        self._late_stream = torch.cuda.Stream(device=self.device)
+                    self._late_stream.wait_stream(main)
+                    with torch.cuda.stream(self._late_stream):
+                        solve(late)
+                        late_event = self._late_stream.record_event()
+                    for n in late:
+                        for t in (layers[n].weight.data, results[n]["scale"], results[n]["zero"], results[n]["codes"], results[n]["perm"]):
+                            if isinstance(t, torch.Tensor):
+                                t.record_stream(main)
+                for names in batches:
+                    if names is not late:
+                        solve(names)
+
+            def finish_solves():
+                for acc, _, _ in distinct:
+                    acc.check()  # deferred "not positive definite" checks of this group's factorisations (one sync each)
+                for n in list(solvers):
+                    solvers[n].free()
+
+            if late is None:
+                with _phase("gptq.solve_wait"):
+                    finish_solves()
+                del solvers, distinct
             # Step 2.5: outputs of the quantised block become the next block's inputs (reference :749-762)
             def replace(j, out):
                 if "hidden_states" in self.cache_key_arguments:
@@ -1581,8 +1649,24 @@ class RAWGPTQuantizer(object):
                     self.cache_positional_arguments[0][j] = out
 
             if propagate:
-                self._run_block(block, on_output=replace)
+                gates = []
+                if late is not None:
+                    def gate(_, inp):  # the forward's stream waits for the late solve where it first needs its weight
+                        torch.cuda.current_stream(self.device).wait_event(late_event)
+
+                    gates = [layers[n].register_forward_pre_hook(gate) for n in late]
+                with _phase("gptq.second_forward"):
+                    self._run_block(block, on_output=replace)
+                for h in gates:
+                    h.remove()
+            if late is not None:
+                main.wait_event(late_event)  # (a block whose forward never reached those modules)
+                with _phase("gptq.solve_wait"):
+                    finish_solves()
+                del solvers, distinct
             # Step 2.6: export to the packed module (reference :769-849) -- on device, from the emitted codes
+            pack_phase = _phase("gptq.pack")
+            pack_phase.__enter__()
             for name, layer in layers.items():
                 cfg = self.get_layer_config(self.get_full_layer_name(name, block_idx))
                 r = results[name]
@@ -1596,6 +1680,7 @@ class RAWGPTQuantizer(object):
                 )
                 new_module.pack_codes(r["codes"], r["scale"], r["zero"], layer.bias, g_idx=r["perm"])
                 set_module(block, name, new_module)
+            pack_phase.__exit__()
             del results
 
 

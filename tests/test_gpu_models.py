@@ -405,6 +405,73 @@ def test_gptq_prepare_convert_equals_quantize():
         assert torch.equal(ma[n].scales, mb[n].scales), n
 
 
+def test_2x_fit_gptq_equals_prepare_convert():
+    """north_star's drop-in surface: `quantization.fit(model, PostTrainingQuantConfig(... GPTQ ...), calib_dataloader=...)` runs end to
+    end on the GPU and produces the packed buffers of the 3.x route (reference successor: quantize.py:253 prepare / convert;
+    test/torch/quantization/weight_only/test_gptq.py:82-104 compares the routes the same way).  RTN through the same entry point too."""
+    from neural_compressor_amd import quantization
+    from neural_compressor_amd.config import PostTrainingQuantConfig
+    from neural_compressor_amd.torch.quantization import GPTQConfig, RTNConfig, convert, prepare
+
+    ids = calib_ids()
+    conf = PostTrainingQuantConfig(
+        approach="weight_only",
+        op_type_dict={".*": {"weight": {"bits": 4, "group_size": 32, "scheme": "sym", "algorithm": "GPTQ"}}},
+        op_name_dict={".*lm_head": {"weight": {"dtype": "fp32"}}},
+        recipes={"gptq_args": {"percdamp": 0.01, "block_size": 128}},
+    )
+    q = quantization.fit(tiny_llama(), conf, calib_dataloader=[(x, 0) for x in ids])  # (inputs, label) pairs as 2.x dataloaders yield
+    a = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, use_sym=True, block_size=128, percdamp=0.01))
+    for x in ids:
+        a(x)
+    a = convert(a)
+    mq, ma = _woq_modules(q), _woq_modules(a)
+    assert mq.keys() == ma.keys() and len(mq) == 14 and not any("lm_head" in n for n in mq)
+    for n in mq:
+        assert torch.equal(mq[n].qweight, ma[n].qweight), n
+        assert torch.equal(mq[n].scales, ma[n].scales), n
+        assert torch.equal(mq[n].qzeros, ma[n].qzeros), n
+    with torch.no_grad():
+        assert torch.equal(q(ids[0].to("cuda")).logits, a(ids[0].to("cuda")).logits)
+    # calib_func instead of a dataloader, and the RTN default entry (no calibration)
+    q2 = quantization.fit(tiny_llama(), conf, calib_func=lambda m: [m(x) for x in ids])
+    for n, m in _woq_modules(q2).items():
+        assert torch.equal(m.qweight, ma[n].qweight), n
+    r = quantization.fit(tiny_llama(), PostTrainingQuantConfig(
+        op_type_dict={".*": {"weight": {"bits": 4, "group_size": 32, "scheme": "asym", "algorithm": "RTN"}}}))
+    from neural_compressor_amd.torch.quantization import quantize
+    r3 = quantize(tiny_llama(), RTNConfig(bits=4, group_size=32, use_sym=False))
+    mr, m3 = _woq_modules(r), _woq_modules(r3)
+    assert mr.keys() == m3.keys() and len(mr) > 0
+    for n in mr:
+        assert torch.equal(mr[n].qweight, m3[n].qweight) and torch.equal(mr[n].qzeros, m3[n].qzeros), n
+
+
+def test_gptq_late_solve_is_bit_identical(monkeypatch):
+    """The block's last solve on its own stream underneath the second forward (gptq.LATE_SOLVE): the same launches on the same
+    operands, only scheduled differently -- packed buffers and outputs identical to the in-order schedule."""
+    from neural_compressor_amd.torch.algorithms.weight_only import gptq as G
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    ids = calib_ids()
+
+    def run(late):
+        monkeypatch.setattr(G, "LATE_SOLVE", late)
+        m = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, use_sym=False, block_size=128))
+        for x in ids:
+            m(x)
+        m = convert(m)
+        with torch.no_grad():
+            return _woq_modules(m), m(ids[0].to("cuda")).logits
+
+    (ma, ya), (mb, yb) = run(True), run(False)
+    assert ma.keys() == mb.keys()
+    for n in ma:
+        assert torch.equal(ma[n].qweight, mb[n].qweight), n
+        assert torch.equal(ma[n].scales, mb[n].scales) and torch.equal(ma[n].qzeros, mb[n].qzeros), n
+    assert torch.equal(ya, yb)
+
+
 def test_gptq_quant_lm_head_matches_oracle_on_last_block_outputs():
     """GPTQConfig(quant_lm_head=True): step 2.7 of the reference (gptq.py:887-1080) calibrates lm_head on the last
     block's cached outputs.  (Run through prepare/convert the reference itself iterates an EMPTY dataloader there

@@ -327,6 +327,80 @@ static int run_d2r_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool 
   return fails;
 }
 
+
+// ---- per-workgroup timeline of the direct-to-register dequant-GEMM (harness flag 98): where the kernel's span goes ----
+extern "C" int inc_debug_set_d2r_timeline(void* dev_buffer);
+static void run_d2r_timeline(int64_t M, int64_t N, int64_t K) {
+  Packed W(N, K, 128, true);
+  DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
+  {
+    std::vector<uint16_t> hx(x.n);
+    for (auto& v : hx) v = f2bf(rnd_normal());
+    x.upload(hx);
+  }
+  const int64_t nwg = ((M + 255) / 256) * ((N + 255) / 256);
+  DevBuf<unsigned long long> tl((size_t)nwg * 10 + 256);
+  tl.zero();
+  inc_debug_set_d2r_timeline(tl.p);
+  inc_debug_set_small_tiles(90);
+  for (int i = 0; i < 6; ++i)  // warm clocks with the plain kernel
+    INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+  inc_debug_set_small_tiles(98);
+  Timer t;
+  for (int i = 0; i < 3; ++i)
+    INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+  t.start();
+  INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
+  const float ev_ms = t.stop_ms();
+  HIPCHECK(hipDeviceSynchronize());
+  inc_debug_set_small_tiles(0);
+  inc_debug_set_d2r_timeline(nullptr);
+  std::vector<unsigned long long> h = tl.download();
+  const double tick_us = 0.01;  // s_memrealtime: 100 MHz
+  unsigned long long t_first = ~0ull, t_last = 0;
+  for (int64_t w = 0; w < nwg; ++w) {
+    t_first = std::min(t_first, h[w * 10 + 0]);
+    t_last = std::max(t_last, h[w * 10 + 3]);
+  }
+  std::vector<double> start, pro, loop, epi, endgap, cyc_step, mhz;
+  double xcd_loop[8] = {0}, xcd_end[8] = {0};
+  int xcd_n[8] = {0};
+  const int nk = (int)(K / 64);
+  for (int64_t w = 0; w < nwg; ++w) {
+    const unsigned long long* e = &h[w * 10];
+    start.push_back((e[0] - t_first) * tick_us);
+    pro.push_back((e[1] - e[0]) * tick_us);
+    loop.push_back((e[2] - e[1]) * tick_us);
+    epi.push_back((e[3] - e[2]) * tick_us);
+    endgap.push_back((t_last - e[3]) * tick_us);
+    cyc_step.push_back((double)(e[6] - e[5]) / nk);
+    mhz.push_back((double)(e[6] - e[5]) / ((e[2] - e[1]) * tick_us));
+    const int xc = (int)(e[8] & 7);
+    xcd_loop[xc] += (e[2] - e[1]) * tick_us;
+    xcd_end[xc] += (e[3] - t_first) * tick_us;
+    ++xcd_n[xc];
+  }
+  auto stats = [](std::vector<double> v, const char* label, const char* unit) {
+    std::sort(v.begin(), v.end());
+    double sum = 0;
+    for (double a : v) sum += a;
+    printf("    %-34s mean %9.2f  min %9.2f  p10 %9.2f  p50 %9.2f  p90 %9.2f  max %9.2f %s\n", label, sum / v.size(), v.front(), v[v.size() / 10], v[v.size() / 2],
+           v[v.size() * 9 / 10], v.back(), unit);
+  };
+  printf("D2R TIMELINE M=%ld N=%ld K=%ld: %ld workgroups (%.2f per CU), %d K-steps; HIP-event time %.1f us, first entry -> last store acknowledged %.1f us\n", (long)M,
+         (long)N, (long)K, (long)nwg, nwg / 256.0, nk, ev_ms * 1e3, (t_last - t_first) * tick_us);
+  stats(start, "entry after the first entry", "us");
+  stats(pro, "prologue (entry -> first K-step)", "us");
+  stats(loop, "K-loop", "us");
+  stats(epi, "epilogue (-> stores acknowledged)", "us");
+  stats(endgap, "finished before the last one by", "us");
+  stats(cyc_step, "shader cycles per K-step", "cycles (2048 = MFMA-bound)");
+  stats(mhz, "shader clock inside the K-loop", "MHz");
+  printf("    per XCD (mean K-loop us / mean end time us / workgroups):");
+  for (int i = 0; i < 8; ++i) printf("  %d: %.1f / %.1f / %d", i, xcd_n[i] ? xcd_loop[i] / xcd_n[i] : 0.0, xcd_n[i] ? xcd_end[i] / xcd_n[i] : 0.0, xcd_n[i]);
+  printf("\n");
+}
+
 // ---- mid-M strip kernel vs the 256-row tile + split-K path: checked against the fp32 reference rows, then timed --------
 static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool with_bias, bool time_it) {
   Packed W(N, K, gs, sym);
@@ -942,6 +1016,12 @@ int main(int argc, char** argv) {
     fails += run_d2r_case(4096, 11008, 4096, 128, true, false, true, false);
     fails += run_d2r_case(4096, 4096, 11008, 128, true, false, true, false);
     fails += run_d2r_case(8192, 4096, 4096, 128, false, true, true, false);
+  }
+  if (what == "d2rtl") {
+    run_d2r_timeline(4096, 4096, 4096);
+    run_d2r_timeline(4096, 4096, 11008);
+    run_d2r_timeline(8192, 4096, 4096);
+    run_d2r_timeline(4096, 11008, 4096);
   }
   if (what == "gemm" || what == "all") {
     fails += run_gemm_case(256, 256, 64, 32, false, true, false, 64);     // one tile, one K-step, gs=32 asym
