@@ -74,6 +74,8 @@ SIGNATURES = {
     "inc_gptq_quantize_layer": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int, _P, c_int64, c_int64, c_int, c_int, c_int,
                                         c_int, c_int, c_int, _P, _P]),
     "inc_chol_diag_block": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, c_int, _P]),
+    "inc_gptq_inverse_factor_workspace_bytes": (c_int64, [c_int64]),
+    "inc_gptq_inverse_factor": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int, _P, _P]),
     "inc_awq_act_abs_sum": (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),
     "inc_awq_weight_scale_workspace_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "inc_awq_weight_scale": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, _P, c_int64, _P]),

@@ -224,19 +224,24 @@ __global__ __launch_bounds__(256) void chol_diag_block_kernel(float* __restrict_
 
 }  // namespace
 
-extern "C" {
-
-int inc_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, int32_t* info, int tag,
-                        inc_stream_t stream) {
-  INC_CHECK_ARG(A && Linv && n > 0 && n <= CB && lda >= n && ldi >= n);
+// launcher shared with ifac.hip (inc_gptq_inverse_factor issues one of these per 128 columns)
+int inc_launch_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, int32_t* info, int tag, hipStream_t s) {
   const size_t smem = (size_t)(2 * CB * CP + CB * 8 + 64) * sizeof(float);
   static std::atomic<uint64_t> attr_set{0};
   if (inc_attr_needed(attr_set)) {
     (void)hipFuncSetAttribute((const void*)chol_diag_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     inc_attr_done(attr_set);
   }
-  chol_diag_block_kernel<<<1, 256, smem, inc_s(stream)>>>(A, lda, n, Linv, ldi, info, tag);
+  chol_diag_block_kernel<<<1, 256, smem, s>>>(A, lda, n, Linv, ldi, info, tag);
   INC_LAUNCH_RETURN();
+}
+
+extern "C" {
+
+int inc_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, int32_t* info, int tag,
+                        inc_stream_t stream) {
+  INC_CHECK_ARG(A && Linv && n > 0 && n <= CB && lda >= n && ldi >= n);
+  return inc_launch_chol_diag_block(A, lda, n, Linv, ldi, info, tag, inc_s(stream));
 }
 
 }  // extern "C"

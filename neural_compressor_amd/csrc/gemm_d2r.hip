@@ -584,6 +584,8 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
 }  // namespace
 
 #ifdef INC_KBENCH
+int g_d2r_abl_override = 0;  // harness flag 98: which time-stamped instantiation runs (256 | ablation bits)
+extern "C" void inc_debug_set_d2r_abl(int abl) { g_d2r_abl_override = abl; }
 extern "C" int inc_debug_set_d2r_timeline(void* dev_buffer) {  // harness only: where ABL 256 writes (10 x u64 per workgroup)
   unsigned long long* p = (unsigned long long*)dev_buffer;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_d2r_timeline), &p, sizeof(p)) == hipSuccess ? 0 : -3;
@@ -596,6 +598,9 @@ int inc_launch_woq_gemm_d2r(const uint16_t* x, const uint32_t* qw, const uint16_
                             int splits, bool bf, int ns, int abl, hipStream_t s) {
   const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
   dim3 g2(grid, (unsigned)splits);
+#ifdef INC_KBENCH
+  if (abl == 256 && g_d2r_abl_override) abl = g_d2r_abl_override;
+#endif
 #define INC_D2R(B, NS_, A)                                                                                                             \
   {                                                                                                                                    \
     constexpr int smem = d2r_smem_bytes<NS_>();                                                                                        \
@@ -617,6 +622,11 @@ int inc_launch_woq_gemm_d2r(const uint16_t* x, const uint32_t* qw, const uint16_
   else if (abl == 76) INC_D2R(true, 4, 76)   /* no global traffic, no barrier */
   else if (abl == 128) INC_D2R(true, 4, 128) /* no epilogue stores */
   else if (abl == 256) INC_D2R(true, 4, 256) /* per-workgroup time stamps */
+  else if (abl == 260) INC_D2R(true, 4, 260) /* ... of the timing-only ablations */
+  else if (abl == 264) INC_D2R(true, 4, 264)
+  else if (abl == 268) INC_D2R(true, 4, 268)
+  else if (abl == 332) INC_D2R(true, 4, 332)
+  else if (abl == 320) INC_D2R(true, 4, 320) /* no barrier only */
 #endif
   else INC_D2R(true, 4, 0)
 #undef INC_D2R

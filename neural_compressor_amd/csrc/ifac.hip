@@ -1,0 +1,348 @@
+// ifac.hip -- K6': the whole "inverse Cholesky factor" of GPTQ behind ONE C-ABI call (inc_gptq_inverse_factor).
+//
+// Reference (neural_compressor/torch/algorithms/weight_only/gptq.py:1228-1231):
+//     H = torch.linalg.cholesky(H); H = torch.cholesky_inverse(H); H = torch.linalg.cholesky(H, upper=True); Hinv = H
+// i.e. the upper Cholesky factor U of H^-1 (H^-1 = U^T U).  With J the index reversal,
+//     J H J = L L^T (lower Cholesky of the index-reversed matrix)   =>   U = J L^-1 J,
+// so ONE blocked Cholesky and ONE blocked triangular inverse replace the three LAPACK factorisations (half the flops, one
+// rounding pass; at least as close to the fp64 result as the fp32 trio -- tests/test_gpu_parity.py).  Round 1-3 ran the blocked
+// algorithm from Python with torch.mm for every product; this file owns all of it:
+//   * f32gemm_kernel        exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: fmaf-chain semantics), NT and NN forms,
+//                           triangular operands skipped by K-range per tile, lower-triangle-only outputs (syrk), batched pairs
+//   * chol_diag_block_kernel (chol.hip) the 128 x 128 diagonal block: factor + inverse of the factor in one workgroup
+//   * ifac_flip_* / ifac_copy_panel: index reversal in / out, panel write-back
+//   * the host side below issues them on the caller's stream (+ an optional second stream for the look-ahead over outer blocks)
+// Two-level blocking (128 inside IFAC_OUTER columns), only the LOWER triangle of the working copy is read or kept up to date.
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+int inc_launch_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, int32_t* info, int tag, hipStream_t s);  // chol.hip
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int IFAC_NB = 128;      // leaf (diagonal block) edge
+constexpr int IFAC_OUTER = 1024;  // outer block of the two-level factorisation
+constexpr int BK = 16;            // k per LDS stage
+
+enum { KR_FULL = 0, KR_B_LOWER_NT = 1, KR_B_LOWER_NN = 2, KR_A_LOWER = 3 };
+
+struct GemmArgs {
+  const float* A;  // A(m, k) = A[m * lda + k]
+  const float* B;  // NT: B(k, n) = B[n * ldb + k];  NN: B(k, n) = B[k * ldb + n]
+  float* C;        // C(m, n) = C[m * ldc + n]
+  int64_t lda, ldb, ldc;
+  int64_t sA, sB, sC;  // element strides between the members of a batch (blockIdx.y)
+  int M, N, K;
+  float alpha, beta;
+  int krange;      // which K-range a tile needs (triangular operands): see tile_k_range
+  int lower_only;  // square C: only tiles that touch the lower triangle (tile column start <= tile row end)
+};
+
+// C = beta C + alpha A B on the fp32 matrix cores.  Workgroup = 4 waves as 2 x 2, wave tile (TM/2) x (TN/2) = MI x NI MFMA tiles of
+// 32 x 32; operands staged k-major in LDS (As[k][m], Bs[k][n]: the fragment of v_mfma_f32_32x32x2_f32 is lane -> (row or column
+// = lane & 31, k = lane >> 5), i.e. two consecutive 128-byte LDS rows: conflict-free ds_read_b32), two stages, register prefetch.
+// The fp32 MFMA runs at 1/16 of the bf16 rate (256 flop / clk / CU): 16 KiB of operands per 2048 MFMA cycles -- every other
+// cost is small beside it, which is why the loaders are simple.
+template <int TM, int TN, bool B_NT>
+__global__ __launch_bounds__(256) void f32gemm_kernel(GemmArgs g) {
+  constexpr int MI = TM / 64, NI = TN / 64;
+  constexpr int PA = TM + 4, PB = TN + 4;  // LDS pitches (floats): +4 keeps the two k rows of a fragment on different banks
+  __shared__ __attribute__((aligned(16))) float As[2][BK * PA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.N + TN - 1) / TN;
+  int ti, tj;
+  if (g.lower_only) {  // linear index over the lower triangle of tiles (TM == TN): ti (ti + 1) / 2 + tj
+    const int t = blockIdx.x;
+    ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    tj = t - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x / tiles_n;
+    tj = blockIdx.x - ti * tiles_n;
+  }
+  const int m0 = ti * TM, n0 = tj * TN;
+  int k_lo = 0, k_hi = g.K;
+  if (g.krange == KR_B_LOWER_NT) k_hi = min(g.K, n0 + TN);       // B[n, k] = 0 for k > n
+  else if (g.krange == KR_B_LOWER_NN) k_lo = min(n0, g.K);       // B[k, n] = 0 for k < n
+  else if (g.krange == KR_A_LOWER) k_hi = min(g.K, m0 + TM);     // A[m, k] = 0 for k > m
+  k_lo &= ~(BK - 1);
+  const float* __restrict__ A = g.A + (int64_t)blockIdx.y * g.sA;
+  const float* __restrict__ B = g.B + (int64_t)blockIdx.y * g.sB;
+  float* __restrict__ C = g.C + (int64_t)blockIdx.y * g.sC;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- loaders: global -> registers (next stage) -> LDS --------------------------------------------------------------------
+  constexpr int NA = TM / 64;  // float4 per thread of the A tile (TM rows x 16 k)
+  constexpr int NB_ = TN / 64;
+  float4 ra[NA], rb[NB_];
+  auto load_a = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 2, c4 = idx & 3;
+      const int m = m0 + row;
+      ra[i] = (m < g.M && k0 + 4 * c4 < g.K) ? *reinterpret_cast<const float4*>(A + (int64_t)m * g.lda + k0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 2, c4 = idx & 3;
+      float* d = &As[buf][(4 * c4) * PA + row];
+      d[0] = ra[i].x; d[PA] = ra[i].y; d[2 * PA] = ra[i].z; d[3 * PA] = ra[i].w;
+    }
+  };
+  auto load_b = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NB_; ++i) {
+      const int idx = tid + 256 * i;
+      if constexpr (B_NT) {
+        const int row = idx >> 2, c4 = idx & 3, n = n0 + row;
+        rb[i] = (n < g.N && k0 + 4 * c4 < g.K) ? *reinterpret_cast<const float4*>(B + (int64_t)n * g.ldb + k0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const int k = idx / (TN / 4), n4 = idx - k * (TN / 4), n = n0 + 4 * n4;
+        rb[i] = (n < g.N && k0 + k < g.K) ? *reinterpret_cast<const float4*>(B + (int64_t)(k0 + k) * g.ldb + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NB_; ++i) {
+      const int idx = tid + 256 * i;
+      if constexpr (B_NT) {
+        const int row = idx >> 2, c4 = idx & 3;
+        float* d = &Bs[buf][(4 * c4) * PB + row];
+        d[0] = rb[i].x; d[PB] = rb[i].y; d[2 * PB] = rb[i].z; d[3 * PB] = rb[i].w;
+      } else {
+        const int k = idx / (TN / 4), n4 = idx - k * (TN / 4);
+        *reinterpret_cast<float4*>(&Bs[buf][k * PB + 4 * n4]) = rb[i];
+      }
+    }
+  };
+
+  const int nsteps = (k_hi - k_lo + BK - 1) / BK;
+  if (nsteps > 0) {
+    load_a(k_lo);
+    load_b(k_lo);
+    store_a(0);
+    store_b(0);
+  }
+  __syncthreads();
+  const int fa = (lane >> 5) * PA + wm * (TM / 2) + (lane & 31);
+  const int fb = (lane >> 5) * PB + wn * (TN / 2) + (lane & 31);
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) {
+      load_a(k_lo + (s + 1) * BK);
+      load_b(k_lo + (s + 1) * BK);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = As[buf][2 * kk * PA + fa + 32 * i];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = Bs[buf][2 * kk * PB + fb + 32 * j];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) {
+      store_a(buf ^ 1);  // the other stage: its last readers passed the barrier at the end of step s - 1
+      store_b(buf ^ 1);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: accumulator register r = 4 rq + e of a 32 x 32 tile is row 8 rq + 4 (lane >> 5) + e, column lane & 31 -----------
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn * (TN / 2) + 32 * j + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (TM / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        if (row < g.M && col < g.N) {
+          float* c = C + (int64_t)row * g.ldc + col;
+          float v = g.alpha * acc[i][j][r];
+          if (g.beta != 0.f) v += g.beta * *c;
+          *c = v;
+        }
+      }
+    }
+}
+
+int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || batch <= 0) return INC_OK;
+  // tile choice: 128 x 128 when that still gives the chip enough workgroups, else 64 x 64 (the chain's small products)
+  auto ntiles = [&](int t) {
+    const int64_t tm = (g.M + t - 1) / t, tn = (g.N + t - 1) / t;
+    return g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
+  };
+  const bool big = ntiles(128) * batch >= 192;
+  const int t = big ? 128 : 64;
+  dim3 grid((unsigned)ntiles(t), (unsigned)batch);
+  if (big) {
+    if (b_nt) f32gemm_kernel<128, 128, true><<<grid, 256, 0, s>>>(g);
+    else f32gemm_kernel<128, 128, false><<<grid, 256, 0, s>>>(g);
+  } else {
+    if (b_nt) f32gemm_kernel<64, 64, true><<<grid, 256, 0, s>>>(g);
+    else f32gemm_kernel<64, 64, false><<<grid, 256, 0, s>>>(g);
+  }
+  return hipGetLastError() == hipSuccess ? INC_OK : INC_ERR_LAUNCH;
+}
+
+// A[i, j] = H[K-1-i, K-1-j] for i, j < K; identity on the padding (chol(blockdiag(Hr, I)) = blockdiag(L, I))
+__global__ __launch_bounds__(256) void ifac_flip_in_kernel(const float* __restrict__ H, int64_t K, float* __restrict__ A, int64_t Kp) {
+  const int64_t i = blockIdx.y;
+  for (int64_t j = blockIdx.x * 256 + threadIdx.x; j < Kp; j += (int64_t)gridDim.x * 256) {
+    float v = i == j ? 1.f : 0.f;
+    if (i < K && j < K) v = H[(K - 1 - i) * K + (K - 1 - j)];
+    A[i * Kp + j] = v;
+  }
+}
+// U[i, j] = X[K-1-i, K-1-j] for j >= i, zero below the diagonal
+__global__ __launch_bounds__(256) void ifac_flip_out_kernel(const float* __restrict__ X, int64_t Kp, float* __restrict__ U, int64_t K) {
+  const int64_t i = blockIdx.y;
+  for (int64_t j = blockIdx.x * 256 + threadIdx.x; j < K; j += (int64_t)gridDim.x * 256)
+    U[i * K + j] = j >= i ? X[(K - 1 - i) * Kp + (K - 1 - j)] : 0.f;
+}
+// dst[r, 0:cols] = src[r, 0:cols] (16-byte pieces; cols % 4 == 0)
+__global__ __launch_bounds__(256) void ifac_copy_panel_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int64_t rows, int cols) {
+  const int c4 = cols >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < rows * c4; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = *reinterpret_cast<const float4*>(src + r * lds_ + c);
+  }
+}
+
+struct Seg {
+  int64_t start, size;
+};
+
+}  // namespace
+
+extern "C" {
+
+// A [Kp, Kp] + X [Kp, Kp] + T [Kp, Kp] + P [Kp, IFAC_OUTER] fp32, Kp = K rounded up to 128
+int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K) {
+  if (K <= 0) return 0;
+  const int64_t Kp = ceil_div64(K, IFAC_NB) * IFAC_NB;
+  return (3 * Kp * Kp + Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float);
+}
+
+int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace, int64_t workspace_bytes, int32_t* info, int flags,
+                            inc_stream_t stream, inc_stream_t aux_stream) {
+  INC_CHECK_ARG(H && U && workspace && info && K > 0 && K < (1ll << 30));
+  (void)flags;
+  if (workspace_bytes < inc_gptq_inverse_factor_workspace_bytes(K)) return INC_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return INC_ERR_BAD_ARG;
+  hipStream_t s = inc_s(stream);
+  (void)aux_stream;
+  const int64_t Kp = ceil_div64(K, IFAC_NB) * IFAC_NB, ld = Kp;
+  float* A = static_cast<float*>(workspace);
+  float* X = A + Kp * Kp;
+  float* T = X + Kp * Kp;  // products C X11 of the doubling levels: the pair (s1, n1, s2, n2) keeps its n2 x n1 product in rows s2.. of T
+  float* P = T + Kp * Kp;  // panel L[i > block, block] before it is written back
+  if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess) return INC_ERR_LAUNCH;
+  if (hipMemsetAsync(X, 0, (size_t)Kp * Kp * sizeof(float), s) != hipSuccess) return INC_ERR_LAUNCH;
+  {
+    dim3 grid((unsigned)std::min<int64_t>(ceil_div64(Kp, 256), 64), (unsigned)Kp);
+    ifac_flip_in_kernel<<<grid, 256, 0, s>>>(H, K, A, Kp);
+  }
+  int rc = INC_OK;
+  auto gemm = [&](const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t M, int64_t N, int64_t Kd, float alpha,
+                  float beta, int krange, bool lower_only, bool b_nt, int batch = 1, int64_t sa = 0, int64_t sb = 0, int64_t sc = 0) {
+    GemmArgs g{a, b, c, lda, ldb, ldc, sa, sb, sc, (int)M, (int)N, (int)Kd, alpha, beta, krange, lower_only ? 1 : 0};
+    const int r = launch_f32gemm(g, b_nt, batch, s);
+    if (r != INC_OK) rc = r;
+  };
+  auto copy_panel = [&](const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int cols) {
+    const int64_t n4 = rows * (cols / 4);
+    ifac_copy_panel_kernel<<<(unsigned)std::min<int64_t>(ceil_div64(n4, 256), 2048), 256, 0, s>>>(src, lds_, dst, ldd, rows, cols);
+  };
+  // X of the span covered by `segs` (whose diagonal blocks of X already hold the inverses) by recursive doubling:
+  //   inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]];  both factors of X21 = -X22 (C X11) are lower-triangular inverses
+  auto invert_by_doubling = [&](std::vector<Seg> segs) {
+    while (segs.size() > 1) {
+      std::vector<Seg> nxt;
+      // pairs of equal geometry at a constant distance go out as ONE batched launch per product
+      size_t p = 0;
+      const size_t npairs = segs.size() / 2;
+      while (p < npairs) {
+        const Seg a = segs[2 * p], b = segs[2 * p + 1];
+        size_t q = p + 1;
+        while (q < npairs && segs[2 * q].size == a.size && segs[2 * q + 1].size == b.size &&
+               segs[2 * q].start - segs[2 * (q - 1)].start == a.size + b.size)
+          ++q;
+        const int batch = (int)(q - p);
+        const int64_t n1 = a.size, n2 = b.size, step = (a.size + b.size) * (ld + 1);
+        const int64_t ldt = Kp;
+        float* t0 = T + b.start * ldt;
+        const int64_t tstep = (a.size + b.size) * ldt;
+        // T = C X11  (C = A[s2.., s1..] general n2 x n1, X11 lower: k >= n)
+        gemm(A + b.start * ld + a.start, ld, X + a.start * ld + a.start, ld, t0, ldt, n2, n1, n1, 1.f, 0.f, KR_B_LOWER_NN, false, false, batch, step, step, tstep);
+        // X21 = -X22 T  (X22 lower: k <= m)
+        gemm(X + b.start * ld + b.start, ld, t0, ldt, X + b.start * ld + a.start, ld, n2, n1, n2, -1.f, 0.f, KR_A_LOWER, false, false, batch, step, tstep, step);
+        for (size_t r = p; r < q; ++r) nxt.push_back(Seg{segs[2 * r].start, segs[2 * r].size + segs[2 * r + 1].size});
+        p = q;
+      }
+      if (segs.size() & 1) nxt.push_back(segs.back());
+      segs.swap(nxt);
+    }
+    return segs[0];
+  };
+
+  std::vector<Seg> top;
+  int tag = 0;
+  for (int64_t Bo = 0; Bo < Kp; Bo += IFAC_OUTER) {
+    const int64_t n2 = std::min<int64_t>(IFAC_OUTER, Kp - Bo);
+    float* D = A + Bo * ld + Bo;
+    float* XD = X + Bo * ld + Bo;
+    std::vector<Seg> inner;
+    for (int64_t j = 0; j < n2; j += IFAC_NB) {
+      ++tag;
+      if (inc_launch_chol_diag_block(D + j * ld + j, ld, IFAC_NB, XD + j * ld + j, ld, info, tag, s) != INC_OK) rc = INC_ERR_LAUNCH;
+      inner.push_back(Seg{Bo + j, IFAC_NB});
+      if (j + IFAC_NB < n2) {
+        const int64_t m = n2 - (j + IFAC_NB);
+        float* panel = D + (j + IFAC_NB) * ld + j;  // [m, 128]
+        // L_panel = A_panel inv(L_jj)^T  (inv(L_jj) lower)
+        gemm(panel, ld, XD + j * ld + j, ld, P, IFAC_NB, m, IFAC_NB, IFAC_NB, 1.f, 0.f, KR_B_LOWER_NT, false, true);
+        copy_panel(P, IFAC_NB, panel, ld, m, IFAC_NB);
+        // trailing update inside the outer block, lower triangle only
+        gemm(P, IFAC_NB, P, IFAC_NB, D + (j + IFAC_NB) * (ld + 1), ld, m, m, IFAC_NB, -1.f, 1.f, KR_FULL, true, true);
+      }
+    }
+    top.push_back(invert_by_doubling(inner));
+    if (Bo + n2 < Kp) {
+      const int64_t Mr = Kp - (Bo + n2);
+      float* panel = A + (Bo + n2) * ld + Bo;  // [Mr, n2]
+      gemm(panel, ld, XD, ld, P, IFAC_OUTER, Mr, n2, n2, 1.f, 0.f, KR_B_LOWER_NT, false, true);  // L_panel = A_panel inv(L_DD)^T
+      copy_panel(P, IFAC_OUTER, panel, ld, Mr, (int)n2);
+      gemm(P, IFAC_OUTER, P, IFAC_OUTER, A + (Bo + n2) * (ld + 1), ld, Mr, Mr, n2, -1.f, 1.f, KR_FULL, true, true);
+    }
+  }
+  invert_by_doubling(top);
+  {
+    dim3 grid((unsigned)std::min<int64_t>(ceil_div64(K, 256), 64), (unsigned)K);
+    ifac_flip_out_kernel<<<grid, 256, 0, s>>>(X, Kp, U, K);
+  }
+  if (rc != INC_OK) return rc;
+  INC_LAUNCH_RETURN();
+}
+
+}  // extern "C"

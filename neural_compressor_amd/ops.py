@@ -632,6 +632,26 @@ def chol_diag_block(A_view, Linv_view, info, tag):
         )
 
 
+def gptq_inverse_factor(H, aux_stream=None):
+    """Upper Cholesky factor U of H^-1 for the damped SPD fp32 Hessian H [K,K] (gptq.py:1228-1231) as ONE C-ABI call
+    (include/inc_mi355x.h: inc_gptq_inverse_factor).  Returns (U, info): `info` is a device int32 that stays 0 unless H
+    is not positive definite (no host synchronisation here)."""
+    dev = _dev(H)
+    K = H.shape[0]
+    assert H.shape == (K, K) and H.dtype == torch.float32 and H.is_contiguous()
+    U = torch.empty((K, K), dtype=torch.float32, device=dev)
+    info = torch.empty(1, dtype=torch.int32, device=dev)
+    wsb = int(lib.inc_gptq_inverse_factor_workspace_bytes(K))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    aux = aux_stream.cuda_stream if aux_stream is not None else None
+    if aux_stream is not None:
+        for t in (H, U, ws, info):
+            t.record_stream(aux_stream)
+    with torch.cuda.device(dev):
+        check(lib.inc_gptq_inverse_factor(_ptr(H), K, _ptr(U), _ptr(ws), wsb, _ptr(info), 0, _stream(), aux), "inc_gptq_inverse_factor")
+    return U, info
+
+
 # ---------------------------------------------------------------------------------------------------
 # K8 AWQ statistics
 # ---------------------------------------------------------------------------------------------------

@@ -159,6 +159,7 @@ def _chol_side_stream(device):
     return st
 
 
+CHOL_PYTHON = os.environ.get("INC_MI355X_CHOL_PYTHON", "0") == "1"
 CHOL_OUTER = int(os.environ.get("INC_MI355X_CHOL_OUTER", "1024"))  # outer block of the two-level factorisation (columns)
 TRI_DEPTH = int(os.environ.get("INC_MI355X_CHOL_TRI_DEPTH", "2"))    # levels of 2 x 2 splitting in the triangular products
 TRI_MIN = 512                                                        # do not split below this half size
@@ -184,6 +185,14 @@ def inverse_cholesky_upper(H, check=True):
     host synchronisation): the caller checks it later with `raise_if_not_spd`.
     """
     assert H.dim() == 2 and H.shape[0] == H.shape[1] and H.dtype == torch.float32
+    if H.is_cuda and not CHOL_PYTHON:
+        # the whole factorisation behind the C-ABI (csrc/ifac.hip): the same blocked algorithm with this library's own fp32 MFMA
+        # GEMMs instead of torch.mm.  INC_MI355X_CHOL_PYTHON=1 keeps the Python + torch.mm form below (its A/B partner in the tests).
+        U, info = ops.gptq_inverse_factor(H.contiguous())
+        if not check:
+            return U, info
+        raise_if_not_spd(info)
+        return U
     K = H.shape[0]
     nb = CHOL_NB
     Kp = -(-K // nb) * nb
@@ -425,6 +434,8 @@ class HessianAccumulator:
     def _committed(self):
         self._n += self._pending
         self._fill, self._pending, self._direct = 0, 0, None
+        if self._zc_ok and self._stage is not None and self._stage.shape[0] >= self.STAGE_TOKENS:
+            self._stage = None  # full stages are read in place from now on: drop the [65536, K] copy buffer (1.4 GB at K = 11008)
 
     def flush(self):
         item = self._launch_item()
@@ -435,7 +446,8 @@ class HessianAccumulator:
     @staticmethod
     def flush_many(accs, only_due=False):
         """Fold the pending batches of several accumulators with ONE launch (inc_gptq_hessian_accum_multi) when the
-        library takes the batch, else one launch each; every tile is computed as in the single launch.  `only_due`: leave
+        library takes the batch, else one launch each.  Deterministic; equal to the single launches up to fp32 summation order
+        (the batched launch may sum its last tiles over several token ranges, csrc/gptq.hip "tail split").  `only_due`: leave
         partially filled stages alone (batches that cannot be stacked keep accumulating up to STAGE_TOKENS)."""
         todo, seen = [], set()
         for acc in accs:
@@ -1210,6 +1222,18 @@ class RAWGPTQuantizer(object):
             shape, dtype = meta[0][0], getattr(torch, meta[0][1])
         else:
             shape, dtype = tuple(ref.shape), ref.dtype
+        # The exchange ships one message per (block, source rank) sized `count x shape[1:]` and slices it back into samples: that is
+        # only the cached data when EVERY cached hidden state is one sample of exactly this shape (run_fn fed batches of one, all of
+        # one sequence length).  Checked on every rank BEFORE any collective of a round is posted, and all ranks raise together.
+        hidden = self._hidden_list()[:n_local]
+        bad = int(any((not isinstance(h, torch.Tensor)) or tuple(h.shape) != tuple(shape) or h.shape[0] != 1 or h.dtype != dtype for h in hidden))
+        if ctx is not None:
+            flag = torch.tensor([bad], dtype=torch.int64, device="cpu" if ctx.backend == "gloo" else self.device)
+            bad = int(ctx.all_reduce(flag).item())
+        if bad:
+            raise ValueError("layer-per-GPU calibration (independent_blocks) needs calibration batches of ONE sample each, all of the same "
+                             f"shape {tuple(shape)} / dtype {dtype}: {bad} rank(s) cached something else (batch size > 1 or ragged "
+                             "sequence lengths); feed run_fn one padded sample per forward, or use the sample-sharded mode")
         self._layer_state = dict(world=world, rank=rank, exchange=exchange, counts=counts, n_total=sum(counts), shape=shape, dtype=dtype)
 
     @torch.no_grad()
@@ -1433,6 +1457,11 @@ class RAWGPTQuantizer(object):
             solver.row_ctx = self.dist_ctx
         elif self.hessian_allreduce:
             solver.acc.allreduce(None if self.hessian_allreduce is True else self.hessian_allreduce)
+        elif self.layer_ctx is not None and self.layer_ctx.world > 1:
+            # mode "layer": every rank holds only ITS samples' last-block outputs here.  The ranks' running means are combined
+            # (H = sum_r (n_r / n) H_r over RCCL) so that every rank factorises the same Hessian and packs the same lm_head, as
+            # independent_finish promises; a rank without samples contributes H = 0 with weight 0.
+            solver.acc.allreduce(self.layer_ctx.group)
         scale, _, zp, Q = solver.fasterquant(
             layer.weight.data, blocksize=cfg["block_size"], percdamp=cfg["percdamp"], groupsize=cfg["group_size"],
             act_order=cfg["act_order"], hybrid_order=cfg["hybrid_order"], fp8_aware=cfg["fp8_aware"],

@@ -162,6 +162,7 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         dev = self.qweight.device
         N, K = self.out_features, self.in_features
         self._plan_key = None  # the kernels write the buffers through raw pointers: drop the cached forward plan
+        self.__dict__["_call"] = None  # ... and the prepared call (its converted bias / plan belong to the old contents)
         if bias is not None:
             assert hasattr(self, "bias"), "bias is not set when initializing."
             self.bias = bias.detach().to(dev).type(self.float_type)
@@ -211,6 +212,7 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         assert self.use_optimum_format, "pack_codes writes the optimum layout"
         dev = self.qweight.device
         self._plan_key = None
+        self.__dict__["_call"] = None
         if bias is not None:
             self.bias = bias.detach().to(dev).type(self.float_type)
         if g_idx is not None:
@@ -273,7 +275,7 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         # decode path: a prepared call for the plain fused plan (ops.WoqGemmCall); the 6-us kernel makes the host side count
         d = self.__dict__
         call = d.get("_call")
-        if call is not None and x.dtype is call.dtype and x.device == call.dev and x.is_contiguous() and x.numel() > 0:
+        if call is not None and x.dtype is call.dtype and x.device == call.dev and x.is_contiguous() and x.numel() > 0 and x.shape[-1] == call.K:
             bufs = self._buffers
             if call.current(bufs["qweight"], bufs["scales"], bufs["qzeros"], bufs.get("bias", d.get("bias")), bufs.get("g_idx", d.get("g_idx"))):
                 y = call(x if x.dim() == 2 else x.view(-1, call.K))

@@ -1,5 +1,5 @@
-"""Time inverse_cholesky_upper (GPTQ's Hinv factor) alone on the GPU for several outer block sizes.
-usage: python scripts/chol_time.py [K ...]"""
+"""Time the inverse-Cholesky factor of GPTQ (Hinv) alone on the GPU: the one-call C-ABI form (inc_gptq_inverse_factor) and the
+Python + torch.mm form it replaced.  usage: python scripts/chol_time.py [K ...]"""
 import sys
 import time
 
@@ -17,23 +17,24 @@ def main():
         X = torch.randn(4 * K if K <= 4096 else 2 * K, K, device=dev)
         H = (X.t() @ X) / X.shape[0]
         H.diagonal().add_(0.01 * H.diagonal().mean())
-        ref = None
-        for outer, depth in ((1024, 0), (1024, 1), (1024, 2), (1024, 3), (2048, 2)):
-            G.CHOL_OUTER = outer
-            G.TRI_DEPTH = depth
+        H64 = H.double()
+        ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H64)), upper=True) if K <= 4096 else None
+        first = None
+        for form in ("cabi", "python"):
+            G.CHOL_PYTHON = form == "python"
             U = G.inverse_cholesky_upper(H)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(5):
                 U = G.inverse_cholesky_upper(H, check=False)[0]
             torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / 3 * 1e3
-            if ref is None:
-                ref = U
-            # residual of the definition: U H U^T = I
-            R = U @ H @ U.t()
-            res = float((R - torch.eye(K, device=dev)).norm() / K ** 0.5)
-            print(f"K={K} outer={outer} tri_depth={depth}: {ms:8.2f} ms  |U H U^T - I|_F/sqrt(K)={res:.2e}  rel diff to the first row: {float((U - ref).norm() / ref.norm()):.2e}", flush=True)
+            ms = (time.perf_counter() - t0) / 5 * 1e3
+            if first is None:
+                first = U
+            R = U.double() @ H64 @ U.double().t()
+            res = float((R - torch.eye(K, device=dev, dtype=torch.float64)).norm() / K ** 0.5)
+            err = f" rel err vs fp64 trio {float((U.double() - ref).norm() / ref.norm()):.2e}" if ref is not None else ""
+            print(f"K={K} {form:7s}: {ms:8.2f} ms  |U H U^T - I|_F/sqrt(K)={res:.2e}{err}  rel diff to the C-ABI form: {float((U - first).norm() / first.norm()):.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -33,14 +33,14 @@ while [[ $# -gt 0 ]]; do
             -d "$R/gpurun_out/tl_late$late" -o tl -- python "$R/bench.py" --steps 2 --warmup 2 $BENCH_MIN > "$R/gpurun_out/tl_late$late.log" 2> "$R/gpurun_out/tl_late$late.err" )
         echo "timeline late=$late exit $?"; grep -o '"ms_per_step": [0-9.]*' gpurun_out/tl_late$late.log
         python3 scripts/step_timeline.py gpurun_out/tl_late$late gpurun_out/step_timeline_late$late.md > /dev/null 2> gpurun_out/step_timeline_late$late.err || tail -3 gpurun_out/step_timeline_late$late.err
-        head -40 gpurun_out/step_timeline_late$late.md
+        head -12 gpurun_out/step_timeline_late$late.md | cut -c1-300
         find gpurun_out/tl_late$late -name "*.csv" -size +20M -delete   # (keep the merge-back small)
       done ;;
     benchab)
       shift
       for v in 1 0 1 0; do
         env "$1=$v" timeout 300 python bench.py --steps 4 --warmup 1 $BENCH_MIN > gpurun_out/bench_ab.log 2> gpurun_out/bench_ab.err
-        python3 - $1 $v <<'PY'
+        python3 - $1 $v <<'PY' | tee -a gpurun_out/bench_ab_summary.txt
 import json, sys
 for line in open("gpurun_out/bench_ab.log"):
     if line.startswith("{"):

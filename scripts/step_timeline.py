@@ -31,9 +31,11 @@ def classify(name):
         return "column loop (own)"
     if "woq_pack" in n or "pack_" in n or "woq_" in n:
         return "pack / woq (own)"
-    if n.startswith("Cijk_") or "Cijk_" in n:
-        return "library GEMM fp32" if "_S_B_" in n or "_SB_" in n or "Cijk_Alik_Bljk_S_" in n or "Cijk_Ailk_Bljk_S_" in n or "_S_S" in n.split("MT")[0] else "library GEMM bf16 (model forward)"
-    if "attention" in n.lower() or "fmha" in n.lower() or "flash" in n.lower() or "sdpa" in n.lower():
+    if "Cijk_" in n:
+        # Tensile names: Cijk_<A layout>_<B layout>_<types>_...; fp32 GEMMs carry the type string "S_B" / "SB", bf16 ones "BBS_BH" / "B_B"
+        head = n.split("Cijk_")[1].split("_MT")[0]
+        return "library GEMM fp32 (factorisation)" if ("_S_B_" in "_" + head + "_" or head.endswith("_SB") or "_SB_" in head) else "library GEMM bf16 (model forward)"
+    if "attention" in n.lower() or "fmha" in n.lower() or "flash" in n.lower() or "sdpa" in n.lower() or "attn_fwd" in n:
         return "attention (model forward)"
     if "elementwise" in n or "reduce_kernel" in n or "rms" in n.lower() or "norm" in n.lower() or "CatArray" in n or "index" in n or "copy" in n.lower() or "softmax" in n.lower():
         return "elementwise / norm / copies (torch)"

@@ -154,3 +154,46 @@ def test_layer_mode_activation_exchange_gloo_world3_with_an_empty_rank(exchange)
         out = mgr.dict()
         mp.spawn(_layer_exchange_worker, args=(world, port, exchange, out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True, 2: True}
+
+
+def _layer_setup_worker(rank, world, port, case, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neural_compressor_amd import distributed as D
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import RAWGPTQuantizer
+
+    D.init_from_env(backend="gloo")
+    rq = object.__new__(RAWGPTQuantizer)
+    rq.device = torch.device("cpu")
+    rq.layer_ctx = D.CalibrationGroup()
+    good = [torch.zeros(1, 4, 5) for _ in range(2)]
+    if case == "batch2" and rank == 1:
+        hidden = [torch.zeros(2, 4, 5)]          # one cached batch holding two samples
+    elif case == "ragged" and rank == 1:
+        hidden = [torch.zeros(1, 4, 5), torch.zeros(1, 3, 5)]
+    else:
+        hidden = good
+    rq.cache_key_arguments = {"hidden_states": hidden, "batch_num": len(hidden)}
+    rq.cache_positional_arguments = []
+    try:
+        rq.independent_setup()
+        out[rank] = ("ok", rq._layer_state["counts"], rq._layer_state["shape"])
+    except ValueError as e:
+        out[rank] = ("raised", str(e)[:40])
+    dist.barrier()  # every rank is still in step: nobody hangs in a collective the other never posts
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("case", ["fine", "batch2", "ragged"])
+def test_layer_mode_setup_rejects_batches_it_cannot_exchange(case):
+    """round-3 advice: the layer-per-GPU exchange sizes its messages `count x sample shape`; a rank whose run_fn fed batches of more
+    than one sample (or ragged lengths) must make EVERY rank raise before any collective of a round is posted."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_layer_setup_worker, args=(world, port, case, out), nprocs=world, join=True)
+        res = dict(out)
+    if case == "fine":
+        assert res[0] == res[1] == ("ok", [2, 2], (1, 4, 5))
+    else:
+        assert res[0][0] == res[1][0] == "raised", res

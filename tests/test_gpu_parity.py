@@ -641,10 +641,15 @@ def test_awq_stats(hip, golden):
 # ---------------------------------------------------------------------------------------------------
 # K6' blocked inverse-Cholesky factor (replaces the potrf -> potri -> potrf trio, gptq.py:1228-1230)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("K", [96, 128, 300, 1024])
-def test_inverse_cholesky_upper_vs_reference_trio(hip, K):
+@pytest.mark.parametrize("form", ["cabi", "python"])
+@pytest.mark.parametrize("K", [96, 128, 300, 1024, 2432])
+def test_inverse_cholesky_upper_vs_reference_trio(hip, K, form, monkeypatch):
+    """`form`: the whole factorisation as ONE C-ABI call (inc_gptq_inverse_factor: this library's own fp32 MFMA GEMMs) or the
+    Python + torch.mm form of rounds 1-3 (its A/B partner); K = 2432 spans three outer blocks with a short last one."""
+    from neural_compressor_amd.torch.algorithms.weight_only import gptq as G
     from neural_compressor_amd.torch.algorithms.weight_only.gptq import inverse_cholesky_upper
 
+    monkeypatch.setattr(G, "CHOL_PYTHON", form == "python")
     g = torch.Generator().manual_seed(K)
     X = torch.randn(4 * K, K, generator=g, dtype=torch.float64)
     H64 = (2.0 / X.shape[0]) * X.T @ X
@@ -665,13 +670,43 @@ def test_inverse_cholesky_upper_vs_reference_trio(hip, K):
     assert resid <= 1e-3, resid
 
 
-def test_inverse_cholesky_upper_rejects_non_spd(hip):
+@pytest.mark.parametrize("form", ["cabi", "python"])
+def test_inverse_cholesky_upper_rejects_non_spd(hip, form, monkeypatch):
+    from neural_compressor_amd.torch.algorithms.weight_only import gptq as G
     from neural_compressor_amd.torch.algorithms.weight_only.gptq import inverse_cholesky_upper
 
+    monkeypatch.setattr(G, "CHOL_PYTHON", form == "python")
     H = torch.eye(256)
     H[200, 200] = -1.0
     with pytest.raises(torch.linalg.LinAlgError):
         inverse_cholesky_upper(H.to(hip))
+    # ... and the status word is reset by the next call on a good matrix (the C-ABI call writes it)
+    U = inverse_cholesky_upper(torch.eye(256).to(hip))
+    assert torch.equal(U.cpu(), torch.eye(256))
+
+
+def test_inverse_factor_cabi_matches_the_python_form(hip, monkeypatch):
+    """Same blocked algorithm, same leaf kernel; only the fp32 GEMMs differ (own MFMA kernel vs the library's): the two factors agree
+    to a few fp32 ulps of their largest entries, and the ABI rejects a short workspace."""
+    from neural_compressor_amd import _lib, ops
+    from neural_compressor_amd.torch.algorithms.weight_only import gptq as G
+
+    K = 1408  # 11 leaf blocks: one full outer block + a 384-column one
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(3 * K, K, generator=g)
+    H = ((2.0 / X.shape[0]) * X.T @ X)
+    H += 0.01 * H.diagonal().mean() * torch.eye(K)
+    H = H.to(hip)
+    monkeypatch.setattr(G, "CHOL_PYTHON", True)
+    Up = G.inverse_cholesky_upper(H)
+    Uc, info = ops.gptq_inverse_factor(H)
+    assert int(info.item()) == 0
+    assert float((Uc - Up).abs().max() / Up.abs().max()) <= 2e-5
+    assert torch.equal(Uc, torch.triu(Uc))
+    ws = torch.empty(1024, dtype=torch.uint8, device=hip)
+    out = torch.empty_like(H)
+    rc = _lib.lib.inc_gptq_inverse_factor(H.data_ptr(), K, out.data_ptr(), ws.data_ptr(), 1024, info.data_ptr(), 0, None, None)
+    assert rc == -4  # INC_ERR_WORKSPACE
 
 
 @pytest.mark.gpu

@@ -330,7 +330,8 @@ static int run_d2r_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool 
 
 // ---- per-workgroup timeline of the direct-to-register dequant-GEMM (harness flag 98): where the kernel's span goes ----
 extern "C" int inc_debug_set_d2r_timeline(void* dev_buffer);
-static void run_d2r_timeline(int64_t M, int64_t N, int64_t K) {
+extern "C" void inc_debug_set_d2r_abl(int abl);
+static void run_d2r_timeline(int64_t M, int64_t N, int64_t K, int abl = 256, const char* label = "full kernel") {
   Packed W(N, K, 128, true);
   DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
   {
@@ -346,6 +347,7 @@ static void run_d2r_timeline(int64_t M, int64_t N, int64_t K) {
   for (int i = 0; i < 6; ++i)  // warm clocks with the plain kernel
     INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
   inc_debug_set_small_tiles(98);
+  inc_debug_set_d2r_abl(abl);
   Timer t;
   for (int i = 0; i < 3; ++i)
     INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, nullptr, 0, nullptr));
@@ -387,8 +389,8 @@ static void run_d2r_timeline(int64_t M, int64_t N, int64_t K) {
     printf("    %-34s mean %9.2f  min %9.2f  p10 %9.2f  p50 %9.2f  p90 %9.2f  max %9.2f %s\n", label, sum / v.size(), v.front(), v[v.size() / 10], v[v.size() / 2],
            v[v.size() * 9 / 10], v.back(), unit);
   };
-  printf("D2R TIMELINE M=%ld N=%ld K=%ld: %ld workgroups (%.2f per CU), %d K-steps; HIP-event time %.1f us, first entry -> last store acknowledged %.1f us\n", (long)M,
-         (long)N, (long)K, (long)nwg, nwg / 256.0, nk, ev_ms * 1e3, (t_last - t_first) * tick_us);
+  printf("D2R TIMELINE [%s] M=%ld N=%ld K=%ld: %ld workgroups (%.2f per CU), %d K-steps; HIP-event time %.1f us, first entry -> last store acknowledged %.1f us\n", label,
+         (long)M, (long)N, (long)K, (long)nwg, nwg / 256.0, nk, ev_ms * 1e3, (t_last - t_first) * tick_us);
   stats(start, "entry after the first entry", "us");
   stats(pro, "prologue (entry -> first K-step)", "us");
   stats(loop, "K-loop", "us");
@@ -1022,6 +1024,13 @@ int main(int argc, char** argv) {
     run_d2r_timeline(4096, 4096, 11008);
     run_d2r_timeline(8192, 4096, 4096);
     run_d2r_timeline(4096, 11008, 4096);
+    // timing-only ablations (wrong results by construction): cycles per K-step AND the clock each variant sustains
+    run_d2r_timeline(4096, 4096, 4096, 260, "- x LDS-DMA");
+    run_d2r_timeline(4096, 4096, 4096, 264, "- W loads");
+    run_d2r_timeline(4096, 4096, 4096, 268, "- all global traffic");
+    run_d2r_timeline(4096, 4096, 4096, 320, "- barrier");
+    run_d2r_timeline(4096, 4096, 4096, 332, "- global traffic - barrier");
+    run_d2r_timeline(4096, 4096, 4096, 256, "full kernel again");
   }
   if (what == "gemm" || what == "all") {
     fails += run_gemm_case(256, 256, 64, 32, false, true, false, 64);     // one tile, one K-step, gs=32 asym
