@@ -62,8 +62,23 @@ __global__ __launch_bounds__(256) void f32gemm_kernel(GemmArgs g) {
     while (ti * (ti + 1) / 2 > t) --ti;
     tj = t - ti * (ti + 1) / 2;
   } else {
-    ti = blockIdx.x / tiles_n;
-    tj = blockIdx.x - ti * tiles_n;
+    // tiles in order of DECREASING K-range (the hardware hands out workgroups in index order: longest first packs the last round)
+    const int tiles_m = (g.M + TM - 1) / TM, b = blockIdx.x;
+    if (g.krange == KR_B_LOWER_NN) {         // k_lo = n0: the leftmost tile columns are the longest
+      tj = b / tiles_m;
+      ti = b - tj * tiles_m;
+    } else if (g.krange == KR_B_LOWER_NT) {  // k_hi = n0 + TN: the rightmost tile columns are the longest
+      tj = b / tiles_m;
+      ti = b - tj * tiles_m;
+      tj = tiles_n - 1 - tj;
+    } else if (g.krange == KR_A_LOWER) {     // k_hi = m0 + TM: the bottom tile rows are the longest
+      ti = b / tiles_n;
+      tj = b - ti * tiles_n;
+      ti = tiles_m - 1 - ti;
+    } else {
+      ti = b / tiles_n;
+      tj = b - ti * tiles_n;
+    }
   }
   const int m0 = ti * TM, n0 = tj * TN;
   int k_lo = 0, k_hi = g.K;
@@ -71,9 +86,10 @@ __global__ __launch_bounds__(256) void f32gemm_kernel(GemmArgs g) {
   else if (g.krange == KR_B_LOWER_NN) k_lo = min(n0, g.K);       // B[k, n] = 0 for k < n
   else if (g.krange == KR_A_LOWER) k_hi = min(g.K, m0 + TM);     // A[m, k] = 0 for k > m
   k_lo &= ~(BK - 1);
-  const float* __restrict__ A = g.A + (int64_t)blockIdx.y * g.sA;
-  const float* __restrict__ B = g.B + (int64_t)blockIdx.y * g.sB;
-  float* __restrict__ C = g.C + (int64_t)blockIdx.y * g.sC;
+  // (no __restrict__: the in-place panel solve passes C == A -- every load of a tile precedes its stores, see launch_f32gemm)
+  const float* A = g.A + (int64_t)blockIdx.y * g.sA;
+  const float* B = g.B + (int64_t)blockIdx.y * g.sB;
+  float* C = g.C + (int64_t)blockIdx.y * g.sC;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -191,6 +207,14 @@ int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s) {
     const int64_t tm = (g.M + t - 1) / t, tn = (g.N + t - 1) / t;
     return g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
   };
+  if (g.C == g.A) {
+    // in place (C == A): legal only when ONE tile spans every column and the whole K of its rows -- its K-loop has read the row
+    // block completely before the epilogue stores it, and no other workgroup touches those rows.  The 128-column panel solves.
+    if (!(b_nt && g.N <= 128 && g.K <= 128 && !g.lower_only && batch == 1)) return INC_ERR_BAD_ARG;
+    dim3 grid((unsigned)((g.M + 63) / 64), 1);
+    f32gemm_kernel<64, 128, true><<<grid, 256, 0, s>>>(g);
+    return hipGetLastError() == hipSuccess ? INC_OK : INC_ERR_LAUNCH;
+  }
   const bool big = ntiles(128) * batch >= 192;
   const int t = big ? 128 : 64;
   dim3 grid((unsigned)ntiles(t), (unsigned)batch);
@@ -258,7 +282,7 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
   float* T = X + Kp * Kp;  // products C X11 of the doubling levels: the pair (s1, n1, s2, n2) keeps its n2 x n1 product in rows s2.. of T
   float* P = T + Kp * Kp;  // panel L[i > block, block] before it is written back
   if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess) return INC_ERR_LAUNCH;
-  if (hipMemsetAsync(X, 0, (size_t)Kp * Kp * sizeof(float), s) != hipSuccess) return INC_ERR_LAUNCH;
+  // (X needs no initialisation: every product reads only blocks on or below the block diagonal, all written before they are read)
   {
     dim3 grid((unsigned)std::min<int64_t>(ceil_div64(Kp, 256), 64), (unsigned)Kp);
     ifac_flip_in_kernel<<<grid, 256, 0, s>>>(H, K, A, Kp);
@@ -320,11 +344,10 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
       if (j + IFAC_NB < n2) {
         const int64_t m = n2 - (j + IFAC_NB);
         float* panel = D + (j + IFAC_NB) * ld + j;  // [m, 128]
-        // L_panel = A_panel inv(L_jj)^T  (inv(L_jj) lower)
-        gemm(panel, ld, XD + j * ld + j, ld, P, IFAC_NB, m, IFAC_NB, IFAC_NB, 1.f, 0.f, KR_B_LOWER_NT, false, true);
-        copy_panel(P, IFAC_NB, panel, ld, m, IFAC_NB);
+        // L_panel = A_panel inv(L_jj)^T  (inv(L_jj) lower), in place: one 64 x 128 tile per row block
+        gemm(panel, ld, XD + j * ld + j, ld, panel, ld, m, IFAC_NB, IFAC_NB, 1.f, 0.f, KR_FULL, false, true);
         // trailing update inside the outer block, lower triangle only
-        gemm(P, IFAC_NB, P, IFAC_NB, D + (j + IFAC_NB) * (ld + 1), ld, m, m, IFAC_NB, -1.f, 1.f, KR_FULL, true, true);
+        gemm(panel, ld, panel, ld, D + (j + IFAC_NB) * (ld + 1), ld, m, m, IFAC_NB, -1.f, 1.f, KR_FULL, true, true);
       }
     }
     top.push_back(invert_by_doubling(inner));

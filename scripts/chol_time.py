@@ -10,7 +10,13 @@ import neural_compressor_amd.torch.algorithms.weight_only.gptq as G  # noqa: E40
 
 
 def main():
-    Ks = [int(a) for a in sys.argv[1:]] or [4096, 11008]
+    forms = ("cabi", "python")
+    args = sys.argv[1:]
+    if "--form" in args:
+        i = args.index("--form")
+        forms = (args[i + 1],)
+        del args[i:i + 2]
+    Ks = [int(a) for a in args] or [4096, 11008]
     dev = torch.device("cuda")
     for K in Ks:
         torch.manual_seed(K)
@@ -20,7 +26,7 @@ def main():
         H64 = H.double()
         ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H64)), upper=True) if K <= 4096 else None
         first = None
-        for form in ("cabi", "python"):
+        for form in forms:
             G.CHOL_PYTHON = form == "python"
             U = G.inverse_cholesky_upper(H)
             torch.cuda.synchronize()

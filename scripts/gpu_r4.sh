@@ -50,6 +50,40 @@ PY
       done ;;
     chol)
       timeout 300 python scripts/chol_time.py > gpurun_out/chol_time.log 2>&1; tail -12 gpurun_out/chol_time.log ;;
+    choltrace)
+      rm -rf "$R/gpurun_out/prof_chol"
+      ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_chol" -o c -- python "$R/scripts/chol_time.py" --form cabi 11008 > "$R/gpurun_out/prof_chol.log" 2>&1 )
+      echo "choltrace exit $?"; tail -2 gpurun_out/prof_chol.log
+      python3 - gpurun_out/prof_chol/c_kernel_trace.csv <<'PY' | tee gpurun_out/chol_trace_summary.txt
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the last factorisation = from the last ifac_flip_in to the last ifac_flip_out
+ins = [i for i, r in enumerate(rows) if "ifac_flip_in" in r["Kernel_Name"]]
+outs = [i for i, r in enumerate(rows) if "ifac_flip_out" in r["Kernel_Name"]]
+run = rows[ins[-1]: outs[-1] + 1]
+t0, t1 = int(run[0]["Start_Timestamp"]), int(run[-1]["End_Timestamp"])
+busy = collections.Counter(); cnt = collections.Counter()
+for r in run:
+    n = r["Kernel_Name"]
+    if "f32gemm" in n:
+        g = int(r["Grid_Size_X"]) // 256
+        tile = "128" if "Li128ELi128" in n or "<128, 128" in n else "64"
+        k = f"f32gemm<{tile}> {'NT' if ('Lb1' in n or 'true' in n) else 'NN'} " + ("big(>=256 wg)" if g >= 256 else "small(<256 wg)")
+    else:
+        k = n.split("(")[0][-40:]
+    busy[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[k] += 1
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in run)
+tot = 0; cs, ce = iv[0]
+for s, e in iv[1:]:
+    if s > ce: tot += ce - cs; cs, ce = s, e
+    else: ce = max(ce, e)
+tot += ce - cs
+print(f"span {(t1 - t0) / 1e6:.2f} ms, device busy {tot / 1e6:.2f} ms, idle {(t1 - t0 - tot) / 1e6:.2f} ms, kernels {len(run)}")
+for k, v in busy.most_common(14):
+    print(f"  {v / 1e6:8.2f} ms {cnt[k]:5d} x {k}   ({v / cnt[k] / 1e3:.1f} us each)")
+PY
+      find gpurun_out/prof_chol -name "*.csv" -size +20M -delete ;;
     prof)
       rm -rf "$R/gpurun_out/prof"
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r4 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs --no-per-layer > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
