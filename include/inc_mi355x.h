@@ -292,13 +292,16 @@ int inc_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, 
  *   == `H = cholesky(H); H = cholesky_inverse(H); Hinv = cholesky(H, upper=True)`, computed as U = J L^-1 J with
  *   J H J = L L^T: one blocked Cholesky + one blocked triangular inverse (128 inside 1024 columns), every product an
  *   exact-fp32 MFMA GEMM of this library (v_mfma_f32_32x32x2_f32, triangular operands skipped by K-range, syrk on the
- *   lower tiles only), the diagonal blocks by the inc_chol_diag_block kernel.  Everything is issued on `stream`
- *   (`aux_stream`, may be NULL, is reserved for the look-ahead over outer blocks); deterministic.
+ *   lower tiles only), the diagonal blocks by the inc_chol_diag_block kernel.  The chain (diagonal blocks, block
+ *   inverses, panel solves, the update of the next block's columns) is issued on `stream`; with `aux_stream` (may be
+ *   NULL) the rest of every trailing update and the top-level doubling products run there underneath the chain (two
+ *   transient HIP events; the call returns with `stream` ordered behind everything).  Same results either way;
+ *   deterministic.
  *   workspace: >= inc_gptq_inverse_factor_workspace_bytes(K) bytes, 16-byte aligned, contents undefined on return
- *   (3 Kp^2 + 1024 Kp floats, Kp = K rounded up to 128).
+ *   (3 Kp^2 + 2048 Kp floats, Kp = K rounded up to 128).
  *   info: device int32, written by the call: 0, or the (1-based) index of the last 128-column diagonal block with a
  *   non-positive pivot (H not positive definite -- the reference's torch.linalg.cholesky raises there); U is
- *   undefined in that case.  flags: 0.                                                                             */
+ *   undefined in that case.  flags: bit 0 = ignore aux_stream (one stream).                                                                             */
 int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K);
 int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace, int64_t workspace_bytes, int32_t* info,
                             int flags, inc_stream_t stream, inc_stream_t aux_stream);

@@ -163,17 +163,26 @@ __global__ __launch_bounds__(256) void f32gemm_kernel(GemmArgs g) {
       load_a(k_lo + (s + 1) * BK);
       load_b(k_lo + (s + 1) * BK);
     }
+    // fragments one k-pair ahead of the MFMAs that use them (the compiler's own order was read -> wait -> 4 MFMAs -> read ...)
+    float a[2][MI], b[2][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a[0][i] = As[buf][fa + 32 * i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b[0][j] = Bs[buf][fb + 32 * j];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[MI], b[NI];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = As[buf][2 * kk * PA + fa + 32 * i];
+        for (int i = 0; i < MI; ++i) a[nxt][i] = As[buf][2 * (kk + 1) * PA + fa + 32 * i];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = Bs[buf][2 * kk * PB + fb + 32 * j];
+        for (int j = 0; j < NI; ++j) b[nxt][j] = Bs[buf][2 * (kk + 1) * PB + fb + 32 * j];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads in front of this k-pair's MFMAs
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
     if (s + 1 < nsteps) {
       store_a(buf ^ 1);  // the other stage: its last readers passed the barrier at the end of step s - 1
@@ -261,26 +270,36 @@ struct Seg {
 
 extern "C" {
 
-// A [Kp, Kp] + X [Kp, Kp] + T [Kp, Kp] + P [Kp, IFAC_OUTER] fp32, Kp = K rounded up to 128
+// A [Kp, Kp] + X [Kp, Kp] + T [Kp, Kp] + 2 x P [Kp, IFAC_OUTER] fp32, Kp = K rounded up to 128
 int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K) {
   if (K <= 0) return 0;
   const int64_t Kp = ceil_div64(K, IFAC_NB) * IFAC_NB;
-  return (3 * Kp * Kp + Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float);
+  return (3 * Kp * Kp + 2 * Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float);
 }
 
 int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace, int64_t workspace_bytes, int32_t* info, int flags,
                             inc_stream_t stream, inc_stream_t aux_stream) {
   INC_CHECK_ARG(H && U && workspace && info && K > 0 && K < (1ll << 30));
-  (void)flags;
   if (workspace_bytes < inc_gptq_inverse_factor_workspace_bytes(K)) return INC_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return INC_ERR_BAD_ARG;
   hipStream_t s = inc_s(stream);
-  (void)aux_stream;
   const int64_t Kp = ceil_div64(K, IFAC_NB) * IFAC_NB, ld = Kp;
   float* A = static_cast<float*>(workspace);
   float* X = A + Kp * Kp;
   float* T = X + Kp * Kp;  // products C X11 of the doubling levels: the pair (s1, n1, s2, n2) keeps its n2 x n1 product in rows s2.. of T
-  float* P = T + Kp * Kp;  // panel L[i > block, block] before it is written back
+  float* Pb[2] = {T + Kp * Kp, T + Kp * Kp + Kp * (int64_t)IFAC_OUTER};  // panel L[i > block, block] of outer block b in Pb[b & 1]
+  // Look-ahead (aux_stream given, flags bit 0 clear, more than two outer blocks): the main stream runs the CHAIN -- per outer block the
+  // eight diagonal kernels with their small products, the block's inverse, the panel solve and the update of the NEXT block's columns
+  // -- and the second stream everything the chain does not wait for: the rest of every trailing update and the doubling products of
+  // the top level as soon as their operands are final.  Every memory location receives its updates in the same order either way
+  // (rest(b - 1) is awaited before block b's update touches the same columns): identical results with and without the second stream.
+  hipStream_t side = (aux_stream && !(flags & 1) && Kp > 2 * IFAC_OUTER) ? inc_s(aux_stream) : s;
+  const bool two = side != s;
+  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  if (two && (hipEventCreateWithFlags(&ev_main, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_side, hipEventDisableTiming) != hipSuccess)) {
+    if (ev_main) (void)hipEventDestroy(ev_main);
+    return INC_ERR_LAUNCH;
+  }
   if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess) return INC_ERR_LAUNCH;
   // (X needs no initialisation: every product reads only blocks on or below the block diagonal, all written before they are read)
   {
@@ -288,22 +307,29 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
     ifac_flip_in_kernel<<<grid, 256, 0, s>>>(H, K, A, Kp);
   }
   int rc = INC_OK;
-  auto gemm = [&](const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t M, int64_t N, int64_t Kd, float alpha,
-                  float beta, int krange, bool lower_only, bool b_nt, int batch = 1, int64_t sa = 0, int64_t sb = 0, int64_t sc = 0) {
+  auto gemm = [&](hipStream_t st, const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t M, int64_t N, int64_t Kd,
+                  float alpha, float beta, int krange, bool lower_only, bool b_nt, int batch = 1, int64_t sa = 0, int64_t sb = 0, int64_t sc = 0) {
     GemmArgs g{a, b, c, lda, ldb, ldc, sa, sb, sc, (int)M, (int)N, (int)Kd, alpha, beta, krange, lower_only ? 1 : 0};
-    const int r = launch_f32gemm(g, b_nt, batch, s);
+    const int r = launch_f32gemm(g, b_nt, batch, st);
     if (r != INC_OK) rc = r;
   };
-  auto copy_panel = [&](const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int cols) {
+  auto copy_panel = [&](hipStream_t st, const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int cols) {
     const int64_t n4 = rows * (cols / 4);
-    ifac_copy_panel_kernel<<<(unsigned)std::min<int64_t>(ceil_div64(n4, 256), 2048), 256, 0, s>>>(src, lds_, dst, ldd, rows, cols);
+    ifac_copy_panel_kernel<<<(unsigned)std::min<int64_t>(ceil_div64(n4, 256), 2048), 256, 0, st>>>(src, lds_, dst, ldd, rows, cols);
   };
-  // X of the span covered by `segs` (whose diagonal blocks of X already hold the inverses) by recursive doubling:
-  //   inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]];  both factors of X21 = -X22 (C X11) are lower-triangular inverses
-  auto invert_by_doubling = [&](std::vector<Seg> segs) {
+  // one doubling step: inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]] for `batch` pairs (a_k, b_k) at a constant distance;
+  // both factors of X21 = -X22 (C X11) are lower-triangular inverses (K-ranges skip their zero halves)
+  auto merge_pairs = [&](hipStream_t st, Seg a, Seg b, int batch) {
+    const int64_t n1 = a.size, n2 = b.size, step = (a.size + b.size) * (ld + 1), ldt = Kp, tstep = (a.size + b.size) * ldt;
+    float* t0 = T + b.start * ldt;
+    gemm(st, A + b.start * ld + a.start, ld, X + a.start * ld + a.start, ld, t0, ldt, n2, n1, n1, 1.f, 0.f, KR_B_LOWER_NN, false, false, batch, step, step, tstep);
+    gemm(st, X + b.start * ld + b.start, ld, t0, ldt, X + b.start * ld + a.start, ld, n2, n1, n2, -1.f, 0.f, KR_A_LOWER, false, false, batch, step, tstep, step);
+  };
+  // X of the span covered by `segs` (whose diagonal blocks of X already hold the inverses), level by level; pairs of equal geometry
+  // at a constant distance go out as ONE batched launch per product
+  auto invert_by_doubling = [&](hipStream_t st, std::vector<Seg> segs) {
     while (segs.size() > 1) {
       std::vector<Seg> nxt;
-      // pairs of equal geometry at a constant distance go out as ONE batched launch per product
       size_t p = 0;
       const size_t npairs = segs.size() / 2;
       while (p < npairs) {
@@ -312,15 +338,7 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
         while (q < npairs && segs[2 * q].size == a.size && segs[2 * q + 1].size == b.size &&
                segs[2 * q].start - segs[2 * (q - 1)].start == a.size + b.size)
           ++q;
-        const int batch = (int)(q - p);
-        const int64_t n1 = a.size, n2 = b.size, step = (a.size + b.size) * (ld + 1);
-        const int64_t ldt = Kp;
-        float* t0 = T + b.start * ldt;
-        const int64_t tstep = (a.size + b.size) * ldt;
-        // T = C X11  (C = A[s2.., s1..] general n2 x n1, X11 lower: k >= n)
-        gemm(A + b.start * ld + a.start, ld, X + a.start * ld + a.start, ld, t0, ldt, n2, n1, n1, 1.f, 0.f, KR_B_LOWER_NN, false, false, batch, step, step, tstep);
-        // X21 = -X22 T  (X22 lower: k <= m)
-        gemm(X + b.start * ld + b.start, ld, t0, ldt, X + b.start * ld + a.start, ld, n2, n1, n2, -1.f, 0.f, KR_A_LOWER, false, false, batch, step, tstep, step);
+        merge_pairs(st, a, b, (int)(q - p));
         for (size_t r = p; r < q; ++r) nxt.push_back(Seg{segs[2 * r].start, segs[2 * r].size + segs[2 * r + 1].size});
         p = q;
       }
@@ -330,9 +348,14 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
     return segs[0];
   };
 
-  std::vector<Seg> top;
-  int tag = 0;
-  for (int64_t Bo = 0; Bo < Kp; Bo += IFAC_OUTER) {
+  struct Top {
+    Seg seg;
+    int level;
+  };
+  std::vector<Top> stack;  // inverted spans of the top level, merged like a binary counter as the outer blocks complete
+  int tag = 0, nblk = 0;
+  bool rest_pending = false;
+  for (int64_t Bo = 0; Bo < Kp; Bo += IFAC_OUTER, ++nblk) {
     const int64_t n2 = std::min<int64_t>(IFAC_OUTER, Kp - Bo);
     float* D = A + Bo * ld + Bo;
     float* XD = X + Bo * ld + Bo;
@@ -345,25 +368,69 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
         const int64_t m = n2 - (j + IFAC_NB);
         float* panel = D + (j + IFAC_NB) * ld + j;  // [m, 128]
         // L_panel = A_panel inv(L_jj)^T  (inv(L_jj) lower), in place: one 64 x 128 tile per row block
-        gemm(panel, ld, XD + j * ld + j, ld, panel, ld, m, IFAC_NB, IFAC_NB, 1.f, 0.f, KR_FULL, false, true);
+        gemm(s, panel, ld, XD + j * ld + j, ld, panel, ld, m, IFAC_NB, IFAC_NB, 1.f, 0.f, KR_FULL, false, true);
         // trailing update inside the outer block, lower triangle only
-        gemm(panel, ld, panel, ld, D + (j + IFAC_NB) * (ld + 1), ld, m, m, IFAC_NB, -1.f, 1.f, KR_FULL, true, true);
+        gemm(s, panel, ld, panel, ld, D + (j + IFAC_NB) * (ld + 1), ld, m, m, IFAC_NB, -1.f, 1.f, KR_FULL, true, true);
       }
     }
-    top.push_back(invert_by_doubling(inner));
-    if (Bo + n2 < Kp) {
-      const int64_t Mr = Kp - (Bo + n2);
+    const Seg whole = invert_by_doubling(s, inner);
+    float* P = Pb[nblk & 1];
+    const int64_t Mr = Kp - (Bo + n2);
+    if (Mr > 0) {
       float* panel = A + (Bo + n2) * ld + Bo;  // [Mr, n2]
-      gemm(panel, ld, XD, ld, P, IFAC_OUTER, Mr, n2, n2, 1.f, 0.f, KR_B_LOWER_NT, false, true);  // L_panel = A_panel inv(L_DD)^T
-      copy_panel(P, IFAC_OUTER, panel, ld, Mr, (int)n2);
-      gemm(P, IFAC_OUTER, P, IFAC_OUTER, A + (Bo + n2) * (ld + 1), ld, Mr, Mr, n2, -1.f, 1.f, KR_FULL, true, true);
+      gemm(s, panel, ld, XD, ld, P, IFAC_OUTER, Mr, n2, n2, 1.f, 0.f, KR_B_LOWER_NT, false, true);  // L_panel = A_panel inv(L_DD)^T
+      copy_panel(s, P, IFAC_OUTER, panel, ld, Mr, (int)n2);
+    }
+    if (two) (void)hipEventRecord(ev_main, s);  // the panel (P, written back) and this block's inverse are complete
+    // chain: the NEXT outer block's columns of the trailing update (everything, without a second stream)
+    float* Cn = A + (Bo + n2) * (ld + 1);  // trailing matrix [Mr, Mr]
+    const int64_t c1 = two ? std::min<int64_t>(IFAC_OUTER, Mr) : Mr;
+    if (Mr > 0) {
+      if (rest_pending) {
+        (void)hipStreamWaitEvent(s, ev_side, 0);  // rest(b - 1) accumulated into the same columns
+        rest_pending = false;
+      }
+      gemm(s, P, IFAC_OUTER, P, IFAC_OUTER, Cn, ld, c1, c1, n2, -1.f, 1.f, KR_FULL, true, true);
+      if (Mr > c1) gemm(s, P + c1 * IFAC_OUTER, IFAC_OUTER, P, IFAC_OUTER, Cn + c1 * ld, ld, Mr - c1, c1, n2, -1.f, 1.f, KR_FULL, false, true);
+    }
+    // second stream: the rest of the trailing update first (the chain waits for it one block later), then the top level: this block's
+    // inverse joins the stack and equal-level neighbours merge (their C operand -- L of the rows below the left span -- became
+    // final with the panel solves above; nothing on the chain reads these products)
+    if (two) (void)hipStreamWaitEvent(side, ev_main, 0);
+    if (Mr > c1) {
+      gemm(side, P + c1 * IFAC_OUTER, IFAC_OUTER, P + c1 * IFAC_OUTER, IFAC_OUTER, Cn + c1 * (ld + 1), ld, Mr - c1, Mr - c1, n2, -1.f, 1.f, KR_FULL, true, true);
+      (void)hipEventRecord(ev_side, side);
+      rest_pending = true;
+    }
+    stack.push_back(Top{whole, 0});
+    while (stack.size() > 1 && stack[stack.size() - 1].level == stack[stack.size() - 2].level) {
+      const Top b = stack.back();
+      stack.pop_back();
+      const Top a = stack.back();
+      stack.pop_back();
+      merge_pairs(side, a.seg, b.seg, 1);
+      stack.push_back(Top{Seg{a.seg.start, a.seg.size + b.seg.size}, a.level + 1});
     }
   }
-  invert_by_doubling(top);
+  // what is left on the stack merges right to left (the last spans are the shortest)
+  while (stack.size() > 1) {
+    const Top b = stack.back();
+    stack.pop_back();
+    const Top a = stack.back();
+    stack.pop_back();
+    merge_pairs(side, a.seg, b.seg, 1);
+    stack.push_back(Top{Seg{a.seg.start, a.seg.size + b.seg.size}, a.level + 1});
+  }
+  if (two) {
+    (void)hipEventRecord(ev_side, side);
+    (void)hipStreamWaitEvent(s, ev_side, 0);
+  }
   {
     dim3 grid((unsigned)std::min<int64_t>(ceil_div64(K, 256), 64), (unsigned)K);
     ifac_flip_out_kernel<<<grid, 256, 0, s>>>(X, Kp, U, K);
   }
+  if (ev_main) (void)hipEventDestroy(ev_main);
+  if (ev_side) (void)hipEventDestroy(ev_side);
   if (rc != INC_OK) return rc;
   INC_LAUNCH_RETURN();
 }

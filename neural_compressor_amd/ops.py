@@ -585,6 +585,29 @@ def probe_mfma_bf16(src, sink, blocks, iters):
     return flops.value
 
 
+_HIP_RT = None
+
+
+def cu_masked_stream(device, mask_words):
+    """A HIP stream restricted to the compute units whose bits are set (hipExtStreamCreateWithCUMask), as a torch stream; None when
+    the runtime refuses.  On the MI355X the 256 bits are 8 words of 32: word w = CU number w of every shader engine (measured with
+    inc_probe_mfma_bf16, scripts/cumask_probe.py: seven words set = 224 CUs, one CU per shader engine left free)."""
+    global _HIP_RT
+    import ctypes
+
+    try:
+        if _HIP_RT is None:
+            _HIP_RT = ctypes.CDLL("libamdhip64.so")
+        st = ctypes.c_void_p()
+        arr = (ctypes.c_uint32 * len(mask_words))(*mask_words)
+        with torch.cuda.device(device):
+            if _HIP_RT.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(mask_words), arr) != 0 or not st.value:
+                return None
+            return torch.cuda.ExternalStream(st.value, device=device)
+    except Exception:  # pragma: no cover - a runtime without the extension
+        return None
+
+
 def trace_marker(marker_id, device=None):
     """Phase boundary for kernel-trace timelines: an empty launch with Grid_Size_X = 64 * marker_id on the current stream."""
     with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
@@ -643,10 +666,10 @@ def gptq_inverse_factor(H, aux_stream=None):
     info = torch.empty(1, dtype=torch.int32, device=dev)
     wsb = int(lib.inc_gptq_inverse_factor_workspace_bytes(K))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    # (no record_stream for `aux_stream`: the call returns with the current stream ordered behind everything it issued on the second
+    # one, so the caching allocator's stream-ordered reuse of H / U / the workspace is already safe -- and record_stream would make
+    # every call hipMalloc a fresh 1.5 GB workspace at K = 11008)
     aux = aux_stream.cuda_stream if aux_stream is not None else None
-    if aux_stream is not None:
-        for t in (H, U, ws, info):
-            t.record_stream(aux_stream)
     with torch.cuda.device(dev):
         check(lib.inc_gptq_inverse_factor(_ptr(H), K, _ptr(U), _ptr(ws), wsb, _ptr(info), 0, _stream(), aux), "inc_gptq_inverse_factor")
     return U, info

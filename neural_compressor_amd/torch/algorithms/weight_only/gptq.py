@@ -143,9 +143,12 @@ def _lookahead_stream(device):
     return st
 
 
-# trailing-update chunks of outer block b under the factorisation of b+1, on a second stream.  OFF by default: alone on the chip a
-# K = 11008 factorisation gains 5 % (29.9 -> 28.3 ms, scripts/chol_trace.py), but inside a GPTQ step, where four factorisations and
-# the column loops already share the chip, the extra streams cost more than they hide (336-338 vs 327-328 ms per block, A/B on one box)
+# Look-ahead of the factorisation (the rest of every trailing update and the top-level doubling products on a second stream, underneath
+# the chain of diagonal blocks; bit-identical results, tests/test_gpu_parity.py).  OFF by default: the diagonal-block kernel needs a
+# whole CU's LDS, so it queues behind the workgroups of the GEMM running beside it -- K = 11008 alone measured 16.1 ms in a good run
+# and 25-33 ms in others against a steady 17.0 ms on one stream (scripts/chol_time.py; a second stream masked to 224 CUs with
+# hipExtStreamCreateWithCUMask, ops.cu_masked_stream, was slower still: 30 ms), and inside a GPTQ step four factorisations and the
+# column loops already share the chip.
 CHOL_LOOKAHEAD = os.environ.get("INC_MI355X_CHOL_LOOKAHEAD", "0") == "1"
 _CHOL_SIDE_STREAMS = {}
 
@@ -188,7 +191,9 @@ def inverse_cholesky_upper(H, check=True):
     if H.is_cuda and not CHOL_PYTHON:
         # the whole factorisation behind the C-ABI (csrc/ifac.hip): the same blocked algorithm with this library's own fp32 MFMA
         # GEMMs instead of torch.mm.  INC_MI355X_CHOL_PYTHON=1 keeps the Python + torch.mm form below (its A/B partner in the tests).
-        U, info = ops.gptq_inverse_factor(H.contiguous())
+        # (second stream: the rest of the trailing updates and the top-level doubling products run underneath the chain of diagonal
+        # blocks -- same results as one stream, INC_MI355X_CHOL_LOOKAHEAD=0 keeps everything on the calling stream)
+        U, info = ops.gptq_inverse_factor(H.contiguous(), aux_stream=_chol_side_stream(H.device) if CHOL_LOOKAHEAD else None)
         if not check:
             return U, info
         raise_if_not_spd(info)

@@ -10,7 +10,7 @@ import neural_compressor_amd.torch.algorithms.weight_only.gptq as G  # noqa: E40
 
 
 def main():
-    forms = ("cabi", "python")
+    forms = ("cabi", "cabi1", "python")  # cabi1: one stream (no look-ahead)
     args = sys.argv[1:]
     if "--form" in args:
         i = args.index("--form")
@@ -28,6 +28,7 @@ def main():
         first = None
         for form in forms:
             G.CHOL_PYTHON = form == "python"
+            G.CHOL_LOOKAHEAD = form == "cabi"
             U = G.inverse_cholesky_upper(H)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

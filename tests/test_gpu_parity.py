@@ -703,6 +703,17 @@ def test_inverse_factor_cabi_matches_the_python_form(hip, monkeypatch):
     assert int(info.item()) == 0
     assert float((Uc - Up).abs().max() / Up.abs().max()) <= 2e-5
     assert torch.equal(Uc, torch.triu(Uc))
+    # the look-ahead form (second stream) gives every memory location its updates in the same order: identical bits
+    side = torch.cuda.Stream(device=hip)
+    for Kb in (K, 3456):  # 3456 = 27 leaf blocks: four outer blocks, three top-level merges
+        Xb = torch.randn(2 * Kb, Kb, generator=g)
+        Hb = ((2.0 / Xb.shape[0]) * Xb.T @ Xb)
+        Hb += 0.01 * Hb.diagonal().mean() * torch.eye(Kb)
+        Hb = Hb.to(hip)
+        U1, _ = ops.gptq_inverse_factor(Hb)
+        U2, i2 = ops.gptq_inverse_factor(Hb, aux_stream=side)
+        torch.cuda.synchronize()
+        assert int(i2.item()) == 0 and torch.equal(U1, U2), Kb
     ws = torch.empty(1024, dtype=torch.uint8, device=hip)
     out = torch.empty_like(H)
     rc = _lib.lib.inc_gptq_inverse_factor(H.data_ptr(), K, out.data_ptr(), ws.data_ptr(), 1024, info.data_ptr(), 0, None, None)
