@@ -631,6 +631,8 @@ def main():
     clock.wrap(ops, "gptq_quantize_layer", lambda w, *a, **k: f"quantize_layer_{w.shape[0]}x{w.shape[1]}",
                lambda w, *a, **k: float(w.shape[0]) * w.shape[1] * (128 + w.shape[1]))
 
+    # float weights of the last block the timed region quantises (the sanity check after the timed region compares against them)
+    float_w = {} if layer_mode else {n: m.weight.data.clone() for n, m in blocks[args.warmup + args.steps - 1].named_modules() if isinstance(m, torch.nn.Linear)}
     with torch.no_grad():
         def step(i):  # exact / single GPU: one block; layer: one round = `world` blocks, one per rank
             if layer_mode:
@@ -663,6 +665,24 @@ def main():
         elapsed = time.perf_counter() - t0
         clock.enabled = False
     note(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
+    # sanity of what the timed steps produced (several streams share the work: a lifetime bug would show up as garbage, not as an error):
+    # every packed module of the last quantised block dequantises to finite values near its float weight
+    sanity = None
+    if not layer_mode:
+        from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+        ref = float_w
+        worst = 0.0
+        for name, m in blocks[args.warmup + args.steps - 1].named_modules():
+            if isinstance(m, MI355XWeightOnlyLinear):
+                w = m.recover().float()
+                w0 = ref[name].float()
+                rel = float((w - w0).norm() / w0.norm())
+                worst = max(worst, rel if bool(torch.isfinite(w).all()) else float("inf"))
+        sanity = dict(last_block_max_rel_weight_error=round(worst, 4), ok=bool(worst < 0.25))
+        if not sanity["ok"]:
+            raise SystemExit(f"bench: the last quantised block does not dequantise near its float weights ({sanity}): refusing to report a time")
+        del ref
     mem1 = torch.cuda.memory_stats(device)
     # caching-allocator activity inside the timed region: hipMalloc / hipFree calls reach the driver only through "segment" events
     allocator = {k: int(mem1.get(v, 0) - mem0.get(v, 0)) for k, v in (("hipMalloc_calls", "num_device_alloc"), ("hipFree_calls", "num_device_free"),
@@ -725,7 +745,7 @@ def main():
                                  f"ONE model on {world} ranks: samples sharded {world}-way, Hessians reduced to owner ranks + factor broadcast "
                                  "(RCCL), row-sharded column loop + all-gather; exact reference semantics"),
                     steps_per_model=steps_per_model),
-        roofline=roofline, kernel_breakdown=breakdown, allocator=allocator,
+        roofline=roofline, kernel_breakdown=breakdown, allocator=allocator, sanity=sanity,
     )
     if round_timing:
         result["layer_round_ms"] = {k.replace("_s", ""): round(v * 1e3 / args.steps, 2) for k, v in round_timing.items() if k != "_"}

@@ -491,6 +491,8 @@ class HessianAccumulator:
         H = self.H
         if H is None:  # no calibration data reached this layer: H = 0 -> every column is "dead" (H = I after the fix)
             H = torch.zeros((self.columns, self.columns), dtype=torch.float32, device=self.device)
+        elif H.is_cuda:
+            H.record_stream(torch.cuda.current_stream(H.device))  # accumulated on the main stream, consumed (and dropped) on this one
         dead = ops.gptq_hessian_finalize(H, percdamp)
         perm = None
         if act_order:
@@ -530,7 +532,10 @@ class HessianAccumulator:
         """Raise if the (deferred) factorisation met a non-positive pivot; one host synchronisation."""
         if self._info is not None:
             info, self._info = self._info, None
-            raise_if_not_spd(info)
+            try:
+                raise_if_not_spd(info)
+            except torch.linalg.LinAlgError as e:
+                raise torch.linalg.LinAlgError(f"{e} [Hessian of {self.columns} columns, {self.nsamples} calibration batches]") from None
 
     # -- mode "sample+rows" (neural_compressor_amd/distributed.py) ------------------------------------------------------
     def reduce_to_owner(self, ctx, owner, n_total):
@@ -1625,6 +1630,12 @@ class RAWGPTQuantizer(object):
             def solve(names):
                 sv = solvers[names[0]]
                 cfg = sv.cfg
+                if names is late:
+                    # the float weights were allocated on the main stream and are DROPPED below (replaced by Q) while the late stream
+                    # has not read them yet: tell the allocator, or the main stream recycles the block under the late solve's feet
+                    # (seen as NaN Hessians one block later)
+                    for n in names:
+                        layers[n].weight.data.record_stream(torch.cuda.current_stream(self.device))
                 if len(names) == 1:
                     W = layers[names[0]].weight.data
                 else:
