@@ -105,12 +105,21 @@ def _pmc_traffic(key):
     return None, None
 
 
+WORKLOADS = {
+    # name: (hidden, ffn, heads, kv heads, blocks of the whole model, BASELINE.json config it stands for)
+    "llama2-7b": (4096, 11008, 32, 32, 32, "Llama-2-7B GPTQ INT4 group_size=128 sym, 128 calib samples, 1 MI355X (configs[1], the headline)"),
+    "llama2-70b": (8192, 28672, 64, 8, 80, "Llama-2-70B GPTQ INT4 g128, layers sharded across 8xMI355X (configs[4]); one block per step here"),
+}
+WORKLOAD = "llama2-7b"
+
+
 def build_model(n_layers, device):
     from transformers import LlamaConfig, LlamaForCausalLM
 
+    hidden, ffn, heads, kv, _, _ = WORKLOADS[WORKLOAD]
     cfg = LlamaConfig(
-        hidden_size=4096, intermediate_size=11008, num_hidden_layers=n_layers, num_attention_heads=32,
-        num_key_value_heads=32, vocab_size=32000, max_position_embeddings=4096, rms_norm_eps=1e-5,
+        hidden_size=hidden, intermediate_size=ffn, num_hidden_layers=n_layers, num_attention_heads=heads,
+        num_key_value_heads=kv, vocab_size=32000, max_position_embeddings=4096, rms_norm_eps=1e-5,
         tie_word_embeddings=False,
     )
     torch.manual_seed(0)
@@ -151,6 +160,30 @@ def bench_dequant_gemm(device, shapes, iters=20):
             torch.cuda.synchronize()
             batches.append(e0.elapsed_time(e1) / iters)
         ms = sorted(batches)[1]
+        dense_ms = None
+        if M >= 1024:
+            # the library's DENSE bf16 GEMM (hipBLASLt through torch) on the same shape, in the same process and thermal state, timed in
+            # alternation with the fused kernel: the yardstick VERDICT r3 asks for (a reference point, not a product path)
+            wd = torch.randn(N, K, device=device, dtype=torch.bfloat16) * 0.02
+            for _ in range(20):
+                torch.nn.functional.linear(x, wd)
+            fused, dense = [], []
+            for _ in range(3):
+                e0.record()
+                for _ in range(iters):
+                    m(x)
+                e1.record()
+                torch.cuda.synchronize()
+                fused.append(e0.elapsed_time(e1) / iters)
+                e0.record()
+                for _ in range(iters):
+                    torch.nn.functional.linear(x, wd)
+                e1.record()
+                torch.cuda.synchronize()
+                dense.append(e0.elapsed_time(e1) / iters)
+            ms = min(ms, sorted(fused)[1])
+            dense_ms = sorted(dense)[1]
+            del wd
         graph_ms = None
         if M <= 512:
             # launch-bound regime: the same `iters` calls captured once in a hipGraph and replayed -- what a decode loop does
@@ -187,6 +220,9 @@ def bench_dequant_gemm(device, shapes, iters=20):
         bound = "mfma" if M >= 128 else "hbm"
         row = dict(M=M, N=N, K=K, ms=round(ms, 4), tflops=round(tflops, 2), gbs=round(gbs, 1), bound=bound,
                    frac=round(tflops / BF16_MFMA_PEAK_TFLOPS if bound == "mfma" else gbs / HBM_PEAK_GBS, 4))
+        if dense_ms is not None:
+            row.update(hipblaslt_dense_bf16_ms=round(dense_ms, 4), hipblaslt_dense_bf16_tflops=round(flops / dense_ms / 1e9, 2),
+                       vs_hipblaslt_dense=round(dense_ms / ms, 4))
         if graph_ms is not None:
             row.update(graph_ms=round(graph_ms, 4), graph_tflops=round(flops / graph_ms / 1e9, 2), graph_gbs=round(bytes_ / graph_ms / 1e6, 1),
                        graph_frac=round((flops / graph_ms / 1e9) / BF16_MFMA_PEAK_TFLOPS if bound == "mfma" else (bytes_ / graph_ms / 1e6) / HBM_PEAK_GBS, 4))
@@ -556,7 +592,13 @@ def main():
     ap.add_argument("--no-per-layer", action="store_true")
     ap.add_argument("--mgpu-mode", choices=("layer", "exact"), default="layer", help="N > 1: one block per GPU on float activations (north_star) | exact reference semantics")
     ap.add_argument("--layer-on-one-gpu", action="store_true", help="N = 1: time the layer-per-GPU mode's round (float forward + quantise, no exchange)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="llama2-7b", help="llama2-70b: BASELINE config #5's block shape (hidden 8192, ffn 28672, GQA 64:8)")
     args = ap.parse_args()
+    global WORKLOAD
+    WORKLOAD = args.workload
+    if args.workload != "llama2-7b":
+        args.no_extra_configs = True  # (the AWQ / SmoothQuant block configs and the e2e model are 7B / 13B-shaped)
+        args.no_e2e = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain script: launch the N ranks ourselves (one process per GPU, RCCL) and hand their output through
         import socket
@@ -592,8 +634,9 @@ def main():
         # ONE model, N ranks.  layer: one block per rank on the float model's activations; exact: samples sharded, Hessians reduced to
         # their owner rank, factors broadcast, row-sharded solves
         os.environ["INC_MI355X_GPTQ_MULTI_GPU"] = "layer" if layer_mode else "sample+rows"
-    rccl_ranks = torch.distributed.get_world_size() if world > 1 else 1
     dist_backend = torch.distributed.get_backend() if world > 1 else None
+    # ranks that really are one process per GPU over RCCL ("nccl"); null when the ranks talk gloo (test runs sharing one device)
+    rccl_ranks = (torch.distributed.get_world_size() if dist_backend == "nccl" else None) if world > 1 else 1
 
     n_blocks = (args.warmup + args.steps) * (world if layer_mode else 1)
     note(f"building {n_blocks}-block Llama-2-7B-shaped model on {device}")
@@ -692,8 +735,10 @@ def main():
     elapsed = D.barrier_max_time(elapsed, device=device)
     ms_per_step = elapsed * 1e3 / args.steps
     # whole job = a 32-block model.  exact / single GPU: 32 steps (N ranks work on the SAME block); layer: ceil(32 / N) rounds
-    steps_per_model = -(-32 // world) if layer_mode else 32
+    hidden, ffn, heads, kv_heads, model_blocks, baseline_cfg = WORKLOADS[WORKLOAD]
+    steps_per_model = -(-model_blocks // world) if layer_mode else model_blocks
     value = steps_per_model * elapsed / args.steps
+    value_is = f"{steps_per_model} x the timed step"
 
     kern = clock.summary()
     breakdown = {k: dict(launches=v["launches"], total_ms=round(v["total_ms"], 3), avg_ms=round(v["avg_ms"], 4)) for k, v in kern.items()}
@@ -725,12 +770,13 @@ def main():
                              "algorithmic flops of EVERY Hessian launch of the timed region / their summed time")
 
     result = dict(
-        metric="llama2_7b_gptq_int4_g128_quantize_wall_clock", value=round(value, 3), unit="s", n_gpus=world, rccl_ranks=rccl_ranks,
+        metric=f"{WORKLOAD.replace('-', '_')}_gptq_int4_g128_quantize_wall_clock", value=round(value, 3), unit="s", n_gpus=world, rccl_ranks=rccl_ranks,
         dist_backend=dist_backend,
         steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 2), higher_is_better=False,
         scaling="strong", vs_baseline=None, dtype="bf16", data="synthetic",
-        config=dict(workload="Llama-2-7B GPTQ INT4 group_size=128 sym, 128 calib samples x 2048 tokens; step = one transformer block "
-                             "(7 Linears: 4x[4096,4096], 2x[11008,4096], 1x[4096,11008]); value = 32 blocks",
+        config=dict(workload=f"{WORKLOAD} GPTQ INT4 group_size=128 sym, {args.samples} calib samples x {args.seq} tokens; step = one transformer block "
+                             f"(7 Linears: q/o [{hidden},{hidden}], k/v [{hidden * kv_heads // heads},{hidden}], gate/up [{ffn},{hidden}], down [{hidden},{ffn}]); "
+                             f"value = {model_blocks} blocks", baseline_config=baseline_cfg,
                     samples=args.samples, seq_len=args.seq, block_size=128, percdamp=0.01,
                     capture_pass=("first forward of a block ends at its last hooked Linear (that Linear's own product and the residual add "
                                   "behind it only feed the output the reference computes and discards, gptq.py:690-702); "
@@ -753,9 +799,33 @@ def main():
     torch.cuda.empty_cache()
     if not args.no_e2e:
         result["e2e"] = bench_e2e(device, args, rank, world, note)
+        if world > 1 and result["e2e"]["blocks"] == model_blocks:
+            # N > 1: the whole job is what `e2e` ran -- capture on every rank, ceil(32 / N) rounds (or 32 sharded blocks), AND the
+            # broadcasts of the packed blocks at the end, max over ranks between two barriers.  The round time stays in ms_per_step.
+            result["value"] = result["e2e"]["wall_s"]
+            result["value_is"] = "e2e.wall_s: prepare -> capture -> all rounds -> packed-block broadcasts of the whole model (max over ranks)"
+            result["rounds_only_s"] = round(value, 3)
+    result.setdefault("value_is", value_is)
+    big = [(4096, 4096, 4096), (4096, 11008, 4096), (4096, 4096, 11008), (8192, 4096, 4096)]
+    if not args.no_gemm and world > 1:
+        # north_star: the 4096x4096 / 11008x4096 linears "at 1, 2, 4 and 8 GPUs": the forward does not shard, so every rank runs the
+        # four BASELINE shapes as a replica at the same time (replicas, reported separately); per-GPU and aggregate
+        torch.distributed.barrier()
+        mine_rows = bench_dequant_gemm(device, big)
+        t = torch.tensor([r["tflops"] for r in mine_rows], dtype=torch.float64, device="cpu" if dist_backend == "gloo" else device)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(gathered, t)
+        if rank == 0:
+            per = torch.stack(gathered).cpu()
+            result["dequant_gemm_replicas"] = [dict(M=m_, N=n_, K=k_, per_gpu_tflops=[round(float(v), 1) for v in per[:, i]],
+                                                    aggregate_tflops=round(float(per[:, i].sum()), 1),
+                                                    min_frac_of_bf16_peak=round(float(per[:, i].min()) / BF16_MFMA_PEAK_TFLOPS, 4))
+                                               for i, (m_, n_, k_) in enumerate(big)]
     if rank == 0 and not args.no_gemm:
-        shapes = [(4096, 4096, 4096), (4096, 11008, 4096), (4096, 4096, 11008), (8192, 4096, 4096)]
+        shapes = list(big)
         shapes += [(m, 4096, 4096) for m in (1, 16, 32, 64, 128, 256, 512)] + [(1, 11008, 4096), (1, 4096, 11008)]
+        if WORKLOAD == "llama2-70b":
+            shapes = [(4096, 8192, 8192), (4096, 28672, 8192), (4096, 8192, 28672), (1, 8192, 8192), (1, 28672, 8192), (1, 8192, 28672)]
         result["dequant_gemm"] = bench_dequant_gemm(device, shapes)
         note("dequant-GEMM shapes timed")
         result["w8a8_gemm"] = bench_w8a8_gemm(device, [(4096, 5120, 5120), (4096, 13824, 5120), (4096, 5120, 13824)])
@@ -767,8 +837,19 @@ def main():
         note("cpu baseline done")
     if rank == 0 and not args.no_per_layer:
         result["ceilings"] = bench_ceilings(device)
-        result["per_layer"] = bench_per_layer(device, result.get("cpu_baseline"))
+        if WORKLOAD == "llama2-7b":
+            result["per_layer"] = bench_per_layer(device, result.get("cpu_baseline"))
         note("ceilings + per-layer figures done")
+    if rank == 0 and result.get("roofline") and result.get("dequant_gemm"):
+        # the second half of BASELINE's metric next to the first, inside an object the driver's record keeps: fused INT4->bf16
+        # dequant-GEMM per shape against the spec peak, against the bare MFMA loop measured in this run, and against the library's
+        # dense bf16 GEMM timed in alternation with it
+        loop = (result.get("ceilings") or {}).get("bf16_mfma_loop_tflops")
+        result["roofline"]["dequant_gemm"] = [
+            dict(shape=f"{r['M']}x{r['N']}x{r['K']}", tflops=r["tflops"], frac_of_spec=r["frac"],
+                 frac_of_measured_mfma_loop=(round(r["tflops"] / loop, 4) if loop else None),
+                 hipblaslt_dense_bf16_tflops=r.get("hipblaslt_dense_bf16_tflops"), vs_hipblaslt_dense=r.get("vs_hipblaslt_dense"))
+            for r in result["dequant_gemm"] if r["M"] >= 1024]
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
