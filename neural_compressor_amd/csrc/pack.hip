@@ -59,11 +59,16 @@ __global__ void unpack_rows_kernel(const UT* __restrict__ packed, int16_t* __res
 // ------------------------------------------------------------------------------------------
 // optimum-format pack: int_weight [N,K] -> qweight [KW,N]
 // ------------------------------------------------------------------------------------------
+// ONE launch packs the whole module (round 4; three launches before): every workgroup transposes its 64 x 64 tile of packed words and
+// then converts its share of the group parameters -- the 64 output columns of its tile x the groups g = blockIdx.x, blockIdx.x +
+// gridDim.x, ... : scales [N,G] fp32 -> [G,N] fp16 and zp [N,G] (or the symmetric constant) -> qzeros [G,NW] holding zp - 1.
 template <int BITS, typename IN_T, bool VEC>
 __global__ __launch_bounds__(256) void woq_pack_qweight_kernel(const IN_T* __restrict__ iw,
                                                                uint32_t* __restrict__ qweight,
                                                                int64_t N, int64_t K, int64_t KW,
-                                                               int shift) {
+                                                               int shift, const float* __restrict__ scales, uint16_t* __restrict__ scales_out,
+                                                               const int32_t* __restrict__ zp, uint32_t* __restrict__ qzeros, int64_t G, int64_t NW,
+                                                               int zconst) {
   constexpr int NP = 32 / BITS;
   constexpr uint32_t MASK = (1u << BITS) - 1u;
   __shared__ uint32_t tile[TILE * TILE_LD];
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void woq_pack_qweight_kernel(const IN_T* __res
   const int64_t kw0 = (int64_t)blockIdx.x * TILE, n0 = (int64_t)blockIdx.y * TILE;
 
   const int64_t kw = kw0 + lane;
-#pragma unroll 4
+#pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
     const int row = wave * 16 + rr;
     const int64_t n = n0 + row;
@@ -107,37 +112,31 @@ __global__ __launch_bounds__(256) void woq_pack_qweight_kernel(const IN_T* __res
     const int64_t kwo = kw0 + kwl;
     if (kwo < KW && n < N) qweight[kwo * N + n] = tile[lane * TILE_LD + kwl];
   }
-}
-
-// zp [N,G] int32 (or NULL -> the symmetric zero point 2^(bits-1)) -> qzeros [G, NW] holding zp-1 packed along N
-__global__ void woq_pack_qzeros_kernel(const int32_t* __restrict__ zp, uint32_t* __restrict__ qzeros,
-                                       int64_t N, int64_t G, int64_t NW, int bits, int zconst) {
-  const int n_pack = 32 / bits;
-  const uint32_t mask = (1u << bits) - 1u;
-  const int64_t total = G * NW;
-  for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total;
-       w += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t g = w / NW, j = w - g * NW;
-    uint32_t word = 0;
-    for (int e = 0; e < n_pack; ++e) {
-      const int64_t n = j * n_pack + e;
-      if (n < N) {
-        const int32_t z = (zp ? zp[n * G + g] : zconst) - 1;
-        word |= (static_cast<uint32_t>(z) & mask) << (bits * e);
+  // group parameters of this tile's columns
+  const int ng = (int)((G - blockIdx.x + gridDim.x - 1) / gridDim.x);  // groups blockIdx.x, + gridDim.x, ... < G  (0 when blockIdx.x >= G)
+  if (scales_out) {
+    for (int i = threadIdx.x; i < ng * TILE; i += 256) {
+      const int64_t g = blockIdx.x + (int64_t)(i / TILE) * gridDim.x, nn = n0 + (i % TILE);
+      if (nn < N) scales_out[g * N + nn] = f32_to_f16_bits(scales[nn * G + g]);
+    }
+  }
+  if (qzeros) {
+    constexpr int WPT = TILE / NP;  // words of qzeros per group and tile
+    for (int i = threadIdx.x; i < ng * WPT; i += 256) {
+      const int64_t g = blockIdx.x + (int64_t)(i / WPT) * gridDim.x, j = n0 / NP + (i % WPT);
+      if (j < NW) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < NP; ++e) {
+          const int64_t nn = j * NP + e;
+          if (nn < N) {
+            const int32_t z = (zp ? zp[nn * G + g] : zconst) - 1;
+            word |= (static_cast<uint32_t>(z) & MASK) << (BITS * e);
+          }
+        }
+        qzeros[g * NW + j] = word;
       }
     }
-    qzeros[w] = word;
-  }
-}
-
-// scales [N,G] fp32 -> [G,N] fp16
-__global__ void woq_pack_scales_kernel(const float* __restrict__ s, uint16_t* __restrict__ out,
-                                       int64_t N, int64_t G) {
-  const int64_t total = G * N;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t g = i / N, n = i - g * N;
-    out[i] = f32_to_f16_bits(s[n * G + g]);
   }
 }
 
@@ -406,19 +405,21 @@ int inc_woq_pack(const void* int_weight, int in_bytes, const float* scales, cons
   const bool vec = in_bytes == 4 && (K % n_pack == 0) && (K % 4 == 0) &&
                    ((reinterpret_cast<uintptr_t>(int_weight) & 15) == 0);
   uint32_t* qw = reinterpret_cast<uint32_t*>(qweight);
+  const float* sc_in = (scales && scales_out) ? scales : nullptr;
+  uint16_t* sc_out = sc_in ? scales_out : nullptr;
+  uint32_t* qz = reinterpret_cast<uint32_t*>(qzeros);
+  const int zconst = 1 << (bits - 1);
+#define INC_PACK_ARGS qw, N, K, KW, shift, sc_in, sc_out, zp, qz, G, NW, zconst
 #define INC_PACK_LAUNCH(B)                                                                              \
   if (in_bytes == 4) {                                                                                  \
-    if (vec) woq_pack_qweight_kernel<B, int32_t, true><<<grid, 256, 0, s>>>((const int32_t*)int_weight, qw, N, K, KW, shift); \
-    else woq_pack_qweight_kernel<B, int32_t, false><<<grid, 256, 0, s>>>((const int32_t*)int_weight, qw, N, K, KW, shift);    \
+    if (vec) woq_pack_qweight_kernel<B, int32_t, true><<<grid, 256, 0, s>>>((const int32_t*)int_weight, INC_PACK_ARGS); \
+    else woq_pack_qweight_kernel<B, int32_t, false><<<grid, 256, 0, s>>>((const int32_t*)int_weight, INC_PACK_ARGS);    \
   } else {                                                                                              \
-    woq_pack_qweight_kernel<B, int8_t, false><<<grid, 256, 0, s>>>((const int8_t*)int_weight, qw, N, K, KW, shift);           \
+    woq_pack_qweight_kernel<B, int8_t, false><<<grid, 256, 0, s>>>((const int8_t*)int_weight, INC_PACK_ARGS);           \
   }
   if (bits == 4) { INC_PACK_LAUNCH(4) } else if (bits == 8) { INC_PACK_LAUNCH(8) } else { INC_PACK_LAUNCH(2) }
 #undef INC_PACK_LAUNCH
-  if (qzeros)
-    woq_pack_qzeros_kernel<<<grid_1d(G * NW), 256, 0, s>>>(zp, reinterpret_cast<uint32_t*>(qzeros), N, G, NW, bits, 1 << (bits - 1));
-  if (scales && scales_out)
-    woq_pack_scales_kernel<<<grid_1d(G * N), 256, 0, s>>>(scales, scales_out, N, G);
+#undef INC_PACK_ARGS
   INC_LAUNCH_RETURN();
 }
 

@@ -786,9 +786,12 @@ def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize
     sc = ref["scale"].repeat_interleave(K // G_, dim=1)
     zp = ref["zero"].repeat_interleave(K // G_, dim=1) if ref.get("zero") is not None else torch.full_like(sc, 8.0)
     ref_codes = torch.round(ref["Q"] / sc + zp).to(torch.int32)
-    same_rows = (a[0].cpu().to(torch.int32) == ref_codes).all(dim=1).float().mean()
+    rows_equal = (a[0].cpu().to(torch.int32) == ref_codes).all(dim=1)
+    same_rows = rows_equal.float().mean()
     assert float(same_rows) >= 0.97, float(same_rows)
-    assert rel_fro(a[1].cpu(), ref["scale"]) <= 1e-6
+    # a row whose code flipped at a tie carries a different W into its later groups (dynamic groups read "W as it is now"): the scales
+    # are compared where the codes agree -- there they are the same arithmetic on the same numbers
+    assert rel_fro(a[1].cpu()[rows_equal], ref["scale"][rows_equal]) <= 1e-6
 
 
 GQW_CASES = {
