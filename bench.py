@@ -471,6 +471,17 @@ def bench_per_layer(device, cpu):
     t_p = timed_gpu(lambda: m.pack(iw, sc, None, None))
     t_u = timed_gpu(lambda: m.unpack())
     t_r = timed_gpu(lambda: m.recover())
+    # the same three at 11008 x 4096 (2.7 x the bytes: the fixed cost of a launch weighs less)
+    N2 = 11008
+    w2 = torch.randn(N2, K, device=device) * 0.02
+    iw2, sc2, _ = quant_tensor(w2, bits=4, group_size=128, scheme="sym", return_int=True)
+    m2 = MI355XWeightOnlyLinear(K, N2, bits=4, group_size=128, device=device)
+    for key, fn, byts in (("pack_11008x4096", lambda: m2.pack(iw2, sc2, None, None), 4.0 * N2 * K + N2 * K / 2),
+                          ("unpack_11008x4096", lambda: m2.unpack(), N2 * K / 2 + 2.0 * N2 * K),
+                          ("recover_11008x4096", lambda: m2.recover(), N2 * K / 2 + 2.0 * N2 * K)):
+        t = timed_gpu(fn)
+        out[key] = dict(gpu_s=round(t, 6), cpu_s=None, gbs=round(byts / t / 1e9, 1), hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))
+    del w2, iw2, sc2, m2
     for key, t, byts, ck in (("quant_tensor_4096x4096", t_q, 2.0 * N * K * 4, "t_quant_tensor_4096"), ("pack_4096x4096", t_p, 4.0 * N * K + N * K / 2, "t_pack_4096"),
                              ("unpack_4096x4096", t_u, N * K / 2 + 2.0 * N * K, "t_unpack_4096"), ("recover_4096x4096", t_r, N * K / 2 + 2.0 * N * K, "t_recover_4096")):
         out[key] = dict(gpu_s=round(t, 6), cpu_s=c(ck), gbs=round(byts / t / 1e9, 1), hbm_frac=round(byts / t / 1e9 / HBM_PEAK_GBS, 4))

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void woq_unpack_qweight_kernel(const uint32_t*
   const int64_t kw0 = (int64_t)blockIdx.x * TILE, n0 = (int64_t)blockIdx.y * TILE;
   {
     const int64_t n = n0 + lane;
-#pragma unroll 4
+#pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
       const int kwl = wave * 16 + rr;
       const int64_t kw = kw0 + kwl;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void woq_unpack_qweight_kernel(const uint32_t*
   }
   __syncthreads();
   const int64_t kw = kw0 + lane;
-#pragma unroll 4
+#pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
     const int row = wave * 16 + rr;
     const int64_t n = n0 + row;
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
   constexpr int NP = 32 / BITS;
   constexpr uint32_t MASK = (1u << BITS) - 1u;
   constexpr int KWT = DQ_KT / NP;                      // packed rows per tile
-  constexpr int LD = DQ_KT + (DT == INC_F32 ? 1 : 8);  // padded row pitch (elements)
-  __shared__ OT tile[TILE * LD];
+  constexpr int LD = DQ_KT + (DT == INC_F32 ? 4 : 8);  // padded row pitch (elements): 16-byte aligned rows, 4-bank skew per row
+  __shared__ __attribute__((aligned(16))) OT tile[TILE * LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t k0 = (int64_t)blockIdx.x * DQ_KT, n0 = (int64_t)blockIdx.y * TILE;
   const int64_t kw0 = k0 / NP;
@@ -256,9 +256,11 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
       int64_t gprev = -1;
       float s = 0.f;
       int32_t z = 0;
+      OT vals[NP];
 #pragma unroll
       for (int e = 0; e < NP; ++e) {
         const int64_t k = kw * NP + e;
+        vals[e] = enc<DT>(0.f);
         if (k < K) {
           const int64_t g = g_idx ? (int64_t)g_idx[k] : k / group_size;
           if (g != gprev) {
@@ -269,8 +271,22 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
           }
           const int32_t q = (int32_t)((word >> (BITS * e)) & MASK);
           const float v = (float)(int8_t)(q - z) * s;  // exact in fp32, one rounding below
-          tile[lane * LD + kwl * NP + e] = enc<DT>(v);
+          vals[e] = enc<DT>(v);
         }
+      }
+      // the word's NP elements leave as 16-byte LDS writes (2-byte writes made this phase LDS-instruction-bound); rows are 16-byte
+      // aligned: LD * sizeof(OT) is a multiple of 16 and kwl * NP * sizeof(OT) too
+      constexpr int PER16 = 16 / (int)sizeof(OT);
+      if constexpr (NP % PER16 == 0) {
+#pragma unroll
+        for (int q4 = 0; q4 < NP / PER16; ++q4) {
+          uint4 pk;
+          __builtin_memcpy(&pk, &vals[q4 * PER16], 16);
+          *reinterpret_cast<uint4*>(&tile[lane * LD + kwl * NP + q4 * PER16]) = pk;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < NP; ++e) tile[lane * LD + kwl * NP + e] = vals[e];
       }
     }
   }
@@ -286,12 +302,13 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
     bool done = false;
     if constexpr (DT != INC_F32) {
       if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-        uint4 v;
-        v.x = (uint32_t)src[0] | ((uint32_t)src[1] << 16);
-        v.y = (uint32_t)src[2] | ((uint32_t)src[3] << 16);
-        v.z = (uint32_t)src[4] | ((uint32_t)src[5] << 16);
-        v.w = (uint32_t)src[6] | ((uint32_t)src[7] << 16);
-        *reinterpret_cast<uint4*>(dst) = v;
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);  // (16-byte aligned: c8 * 2 bytes, LD * 2 = 272)
+        done = true;
+      }
+    } else {
+      if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(src)[0];
+        reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(src)[1];
         done = true;
       }
     }
