@@ -260,6 +260,8 @@ def _nibble_match(a, b):
 # (block 0, block 1) code-match budgets: measured values minus a margin (see _parity_report)
 # measured on MI355X (profiles/r3_parity_report.txt): 1.00000 / 1.00000 for both configurations
 GPTQ_CODE_BUDGET = {"sym_g32": (0.9995, 0.995), "asym_g32": (0.9995, 0.995)}
+GPTQ_OPTION_BUDGET = {"true_seq": (0.9965, 0.974), "mse": (0.9995, 0.995)}   # measured 0.99778 / 0.97788 and 1.0 / 1.0
+GPTQ_OPTION_LOGITS = {"act_order": 6e-2, "true_seq": 3e-2, "mse": 1e-2}         # rel-Frobenius vs the reference's CPU logits
 
 
 def _parity_report(tag, mods, g, n_blocks=2):
@@ -373,14 +375,49 @@ def test_gptq_options_tiny_llama_vs_reference(tag, kw):
     else:
         first = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items() if ".layers.0." in n)
         worst = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items())
-        _parity_report(f"gptq_tiny_llama_{tag}", mods, g)
+        rep = _parity_report(f"gptq_tiny_llama_{tag}", mods, g)
         # mse: a grid argmin may land on the neighbouring point; true_sequential: the later groups of a block are calibrated
         # through the already PACKED q/k/v, whose fused kernel multiplies in fp16 where the reference's CPU module uses fp32
+        # (demonstrated by test_gptq_true_sequential_divergence_is_the_fp16_packed_forward).  Budgets = measured per block
+        # (profiles/r4/parity_report.txt: true_seq 0.99778 / 0.97788, mse 1.00000 / 1.00000) minus a margin
+        lo0, lo1 = GPTQ_OPTION_BUDGET[tag]
+        assert rep[0]["code_match"] >= lo0 and rep[1]["code_match"] >= lo1, rep
         assert first >= 0.95 and worst >= 0.88, (first, worst)
     with torch.no_grad():
         y = q(ids[0].to("cuda")).logits.float().cpu()
     ref = torch.from_numpy(g["logits"])
-    assert float((y - ref).norm() / ref.norm()) <= 6e-2
+    rel = float((y - ref).norm() / ref.norm())
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "parity_report.txt"), "a") as f:
+            f.write(f"gptq_tiny_llama_{tag}: logits rel-Frobenius vs the reference's CPU model {rel:.3e}\n")
+    except OSError:
+        pass
+    assert rel <= GPTQ_OPTION_LOGITS[tag], rel
+
+
+def test_gptq_true_sequential_divergence_is_the_fp16_packed_forward(monkeypatch):
+    """with true_sequential the later groups of a block see activations that went through the already packed
+    q/k/v.  Our packed forward multiplies in fp16 (fp32 accumulate), the reference's CPU module in fp32 -- the only arithmetic that
+    differs between the two pipelines at that point.  Referee: the SAME run with the packed modules' forward replaced (in this test
+    only) by the reference's CPU arithmetic -- fp16 recover(), widened, fp32 product on the un-rounded input.  The code agreement with the reference's golden model must then be
+    what the other options reach (>= 0.9995 / 0.995), i.e. the 0.978 of block 1 is the fp16 forward, nothing in the solver."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    def fp32_forward(self, x):  # reference modules.py:594-610 on the CPU: recover() in fp16 (the stored scale dtype), widened, fp32 product
+        w = self.recover(torch.float16).float()
+        y = torch.nn.functional.linear(x.float(), w, None if self.bias is None else self.bias.float())
+        return y.to(x.dtype) if x.dtype in (torch.float16, torch.bfloat16) else y
+
+    monkeypatch.setattr(MI355XWeightOnlyLinear, "forward", fp32_forward)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gptq_tiny_llama_true_seq.npz"))
+    ids = calib_ids()
+    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, block_size=128, use_sym=True, true_sequential=True))
+    for x in ids:
+        model(x)
+    q = convert(model)
+    rep = _parity_report("gptq_tiny_llama_true_seq_fp32_forward_referee", _woq_modules(q), g)
+    assert rep[0]["code_match"] >= 0.9995 and rep[1]["code_match"] >= 0.995, rep
 
 
 def test_gptq_prepare_convert_equals_quantize():
