@@ -878,320 +878,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #ifdef INC_KBENCH  // superseded by the direct-to-register kernel (gemm_d2r.hip); kept in the harness build as its bitwise A/B partner (tools/kbench d2r)
-constexpr int PC_THREADS = 768;
-
-// Epilogue of the producer / consumer kernel for a FULL 256 x 256 tile: the accumulator layout (a lane owns 4 consecutive
-// columns of 32 different rows) would leave as 8-byte pieces scattered over 32 rows per store instruction -- 1024 partial-line
-// accesses per wave, 14 us of the 120 us kernel at 4096^3 (tools/kbench pcablate).  Instead the consumers drop the converted
-// tile into LDS (the K-loop's stages are free; row pitch 528 B keeps the 8-byte writes at a 2-way bank conflict) and ALL
-// twelve waves stream it out as 16 bytes per lane, 32 lanes per 512-byte row.  Called by every wave of the workgroup
-// (producers pass acc == nullptr): two barriers, the first one also orders the last LDS-DMA pieces before the overwrite.
-constexpr int PC_CPITCH = TN * 2 + 16;
-template <bool IS_BF16>
-__device__ __forceinline__ void pc_store_tile(char* smem, const f32x16* acc, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
-                                              int64_t m0, int64_t n0, int64_t N, int wm, int wn, int lane, int tid, bool consumer) {
-  __builtin_amdgcn_s_barrier();  // every wave has drained its own DMA / loads (vmcnt(0) before the call): the stages are dead
-  if (consumer) {
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int nl = wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[e] = cvt16<IS_BF16>(bias[n0 + nl + e]);
-        }
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-          const f32x16& a = acc[nf * 4 + mf];
-          const int ml = wm * 128 + mf * 32 + (lane & 31);
-          *reinterpret_cast<uint2*>(smem + ml * PC_CPITCH + nl * 2) =
-              make_uint2(cvt_pair<IS_BF16>(a[4 * rq + 0] + bv[0], a[4 * rq + 1] + bv[1]), cvt_pair<IS_BF16>(a[4 * rq + 2] + bv[2], a[4 * rq + 3] + bv[3]));
-        }
-      }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  uint16_t* const ytile = y + m0 * N + n0;
-  for (int i = tid; i < TM * (TN / 8); i += PC_THREADS) {  // 16-byte chunk i: row i / 32, columns 8 * (i % 32) .. +7
-    const int row = i >> 5, c = i & 31;
-    const uint4 v = *reinterpret_cast<const uint4*>(smem + row * PC_CPITCH + c * 16);
-    *reinterpret_cast<uint4*>(ytile + (int64_t)row * N + c * 8) = v;
-  }
-}
-
-// ABL (harness build only, timing-only, WRONG results): bit 0 no dequant arithmetic, 1 no W ds_write, 2 no x LDS-DMA, 3 no W loads,
-// 4 no fragment reads, 5 no MFMA, 6 no per-step barrier, 7 no epilogue stores, 8 consumers at s_setprio 2, 9 producers at s_setprio 2
-template <bool IS_BF16, int ABL = 0>
-__global__ __launch_bounds__(PC_THREADS) void woq_gemm_w4_pc_kernel(
-    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight,
-    const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
-    const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int64_t M, int64_t N, int64_t K,
-    int64_t NW, int g_shift, int y_vec_ok, float* __restrict__ partial, int steps_per_split) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Abase = smem;                 // 3 stages
-  char* const Bbase = smem + 3 * T_ASTAGE;  // 2 stages
-  const int tiles_n = (int)((N + TN - 1) / TN);
-  const int tiles_m = (int)((M + TM - 1) / TM);
-  const int nwg = tiles_m * tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective XCD remap
-  }
-  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-  const int64_t m0 = (int64_t)tm * TM, n0 = (int64_t)tn * TN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nk_all = (int)(K / TK);
-  const int kbase = blockIdx.y * steps_per_split;
-  const int nk = min(steps_per_split, nk_all - kbase);  // even (K % 128 == 0, slabs of an even number of steps)
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  // full tiles of a 16-byte-aligned y leave through LDS (pc_store_tile): whole 512-byte rows per store instead of 8-byte pieces
-  const bool lds_epilogue = !partial && (y_vec_ok & 2) && m0 + TM <= M && n0 + TN <= N && (ABL & 128) == 0;
-
-  if (wave >= 8) {
-    // =========================================== PRODUCER (weights) ===========================================
-    if constexpr ((ABL & 512) != 0) __builtin_amdgcn_s_setprio(2);
-    const int pw = wave - 8;
-    const float inv_u = fp8_unit_inverse();
-    const int bcol = pw * 64 + lane;  // this thread's weight column of the tile: all 64 k of a step
-    int64_t ncol = n0 + bcol;
-    if (ncol > N - 1) ncol = N - 1;
-    uint32_t wvoff[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) wvoff[o] = (uint32_t)(((int64_t)o * N + ncol) * 4);
-    const uint32_t svoff = (uint32_t)(ncol * 2), zvoff = (uint32_t)((ncol / 8) * 4);
-    const int zshift = 4 * (int)(ncol % 8);
-    // LDS slot of octet o: [nf = bcol >> 5][kk = o >> 1][lane' = (bcol & 31) + 32 * (o & 1)] x 16 B
-    const uint32_t bdst0 = lds0 + 3 * T_ASTAGE + ((bcol >> 5) * 4 * 64 + (bcol & 31)) * 16;
-
-    auto issue_w = [&](int kt, uint32_t (&w)[8], uint32_t& sb, uint32_t& zw) {
-      if constexpr ((ABL & 8) != 0) {
-        asm volatile("" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7]), "=v"(sb), "=v"(zw));
-        return;
-      }
-      kt = kbase + (kt > nk - 1 ? nk - 1 : kt);
-      const uint32_t* wbase = qweight + (int64_t)kt * (TK / 8) * N;
-      const int64_t g = g_shift >= 0 ? (((int64_t)kt * TK) >> g_shift) : 0;
-      const uint16_t* sbase = scales + g * N;
-      const uint32_t* zbase = qzeros + g * NW;
-      asm volatile(
-          "s_nop 4\n\t"
-          "global_load_dword %0, %10, %20\n\t"
-          "global_load_dword %1, %11, %20\n\t"
-          "global_load_dword %2, %12, %20\n\t"
-          "global_load_dword %3, %13, %20\n\t"
-          "global_load_dword %4, %14, %20\n\t"
-          "global_load_dword %5, %15, %20\n\t"
-          "global_load_dword %6, %16, %20\n\t"
-          "global_load_dword %7, %17, %20\n\t"
-          "global_load_ushort %8, %18, %21\n\t"
-          "global_load_dword %9, %19, %22"
-          : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]), "=&v"(sb), "=&v"(zw)
-          : "v"(wvoff[0]), "v"(wvoff[1]), "v"(wvoff[2]), "v"(wvoff[3]), "v"(wvoff[4]), "v"(wvoff[5]), "v"(wvoff[6]), "v"(wvoff[7]),
-            "v"(svoff), "v"(zvoff), "s"(wbase), "s"(sbase), "s"(zbase)
-          : "memory");
-    };
-    // dequantise the 8 words of this thread's column and store each 16-byte fragment row right behind its arithmetic (the LDS
-    // store path then works under the next word's VALU instead of after all of it)
-    auto dequant_tile = [&](int bstage, const uint32_t (&w)[8], uint32_t sb, uint32_t zw) {
-      const float sc0 = f16_bits_to_f32((uint16_t)sb);
-      uint32_t zz = ((zw >> zshift) & 15u) + 1u;  // modules.py:407-410 (stored zp - 1; wraps above 15)
-      zz = zz > 15u ? 0u : zz;
-      const float nzs = -(float)zz * sc0;
-      const float sc = sc0 * inv_u;
-      const uint32_t dst = bdst0 + bstage * T_BSTAGE;
-#pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        const uint4 v = (ABL & 1) ? make_uint4(w[o], w[o] ^ __float_as_uint(sc), w[o], __float_as_uint(nzs)) : dequant8<IS_BF16, ((ABL & 1024) ? 1 : (ABL & 2048) ? 2 : 0)>(w[o], sc, nzs);
-        const u32x4 vv = {v.x, v.y, v.z, v.w};
-        if constexpr ((ABL & 2) != 0) asm volatile("" : : "v"(vv));
-        else asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(dst), "v"(vv), "n"(((o >> 1) * 64 + 32 * (o & 1)) * 16) : "memory");
-      }
-    };
-    // counted wait: a step issues 10 requests; "words" = the PREVIOUS step's 10 have returned (this step's 10 stay in flight)
-    auto wait_words = [&](uint32_t (&w)[8], uint32_t& sb, uint32_t& zw) {
-      if constexpr ((ABL & 8) != 0) {
-        asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(sb), "+v"(zw) : : "memory");
-        return;
-      }
-      asm volatile("s_waitcnt vmcnt(10)"
-                   : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(sb), "+v"(zw)
-                   :
-                   : "memory");
-    };
-
-    uint32_t wa[8], wsa, wza;  // tiles with ODD index
-    uint32_t wb[8], wsb, wzb;  // tiles with EVEN index >= 2
-    {
-      uint32_t w0[8], s0, z0;
-      issue_w(0, w0, s0, z0);
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w0[4]), "+v"(w0[5]), "+v"(w0[6]), "+v"(w0[7]), "+v"(s0), "+v"(z0)
-                   :
-                   : "memory");
-      dequant_tile(0, w0, s0, z0);
-    }
-    issue_w(1, wa, wsa, wza);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#define INC_PC_PSTEP(T, LW, LWS, LWZ, DW, DWS, DWZ)                      \
-  {                                                                      \
-    const int t_ = (T);                                                  \
-    issue_w(t_ + 2, LW, LWS, LWZ);                                       \
-    wait_words(DW, DWS, DWZ);                                            \
-    dequant_tile((t_ & 1) ^ 1, DW, DWS, DWZ);                            \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
-    if constexpr ((ABL & 64) == 0) __builtin_amdgcn_s_barrier();         \
-  }
-    for (int t0 = 0; t0 < nk; t0 += 2) {
-      INC_PC_PSTEP(t0, wb, wsb, wzb, wa, wsa, wza)       // even step: load tile t+2 (even) -> set B, dequantise tile t+1 (odd) <- set A
-      INC_PC_PSTEP(t0 + 1, wa, wsa, wza, wb, wsb, wzb)   // odd step: the reverse
-    }
-#undef INC_PC_PSTEP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads
-    if (lds_epilogue) pc_store_tile<IS_BF16>(smem, nullptr, bias, y, m0, n0, N, 0, 0, lane, tid, false);
-    return;
-  }
-
-  // =========================================== CONSUMER (x DMA + MFMA) ===========================================
-  if constexpr ((ABL & 256) != 0) __builtin_amdgcn_s_setprio(2);
-  const int wm = wave >> 2, wn = wave & 3;
-  uint32_t avoff[4];  // this wave's share of the x tile: LDS rows (wave*4+i)*8 .. +7, 16-byte chunk XOR-ed by (row >> 1) & 7
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int R = (wave * 4 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((R >> 1) & 7);
-    int64_t row = m0 + R;
-    if (row > M - 1) row = M - 1;  // rows past M are computed from a valid row and never stored
-    avoff[i] = (uint32_t)(((row - m0) * K + 8 * c) * 2);
-  }
-  const uint16_t* const xtile = x + m0 * K;
-  auto dma_piece = [&](int kt, int astage, int i) {
-    if constexpr ((ABL & 4) != 0) return;
-    kt = kbase + (kt > nk - 1 ? nk - 1 : kt);
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + astage * T_ASTAGE + (wave * 4 + i) * 1024);
-    lds_dma_1k(xtile + (int64_t)kt * TK, dst, avoff[i]);
-  };
-  f32x16 acc[2][4];  // [n-frag][m-frag]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  const int a_row = wm * 128 + (lane & 31);
-  const int a_sw = ((lane & 31) >> 1) & 7;
-  const int a_hi = lane >> 5;
-  const int b_off = (wn * 2 * 4 * 64 + lane) * 16;
-  // prologue: x tile 0 complete, tile 1 in flight (4 requests)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) dma_piece(0, 0, i);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < 4; ++i) dma_piece(1, 1, i);
-  __builtin_amdgcn_s_barrier();
-  for (int t = 0; t < nk; ++t) {
-    const char* As = Abase + (t % 3) * T_ASTAGE;
-    const char* Bs = Bbase + (t & 1) * T_BSTAGE + b_off;
-    const int nxt = (t + 2) % 3;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      uint4 xa[4], wbv[2];
-      const int chunk = ((2 * kk + a_hi) ^ a_sw) << 4;
-      if constexpr ((ABL & 16) != 0) {
-        asm volatile("" : "=v"(wbv[0].x), "=v"(wbv[0].y), "=v"(wbv[0].z), "=v"(wbv[0].w), "=v"(wbv[1].x), "=v"(wbv[1].y), "=v"(wbv[1].z), "=v"(wbv[1].w));
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) asm volatile("" : "=v"(xa[mf].x), "=v"(xa[mf].y), "=v"(xa[mf].z), "=v"(xa[mf].w));
-      } else {
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) wbv[nf] = *reinterpret_cast<const uint4*>(Bs + (nf * 4 + kk) * 1024);
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) xa[mf] = *reinterpret_cast<const uint4*>(As + (a_row + 32 * mf) * 128 + chunk);
-      }
-      dma_piece(t + 2, nxt, kk);  // one 1 KiB piece of x tile t+2 per k16 group: stage (t+2) % 3 was read last in step t-1
-#pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-          if constexpr ((ABL & 32) != 0) acc[nf][mf][0] += __uint_as_float(wbv[nf].x ^ xa[mf].y);
-          else acc[nf][mf] = mfma32<IS_BF16>(wbv[nf], xa[mf], acc[nf][mf]);
-        }
-    }
-    // x tile t+1 (this wave's 4 pieces, issued one step ago) has landed; this step's 4 stay in flight.  All fragment reads done.
-    if constexpr ((ABL & 4) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr ((ABL & 64) == 0) __builtin_amdgcn_s_barrier();
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail pieces
-  if constexpr ((ABL & 128) != 0) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) asm volatile("" : : "v"(acc[a][b]));
-    return;
-  }
-
-  if (lds_epilogue) {
-    pc_store_tile<IS_BF16>(smem, &acc[0][0], bias, y, m0, n0, N, wm, wn, lane, tid, true);
-    return;
-  }
-  // epilogue: D row i = n-offset (r&3) + 8*(r>>2) + 4*(lane>>5), col j = m-offset lane&31
-  if (partial) {  // split-K: raw fp32 tile into this split's slab (bias and conversion happen in the finalize kernel)
-    float* slab = partial + (int64_t)blockIdx.y * M * N;
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int64_t nb = n0 + wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-          const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
-          if (m >= M) continue;
-          float* dst = slab + m * N + nb;
-          if (nb + 4 <= N && (N % 4) == 0) {
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[nf][mf][4 * rq + 0], acc[nf][mf][4 * rq + 1], acc[nf][mf][4 * rq + 2], acc[nf][mf][4 * rq + 3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (nb + e < N) dst[e] = acc[nf][mf][4 * rq + e];
-          }
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int nf = 0; nf < 2; ++nf) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const int64_t nb = n0 + wn * 64 + nf * 32 + 8 * rq + 4 * (lane >> 5);
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (nb + e < N) bv[e] = cvt16<IS_BF16>(bias[nb + e]);
-      }
-#pragma unroll
-      for (int mf = 0; mf < 4; ++mf) {
-        const int64_t m = m0 + wm * 128 + mf * 32 + (lane & 31);
-        if (m >= M) continue;
-        const float v0 = acc[nf][mf][4 * rq + 0] + bv[0], v1 = acc[nf][mf][4 * rq + 1] + bv[1];
-        const float v2 = acc[nf][mf][4 * rq + 2] + bv[2], v3 = acc[nf][mf][4 * rq + 3] + bv[3];
-        uint16_t* dst = y + m * N + nb;
-        if ((y_vec_ok & 1) && nb + 4 <= N) {
-          *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pair<IS_BF16>(v0, v1), cvt_pair<IS_BF16>(v2, v3));
-        } else {
-          const float vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (nb + e < N) dst[e] = IS_BF16 ? f32_to_bf16_bits(vv[e]) : f32_to_f16_bits(vv[e]);
-        }
-      }
-    }
-  }
-}
+#include "../../tools/kbench_gemm_1.inc"
 #endif  // INC_KBENCH
 
 template <bool IS_BF16>
@@ -2056,67 +1743,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
       else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
     }
 #ifdef INC_KBENCH
-  } else if (big_ok && (K % 128) == 0 && (g_shift == -1 || g_shift >= 6) && (dbg == 0 || dbg == 42 || (dbg >= 51 && dbg <= 74)) && INC_GEMM_DEFAULT_PC) {
-    // producer / consumer specialisation of the 3A2B tile (one scale per column and K-step: group_size >= 64)
-    const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU
-    static std::atomic<uint64_t> pc_attr_set{0};
-    if (inc_attr_needed(pc_attr_set)) {
-      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_pc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_pc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      inc_attr_done(pc_attr_set);
-    }
-    const unsigned grid = (unsigned)(ceil_div64(M, TM) * ceil_div64(N, TN));
-    // bit 0: 8-byte stores possible; bit 1: 16-byte stores possible (full tiles then leave through LDS)
-    const int y_vec_ok = (((N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0)) ? 1 : 0) |
-                         (((N % 8 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0)) ? 2 : 0);
-    int steps = (int)(K / TK);
-    int splits = big_splitk(M, N, K, &steps);
-    float* part = nullptr;
-    if (splits > 1) {
-      if ((y_vec_ok & 1) && workspace && workspace_bytes >= WS_COUNTER_BYTES + (int64_t)splits * M * N * 4)
-        part = (float*)((char*)workspace + WS_COUNTER_BYTES);  // never touch the GEMV's arrival counters
-      else { splits = 1; steps = (int)(K / TK); }
-    }
-    dim3 g2(grid, (unsigned)splits);
-#define INC_PC(B, A) woq_gemm_w4_pc_kernel<B, A><<<g2, PC_THREADS, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok, part, steps)
-    if (!bf) INC_PC(false, 0);
-    // timing-only ablations of the producer / consumer step (tools/kbench pcablate)
-#define INC_PC_ABL(A) { INC_ALLOW_PC(A); INC_PC(true, A); }
-#define INC_ALLOW_PC(A) (void)hipFuncSetAttribute((const void*)woq_gemm_w4_pc_kernel<true, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
-    else if (dbg == 51) INC_PC_ABL(1)
-    else if (dbg == 52) INC_PC_ABL(3)
-    else if (dbg == 53) INC_PC_ABL(4)
-    else if (dbg == 54) INC_PC_ABL(8)
-    else if (dbg == 55) INC_PC_ABL(12)
-    else if (dbg == 56) INC_PC_ABL(15)
-    else if (dbg == 57) INC_PC_ABL(16)
-    else if (dbg == 58) INC_PC_ABL(31)
-    else if (dbg == 59) INC_PC_ABL(95)
-    else if (dbg == 60) INC_PC_ABL(32)
-    else if (dbg == 61) INC_PC_ABL(64)
-    else if (dbg == 62) INC_PC_ABL(48)       // producers alone (consumers neither read nor multiply)
-    else if (dbg == 63) INC_PC_ABL(49)
-    else if (dbg == 64) INC_PC_ABL(51)
-    else if (dbg == 65) INC_PC_ABL(52)
-    else if (dbg == 66) INC_PC_ABL(56)
-    else if (dbg == 67) INC_PC_ABL(60)
-    else if (dbg == 68) INC_PC_ABL(63)
-    else if (dbg == 69) INC_PC_ABL(128)      // no epilogue stores
-    else if (dbg == 70) INC_PC_ABL(256)      // consumers at raised priority
-    else if (dbg == 71) INC_PC_ABL(512)      // producers at raised priority
-    else if (dbg == 72) INC_PC_ABL(128 + 63) // nothing but prologue + barriers
-    else if (dbg == 73) INC_PC_ABL(1024)     // correct results: v_pk_fma_f32 in the dequantisation (the first generation)
-    else if (dbg == 74) INC_PC_ABL(2048)     // correct results: single v_cvt_f32_fp8 conversions
-#undef INC_PC_ABL
-#undef INC_ALLOW_PC
-    else INC_PC(true, 0);
-#undef INC_PC
-    if (part) {
-      int64_t rb = ceil_div64(M * N / 4, 256);
-      if (rb > 4096) rb = 4096;
-      if (bf) splitk_slab_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
-      else splitk_slab_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, splits);
-    }
+#include "../../tools/kbench_gemm_2.inc"
 #endif  // INC_KBENCH
   } else if (big_ok && (K % 128) == 0 && (dbg == 0 || dbg == 40 || dbg == 4 || dbg == 6 || (dbg >= 20 && dbg <= 30) || (dbg >= 31 && dbg <= 37))) {
     const size_t smem = (size_t)3 * T_ASTAGE + 2 * T_BSTAGE;  // 160 KiB: the whole LDS of a CU

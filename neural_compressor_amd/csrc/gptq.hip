@@ -209,142 +209,7 @@ __global__ __launch_bounds__(256) void hessian_syrk_16bit_kernel(const uint16_t*
 constexpr int H2 = 256;  // H tile edge of the 256 x 256 kernels
 
 #ifdef INC_KBENCH  // first 256 x 256 generation (operands transposed in registers): harness flag 45, A/B partner of the kernel below
-// ---- 16-bit inputs, 256x256 tile of H per workgroup (K >= 256) --------------------------------------
-// 512 threads = 8 waves as 2 (i) x 4 (j); a wave owns 128 x 64 of H = 4 x 2 MFMA 32x32x16 tiles.
-// Per 64-token step each thread fetches ONE 8(token) x 8(feature) block (eight 16-byte loads, the wave
-// covers 8 full 128-byte row segments per load), transposes it with 32 v_perm_b32 and writes eight
-// 16-byte [feature][8 tokens] rows.  LDS rows are [feature][64 tokens + 8 pad] (144 B pitch): the
-// 8-lane ds_write_b128 groups write one contiguous 128-byte row, and the ds_read_b128 fragment reads
-// (rows lane&31, pitch 9 x 16 B) hit 16 distinct bank slots per lane group -> both conflict-free.
-// Software pipeline: the block for step s+1 is fetched during step s-1/s, transposed and written to the
-// other LDS stage between the first and second MFMA group of step s; one barrier per step.
-constexpr int H2_OPER = H2 * HPITCH;       // elements per operand per stage
-constexpr int H2_STAGE = 2 * H2_OPER;      // elements per stage
-
-__device__ __forceinline__ void store_block_transposed_perm(uint16_t* lds, const uint4 (&r)[8]) {
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(&r[0]);  // w[token*4 + m]: features 2m, 2m+1 of that token
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    uint32_t lo[4], hi[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const uint32_t a = w[(2 * p) * 4 + m], b = w[(2 * p + 1) * 4 + m];  // tokens 2p, 2p+1
-      lo[p] = __builtin_amdgcn_perm(b, a, 0x05040100u);  // [a.lo16, b.lo16]: feature 2m,   tokens 2p, 2p+1
-      hi[p] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // [a.hi16, b.hi16]: feature 2m+1
-    }
-    *reinterpret_cast<uint4*>(lds + (2 * m) * HPITCH) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    *reinterpret_cast<uint4*>(lds + (2 * m + 1) * HPITCH) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-  }
-}
-
-// branch-free fetch of one 8(token) x 8(feature) block: addresses are clamped into the tensor (features
-// past K only feed rows/columns of H that are never stored; tokens past T are zeroed when TAIL)
-template <bool TAIL>
-__device__ __forceinline__ void load_block8x8_fast(const uint16_t* __restrict__ xf, int64_t T, int64_t ldx,
-                                                   int64_t t0, uint4 (&r)[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    int64_t t = t0 + i;
-    const bool ok = t < T;
-    if (TAIL && !ok) t = T - 1;
-    uint4 v = *reinterpret_cast<const uint4*>(xf + t * ldx);
-    if (TAIL) {
-      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-    }
-    r[i] = v;
-  }
-}
-
-// one 256x256 tile of  H <- beta*H + alpha*X^T X:  `block` of `nblocks` workgroups of ONE problem
-template <bool IS_BF16, bool TAIL>
-__device__ __forceinline__ void hessian_syrk_256_tile(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
-                                                      float* __restrict__ H, float beta, float alpha, int nt, int block, int nblocks) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  uint16_t* smem = reinterpret_cast<uint16_t*>(smem_raw);
-  int ti, tj;
-  xcd_supertile_decode(block, nblocks, nt, ti, tj);
-  const int64_t i0 = (int64_t)ti * H2, j0 = (int64_t)tj * H2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  // staging role: threads 0..255 fetch the i tile, 256..511 the j tile
-  const int oper = tid >> 8, tt = tid & 255;
-  const int t_chunk = tt & 7, f_chunk = tt >> 3;
-  int64_t fbase = (oper == 0 ? i0 : j0) + f_chunk * 8;
-  if (fbase > K - 8) fbase = K - 8;  // K % 8 == 0 on this path: the chunk is entirely outside -> clamp (results unused)
-  const uint16_t* const xf = x + fbase;
-  uint16_t* const wr_base = smem + oper * H2_OPER + (f_chunk * 8) * HPITCH + t_chunk * 8;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int nk = (int)((T + HK - 1) / HK);
-  uint4 regs[8];
-  load_block8x8_fast<TAIL>(xf, T, ldx, (int64_t)t_chunk * 8, regs);
-  store_block_transposed_perm(wr_base, regs);
-  load_block8x8_fast<true>(xf, T, ldx, (int64_t)HK + t_chunk * 8, regs);  // all-zero when there is no step 1
-  __syncthreads();
-
-  const int frag_off = (lane & 31) * HPITCH + 8 * (lane >> 5);
-  auto mma_step = [&](const uint16_t* As, const uint16_t* Bs, int kk) {
-    uint4 a[4], b[2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const uint4*>(As + (m * 32) * HPITCH + frag_off + kk * 16);
-#pragma unroll
-    for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const uint4*>(Bs + (n * 32) * HPITCH + frag_off + kk * 16);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) acc[m][n] = mfma16<IS_BF16>(a[m], b[n], acc[m][n]);
-  };
-
-  // steady state: no branches inside the step (the last two steps are peeled)
-  int kt = 0;
-  for (; kt + 2 < nk; ++kt) {
-    const int cur = kt & 1;
-    const uint16_t* As = smem + cur * H2_STAGE + (wm * 128) * HPITCH;
-    const uint16_t* Bs = smem + cur * H2_STAGE + H2_OPER + (wn * 64) * HPITCH;
-    mma_step(As, Bs, 0);
-    store_block_transposed_perm(wr_base + (cur ^ 1) * H2_STAGE, regs);
-    load_block8x8_fast<TAIL>(xf, T, ldx, (int64_t)(kt + 2) * HK + t_chunk * 8, regs);
-    __builtin_amdgcn_sched_barrier(0);  // keep the fetch up here: hipcc would sink it next to its use
-    mma_step(As, Bs, 1);
-    mma_step(As, Bs, 2);
-    mma_step(As, Bs, 3);
-    __syncthreads();
-  }
-  for (; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const uint16_t* As = smem + cur * H2_STAGE + (wm * 128) * HPITCH;
-    const uint16_t* Bs = smem + cur * H2_STAGE + H2_OPER + (wn * 64) * HPITCH;
-    mma_step(As, Bs, 0);
-    if (kt + 1 < nk) store_block_transposed_perm(wr_base + (cur ^ 1) * H2_STAGE, regs);
-    mma_step(As, Bs, 1);
-    mma_step(As, Bs, 2);
-    mma_step(As, Bs, 3);
-    __syncthreads();
-  }
-
-  // epilogue: D[row i][col j], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); 128-byte runs along j
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int64_t col = j0 + wn * 64 + n * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = i0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < K && col < K) {
-          float* p = H + row * K + col;
-          *p = beta * (*p) + alpha * acc[m][n][r];
-        }
-      }
-    }
-}
+#include "../../tools/kbench_gptq_1.inc"
 #endif  // INC_KBENCH
 
 // ---- 256x256 syrk tile, transpose-read generation (round 2) --------------------------------------------------------
@@ -1105,129 +970,7 @@ __global__ __launch_bounds__(256) void gptq_lazy_update_kernel(float* __restrict
 constexpr int L2T = 128;  // rows / columns of a lazy-update tile
 
 #ifdef INC_KBENCH  // superseded by the third generation below; harness flag 86, its bitwise A/B partner (tools/kbench colloop / qlayer)
-// ---------------------------------------------------------------------------------------------
-// lazy update, second generation: W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] with Err1 held in registers
-// ---------------------------------------------------------------------------------------------
-// 256 threads = 4 waves, each wave owns 32 rows of a 128-row panel and keeps its whole 32 x 128 slice of
-// Err1 as MFMA A-operands in 64 VGPRs for the lifetime of the workgroup.  The workgroup walks over the
-// 128-column tiles assigned to it (tile = chunk, chunk + nchunks, ...): the [128 k][128 col] fp32 tile of
-// Hinv arrives by LDS-DMA into one of two 64 KiB LDS buffers while the previous tile is being multiplied
-// (exact fp32 v_mfma_f32_32x32x2_f32: 256 per wave per tile), the W tile is fetched into registers at the
-// start of the tile and written back as W - acc at its end (same "sum, then subtract" order as before).
-template <bool UNUSED>
-__global__ __launch_bounds__(256) void gptq_lazy_update_v2_kernel(float* __restrict__ w, const float* __restrict__ Hinv,
-                                                                  const float* __restrict__ err, int64_t N, int64_t K,
-                                                                  int64_t i1, int64_t i2, int nchunks, int ncol_tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int chunk = blockIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.y * L2T + wave * 32;  // first row of this wave
-
-  // Err1 slice -> registers: a[s] = Err1[r0 + (lane&31)][2s + (lane>>5)]
-  float a[64];
-  {
-    int64_t row = r0 + (lane & 31);
-    if (row > N - 1) row = N - 1;
-    const float* ep = err + row * QB + (lane >> 5);
-#pragma unroll
-    for (int s = 0; s < 64; ++s) a[s] = ep[2 * s];
-  }
-  // DMA source offsets (bytes from Hinv + i1*K + c0): instruction j of this wave moves tile rows
-  // (wave*16 + j)*2 + (lane>>5), 16-byte chunk lane&31
-  const uint32_t rowoff = (uint32_t)(((wave * 32 + (lane >> 5)) * K) * 4);
-  const float* const hbase = Hinv + i1 * K;
-  auto dma_tile = [&](int ct, int buf) {
-    const int64_t c0 = i2 + (int64_t)ct * L2T;
-    int64_t col = c0 + 4 * (lane & 31);
-    if (col > K - 4) col = K - 4;  // partial last tile: clamped columns are never stored
-    const uint32_t v = rowoff + (uint32_t)(col * 4);
-    const uint32_t step = (uint32_t)(2 * K * 4);
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + buf * (L2T * L2T * 4) + wave * 16384);
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4)
-      lds_dma_4x1k(hbase, dst + q4 * 4096, v + (4 * q4) * step, v + (4 * q4 + 1) * step, v + (4 * q4 + 2) * step,
-                   v + (4 * q4 + 3) * step);
-  };
-
-  int ct = chunk;
-  if (ct >= ncol_tiles) return;
-  dma_tile(ct, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (; ct < ncol_tiles; ct += nchunks, cur ^= 1) {
-    const int64_t c0 = i2 + (int64_t)ct * L2T;
-    if (ct + nchunks < ncol_tiles) dma_tile(ct + nchunks, cur ^ 1);
-    // W tile -> registers (D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    float wt[4][16];
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      int64_t col = c0 + nf * 32 + (lane & 31);
-      if (col > K - 1) col = K - 1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row > N - 1) row = N - 1;
-        wt[nf][r] = w[row * K + col];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc[4];
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
-    const float* hs = reinterpret_cast<const float*>(smem_raw + cur * (L2T * L2T * 4)) + (lane >> 5) * L2T + (lane & 31);
-    // B operands are read from LDS one batch (8 k-steps x 4 column fragments) AHEAD of the MFMAs that use them:
-    // with one wave per SIMD nothing else hides the LDS latency (hipcc alone reads each pair just in time)
-    float bA[32], bB[32];
-    auto load_batch = [&](int g, float (&b)[32]) {
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8)
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) b[s8 * 4 + nf] = hs[(2 * (8 * g + s8)) * L2T + nf * 32];
-    };
-    auto mma_batch = [&](int g, const float (&b)[32]) {
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8)
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
-          acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[8 * g + s8], b[s8 * 4 + nf], acc[nf], 0, 0, 0);
-    };
-    load_batch(0, bA);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      load_batch(2 * p + 1, bB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_batch(2 * p, bA);
-      if (p < 3) load_batch(2 * p + 2, bA);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_batch(2 * p + 1, bB);
-    }
-    if (r0 + 32 <= N && c0 + L2T <= K) {  // wave-uniform: interior tile, unguarded stores
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        float* wp = w + (r0 + 4 * (lane >> 5)) * K + c0 + nf * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) wp[((r & 3) + 8 * (r >> 2)) * K] = wt[nf][r] - acc[nf][r];
-      }
-    } else {
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        const int64_t col = c0 + nf * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (row < N && col < K) w[row * K + col] = wt[nf][r] - acc[nf][r];
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-}
+#include "../../tools/kbench_gptq_2.inc"
 #endif  // INC_KBENCH
 
 // ---------------------------------------------------------------------------------------------
