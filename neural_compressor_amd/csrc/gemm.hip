@@ -1207,7 +1207,7 @@ constexpr int64_t STRIP_MAX_M = 1024;
 constexpr int STRIP_WAVES = 8;                                          // waves per workgroup: eighths of the K range
 constexpr int STRIP_RING = 3;                                           // operand slots (K-steps in flight) per wave
 constexpr int STRIP_SMEM_BYTES = STRIP_WAVES * STRIP_RING * 6 * 1024;   // 144 KiB: the operand rings; the epilogue reuses them
-static_assert(STRIP_SMEM_BYTES >= STRIP_WAVES * 64 * 68 * 4, "the reduction buffer (8 x 64 x 68 fp32) aliases the rings");
+static_assert(STRIP_SMEM_BYTES >= STRIP_WAVES * 64 * 68 * 4, "the reduction buffer (WAVES x 64 x 68 fp32) aliases the rings");
 
 template <bool IS_BF16, int WAVES, int RING>
 __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
@@ -1365,27 +1365,24 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
     }
   };
 
-  static_assert(RING == 3, "the loop below is unrolled over three parameter sets");
+  static_assert(RING >= 2 && 10 * (RING - 1) < 64, "vmcnt counts 63 requests at most");
   if (lo < hi) {
-    Par p0, p1, p2;
+    Par p[RING];  // (indexed by unrolled constants only: registers)
     Step t;
-    issue(0, p0, lo);
-    issue(1, p1, lo + 1);
-    issue(2, p2, lo + 2);
-#define INC_STRIP_STEP(ST, SLOTI, P) \
-  {                                  \
-    landed(P);                       \
-    fetch(t, SLOTI);                 \
-    refresh(P, ST);                  \
-    issue(SLOTI, P, (ST) + 3);       \
-    compute(t);                      \
-  }
-    for (int st = lo; st < hi; st += 3) {
-      INC_STRIP_STEP(st, 0, p0)
-      if (st + 1 < hi) INC_STRIP_STEP(st + 1, 1, p1)
-      if (st + 2 < hi) INC_STRIP_STEP(st + 2, 2, p2)
+#pragma unroll
+    for (int r = 0; r < RING; ++r) issue(r, p[r], lo + r);
+    for (int st = lo; st < hi; st += RING) {
+#pragma unroll
+      for (int r = 0; r < RING; ++r) {
+        if (st + r < hi) {
+          landed(p[r]);
+          fetch(t, r);
+          refresh(p[r], st + r);
+          issue(r, p[r], st + r + RING);
+          compute(t);
+        }
+      }
     }
-#undef INC_STRIP_STEP
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped prefetches past the end
   __syncthreads();                                   // every wave's ring is dead: the reduction buffer takes their place
@@ -1669,7 +1666,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   // 32 < M <= 64 on the larger layers too (M = 64, 11008 x 4096: 21 vs 29 us for the streaming kernel, whose x fragments are
   // per-lane 16-byte gathers; at 4096^2 the streaming kernel keeps a 1 us lead).  Harness flags 42 / 40 / 4 / 6 select the tile paths, 83 this kernel for any M > 16.
   const bool strip_ok = !g_idx && bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
-                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || dbg == 83);
+                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || dbg == 83 || dbg == 84);
   if (strip_ok) {
     int splitk = strip_splitk(M, N, K);
     const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);
@@ -1683,6 +1680,13 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     unsigned* counters = (unsigned*)workspace;
     float* part = splitk > 1 ? (float*)((char*)workspace + WS_COUNTER_BYTES) : nullptr;
     dim3 grid((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)splitk);
+#ifdef INC_KBENCH
+    if (bf && inc_small_tiles_flag(-1) == 84) {  // harness A/B: four waves (one per SIMD) with a six-deep ring
+      (void)hipFuncSetAttribute((const void*)woq_gemm_w4_strip_kernel<true, 4, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 6 * 1024);
+      woq_gemm_w4_strip_kernel<true, 4, 6><<<grid, 64 * 4, 4 * 6 * 6 * 1024, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, g_shift, splitk);
+      INC_LAUNCH_RETURN();
+    }
+#endif
     if (bf) woq_gemm_w4_strip_kernel<true, STRIP_WAVES, STRIP_RING><<<grid, 64 * STRIP_WAVES, STRIP_SMEM_BYTES, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, g_shift, splitk);
     else woq_gemm_w4_strip_kernel<false, STRIP_WAVES, STRIP_RING><<<grid, 64 * STRIP_WAVES, STRIP_SMEM_BYTES, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, g_shift, splitk);
     INC_LAUNCH_RETURN();

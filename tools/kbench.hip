@@ -431,11 +431,13 @@ static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, boo
   HIPCHECK(hipDeviceSynchronize());
   std::vector<float> href = ref.download();
   std::vector<uint16_t> hb = bias.download();
-  const int modes[3] = {M <= 64 ? 83 : 0, 42, M <= 64 ? 0 : 40};
-  const char* labels[3] = {"strip (LDS-DMA rings)", "PC 256-row tile + split-K", M <= 64 ? "streaming kernel (default)" : "3A2B 256-row tile + split-K"};
+  const int NV = 4;
+  const int modes[NV] = {M <= 64 ? 83 : 0, 42, M <= 64 ? 0 : 40, 84};
+  const char* labels[NV] = {"strip (LDS-DMA rings)", "PC 256-row tile + split-K", M <= 64 ? "streaming kernel (default)" : "3A2B 256-row tile + split-K",
+                            "strip, 4 waves x 6-deep ring"};
   int fails = 0;
   std::vector<uint16_t> first;
-  for (int mi = 0; mi < 3; ++mi) {
+  for (int mi = 0; mi < NV; ++mi) {
     inc_debug_set_small_tiles(modes[mi]);
     y.zero();
     for (int rep = 0; rep < 2; ++rep)  // twice: the arrival counters must have been re-armed
@@ -461,12 +463,12 @@ static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, boo
   if (time_it) {
     Timer t;
     const int rounds = 5, iters = 20;
-    std::vector<std::vector<float>> ms(3);
+    std::vector<std::vector<float>> ms(NV);
     for (int i = 0; i < 10; ++i)
       INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
     for (int r = 0; r < rounds; ++r)
-      for (int vi = 0; vi < 3; ++vi) {
-        const int mi = (vi + r) % 3;
+      for (int vi = 0; vi < NV; ++vi) {
+        const int mi = (vi + r) % NV;
         inc_debug_set_small_tiles(modes[mi]);
         INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
         t.start();
@@ -475,7 +477,7 @@ static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, boo
         ms[mi].push_back(t.stop_ms() / iters);
       }
     const double flops = 2.0 * M * N * K;
-    for (int mi = 0; mi < 3; ++mi) {
+    for (int mi = 0; mi < NV; ++mi) {
       std::sort(ms[mi].begin(), ms[mi].end());
       const float med = ms[mi][ms[mi].size() / 2];
       printf("  %-24s median %9.4f ms %8.1f TFLOP/s\n", labels[mi], med, flops / med / 1e9);
