@@ -611,6 +611,10 @@ def bench_awq_sq_blocks(device, note):
         dt = times[-1]
         out[tag] = dict(seconds_per_block=round(dt, 3), first_pass_s=round(times[0], 3), samples=n, seq_len=seq, hidden=dims[0],
                         ffn=dims[1], model_estimate_s=round(dt * (32 if tag == "awq_block" else 40), 1))
+        if tag == "awq_block":
+            out[tag]["floor"] = ("the block's time is 1.36e15 flop of GEMMs the reference's algorithm prescribes (20 whole-block forwards per multi-Linear "
+                                 "tuple + 20 / 10 Linear forwards per module, awq.py:341,454); going below needs the losses in Hessian form, which is "
+                                 "not the reference's bf16-rounded output MSE: a parity decision, not a kernel limit")
         note(f"{tag}: {dt:.2f}s (first pass {times[0]:.2f}s)")
     return out
 

@@ -415,6 +415,7 @@ struct HessianBatch {
   // `slab`), hessian_tail_finalize_kernel folds them into H.  nseg == 1: every tile is one workgroup (full == first[n]).
   int full, nseg;
   float* slab;
+  int block0;  // first workgroup of this launch (the call may issue its rounds of one-tile-per-CU as separate launches)
 };
 
 // token range of segment `seg` of `nseg`: whole TOK-token steps, the first (steps % nseg) segments one step longer
@@ -428,7 +429,8 @@ __device__ __forceinline__ void hessian_segment(int64_t T, int tok, int seg, int
 
 template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST>
 __global__ __launch_bounds__(512) void hessian_syrk_tr_256_multi_kernel(HessianBatch args, int64_t T) {
-  int b = (int)blockIdx.x, seg = 0;
+  const int gb = (int)blockIdx.x + args.block0;  // index in the whole call's grid
+  int b = gb, seg = 0;
   const bool split = b >= args.full;
   if (split) {  // a unit of the split tail: tile full + u / nseg, token range u % nseg
     const int u = b - args.full;
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(512) void hessian_syrk_tr_256_multi_kernel(HessianB
   } else {
     int64_t t0, tc;
     hessian_segment(T, TOK, seg, args.nseg, t0, tc);
-    float* slab = args.slab + ((int64_t)((int)blockIdx.x - args.full)) * (H2 * H2);
+    float* slab = args.slab + ((int64_t)(gb - args.full)) * (H2 * H2);
     if (tc > 0)
       hessian_syrk_tr_tile<IS_BF16, TOK, NST>(args.x[p] + t0 * args.ldx[p], tc, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p],
                                     args.nt[p], b - args.first[p], args.first[p + 1] - args.first[p], slab);
@@ -1269,6 +1271,7 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
   a.full = first;
   a.nseg = 1;
   a.slab = nullptr;
+  a.block0 = 0;
   hipStream_t s = inc_s(stream);
   // Tile quantisation: `first` equal tiles on `cus` CUs (one workgroup per CU: 132 KiB of LDS) run in ceil(first / cus) rounds; when the
   // last round fills less than half of the chip its tiles are cut into nseg = cus / tail token ranges, one workgroup each (a Llama
@@ -1326,8 +1329,24 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
       INC_LAUNCH_RETURN();
     }
 #endif
-    if (xdtype == INC_BF16) hessian_syrk_tr_256_multi_kernel<true><<<grid, 512, smem3, s>>>(a, T);
-    else hessian_syrk_tr_256_multi_kernel<false><<<grid, 512, smem3, s>>>(a, T);
+    // INC_MI355X_HESSIAN_ROUND_LAUNCHES=1 (A/B switch, read once): one launch per round of one-tile-per-CU instead of one launch
+    // for the whole grid -- the tiles of a round then START together, which bounds how far the tiles sharing X panels in an XCD's L2
+    // drift apart (every tile is computed exactly as before)
+    static const bool per_round = [] { const char* e = getenv("INC_MI355X_HESSIAN_ROUND_LAUNCHES"); return e && e[0] == '1'; }();
+    int cus = 256;
+    {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (cus <= 0 || (cus % 8) != 0) cus = 256;
+    }
+    const int chunk = per_round ? cus : grid;
+    for (int b0 = 0; b0 < grid; b0 += chunk) {
+      a.block0 = b0;
+      const int g = grid - b0 < chunk ? grid - b0 : chunk;
+      if (xdtype == INC_BF16) hessian_syrk_tr_256_multi_kernel<true><<<g, 512, smem3, s>>>(a, T);
+      else hessian_syrk_tr_256_multi_kernel<false><<<g, 512, smem3, s>>>(a, T);
+    }
     if (a.nseg > 1) hessian_tail_finalize_kernel<<<4 * (first - a.full), 512, 0, s>>>(a);
     INC_LAUNCH_RETURN();
   }

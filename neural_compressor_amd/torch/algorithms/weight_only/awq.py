@@ -718,6 +718,11 @@ class ActAwareWeightQuant:
                 h.remove()
         # a child whose output was modified in place later in the forward cannot be replayed
         rec = {n: [o for o, _ in lst] for n, lst in rec.items() if all(_versions(o) == v for o, v in lst)}
+        # ... and a child behind which no leaf module starts can never be part of a replayed prefix (the block's last child, e.g. the
+        # MLP): its recorded outputs -- one multi-GB tensor per stacked chunk at the BASELINE calibration size -- are dropped here
+        last_leaf = max((i for i, (kind, _) in enumerate(events) if kind == "leaf"), default=-1)
+        ends = {n: i for i, (kind, n) in enumerate(events) if kind == "end"}
+        rec = {n: lst for n, lst in rec.items() if ends.get(n, len(events)) < last_leaf}
         self._float_block = dict(block=block, outs=outs, events=events, rec=rec, leaves={id(m): n for n, m in leaves.items()})
         return outs
 
@@ -797,10 +802,11 @@ def _versions(obj):
 class _PrefixReplay:
     """Replays the recorded float outputs of `names` (direct children of `block`) during the grid forwards of one module tuple."""
 
-    _verified = set()  # (block class, replayed children): checked once per process against full forwards
-
     def __init__(self, owner, block, names, rec):
         self.owner, self.block, self.names, self.rec = owner, block, names, rec
+        # checked once per quantiser run (= per model) and set of replayed children against full forwards: another model with the same
+        # block class gets its own check
+        self.verified = owner.__dict__.setdefault("_replay_verified", set())
         self.key = (type(block).__qualname__, tuple(names))
         self.versions = {n: [_versions(o) for o in rec[n]] for n in names}
         self.saved = None
@@ -836,11 +842,11 @@ class _PrefixReplay:
         finally:
             self._unpatch()
         ok = self._intact()
-        if ok and self.key not in _PrefixReplay._verified:
+        if ok and self.key not in self.verified:
             full = evaluate()
             ok = len(full) == len(outs) and all(torch.equal(a, b) for (a, _), (b, _) in zip(full, outs))
             if ok:
-                _PrefixReplay._verified.add(self.key)
+                self.verified.add(self.key)
         if not ok:
             logger.warning("AWQ: replaying %s does not reproduce the full forward of %s; running the grid forwards in full",
                            self.names, self.key[0])

@@ -34,10 +34,11 @@ def _quantizer_with_block(n_samples=4):
 def test_prefix_replay_reproduces_full_forwards(monkeypatch, search_batch):
     monkeypatch.setenv("INC_MI355X_AWQ_SEARCH_BATCH", search_batch)
     q, block = _quantizer_with_block()
-    A._PrefixReplay._verified.clear()
     with torch.no_grad():
         org = q._float_block_outputs(block)
         assert q._float_block_outputs(block) is org  # once per block
+        # children behind which no leaf starts (the MLP: the block's last child) are not kept: they can never be a replayed prefix
+        assert set(q._float_block["rec"]) == {"input_layernorm", "self_attn", "post_attention_layernorm"}
         cases = (
             ([block.mlp.gate_proj, block.mlp.up_proj], ["input_layernorm", "self_attn", "post_attention_layernorm"]),
             ([block.self_attn.q_proj, block.self_attn.k_proj, block.self_attn.v_proj], ["input_layernorm"]),
