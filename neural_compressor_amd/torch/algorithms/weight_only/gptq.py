@@ -106,6 +106,7 @@ ONE_CALL = os.environ.get("INC_MI355X_GPTQ_ONE_CALL", "1") != "0"  # the column 
 # forward's stream wait for the solve when it gets there (attention + gate / up run underneath the factorisation).  Same launches,
 # same operands: bit-identical results.  INC_MI355X_GPTQ_LATE_SOLVE=0 keeps every solve in front of the second forward.
 LATE_SOLVE = os.environ.get("INC_MI355X_GPTQ_LATE_SOLVE", "1") == "1"
+LAYER_LOOKAHEAD = os.environ.get("INC_MI355X_GPTQ_LAYER_LOOKAHEAD", "1") == "1"  # mode "layer": next round's exchange under this round's solve
 _TRACE_RANGES = os.environ.get("INC_MI355X_TRACE_RANGES", "0") == "1"  # roctx ranges around the phases of a block (scripts/step_timeline.py)
 
 
@@ -1265,25 +1266,46 @@ class RAWGPTQuantizer(object):
             return now
 
         tp = mark("_", time.perf_counter()) if timing is not None else 0.0
-        round_blocks = list(range(start, min(start + world, len(blocks))))
-        # 1. float forwards of this rank's samples; block b's inputs are kept (the list entries are replaced, not overwritten)
-        kept = {}
-        for b in round_blocks:
-            blocks[b].to(self.device)
-            kept[b] = list(self._hidden_list())
-            if b + 1 < len(blocks) or self.quant_lm_head:
-                def replace(j, out):
-                    self._hidden_list()[j] = out
 
-                self._run_block(blocks[b], on_output=replace)
+        def rounds_blocks(first):
+            return list(range(first, min(first + world, len(blocks))))
+
+        def forwards(rb):
+            # float forwards of this rank's samples; block b's inputs are kept (the list entries are replaced, not overwritten)
+            kept = {}
+            for b in rb:
+                blocks[b].to(self.device)
+                kept[b] = list(self._hidden_list())
+                if b + 1 < len(blocks) or self.quant_lm_head:
+                    def replace(j, out):
+                        self._hidden_list()[j] = out
+
+                    self._run_block(blocks[b], on_output=replace)
+            return kept
+
+        def post(rb, kept):
+            mine_ = next((b for b in rb if owner_of_block(b, world) == rank), None)
+            if ctx is None:
+                return dict(start=rb[0], mine=mine_, full=kept[mine_])
+            pend = self._post_block_inputs(ctx, rb, kept, st["counts"], st["shape"], st["dtype"], st["exchange"], mine_)
+            pend.update(start=rb[0], mine=mine_)
+            return pend
+
+        round_blocks = rounds_blocks(start)
+        # 1. + 2. this round's inputs: posted by the previous call (look-ahead) or produced now
+        pend = st.pop("prefetched", None)
+        if pend is None or pend["start"] != start:
+            pend = post(round_blocks, forwards(round_blocks))
         tp = mark("forward_s", tp)
-        # 2. the inputs of block b -> rank b % world
-        mine = next((b for b in round_blocks if owner_of_block(b, world) == rank), None)
-        if ctx is None:
-            full = kept[mine]
-        else:
-            full = self._exchange_block_inputs(ctx, round_blocks, kept, st["counts"], st["shape"], st["dtype"], st["exchange"], mine)
-        del kept
+        # look-ahead (INC_MI355X_GPTQ_LAYER_LOOKAHEAD=0 disables): the NEXT round's float forwards run now and its block inputs are
+        # posted (batch_isend_irecv, asynchronous under RCCL) before this round's block is quantised, so they cross xGMI underneath the
+        # quantisation instead of in front of it.  Same forwards on the same data, same messages: identical results.
+        if ctx is not None and LAYER_LOOKAHEAD and start + world < len(blocks) and st["exchange"] == "scatter":
+            nxt = rounds_blocks(start + world)
+            st["prefetched"] = post(nxt, forwards(nxt))
+        mine = pend["mine"]
+        full = pend["full"] if "full" in pend else self._finish_block_inputs(ctx, pend, st["counts"])
+        del pend
         tp = mark("exchange_s", tp)
         # 3. quantise the own block on the whole calibration set
         if mine is not None:
@@ -1337,6 +1359,12 @@ class RAWGPTQuantizer(object):
         """Collective C3 of SURVEY 8: returns the inputs of this rank's block as a list of n_total [1, seq, hidden] tensors in global
         sample order (rank 0's samples first), or None when this rank owns no block of the round.  Shards travel as ONE message per
         (block, source rank): 2 GiB / world for Llama-2-7B at 128 x 2048 tokens."""
+        pend = self._post_block_inputs(ctx, round_blocks, kept, counts, shape, dtype, exchange, mine)
+        return pend["full"] if "full" in pend else self._finish_block_inputs(ctx, pend, counts)
+
+    def _post_block_inputs(self, ctx, round_blocks, kept, counts, shape, dtype, exchange, mine):
+        """First half of the exchange: post every send / receive of the round.  Returns {"full": ...} when the exchange completed here
+        (broadcast form), else the pending state `_finish_block_inputs` waits on."""
         import torch.distributed as dist
 
         from ....distributed import owner_of_block
@@ -1376,31 +1404,37 @@ class RAWGPTQuantizer(object):
                     if owner == rank and s != rank:
                         buf = buf.to(self.device) if staged else buf
                         parts[s] = [buf[i : i + 1] for i in range(counts[s])]
-        else:
-            ops, recvs, keep = [], {}, []
-            for b in round_blocks:
-                owner = owner_of_block(b, world)
-                if owner == rank:
-                    for s in range(world):
-                        if s != rank and counts[s] > 0:
-                            buf = torch.empty((counts[s],) + tuple(shape[1:]), dtype=dtype, device=dev)
-                            recvs[s] = buf
-                            ops.append(dist.P2POp(dist.irecv, buf, ctx._global(s), ctx.group))
-                elif counts[rank] > 0:
-                    x = shard_of(b)
-                    keep.append(x)
-                    ops.append(dist.P2POp(dist.isend, x, ctx._global(owner), ctx.group))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            if not staged:
-                torch.cuda.current_stream().synchronize()
-            for s, buf in recvs.items():
-                buf = buf.to(self.device) if staged else buf
-                parts[s] = [buf[i : i + 1] for i in range(counts[s])]
+            return dict(full=None if parts is None else [x for s in range(world) if counts[s] > 0 for x in parts[s]])
+        ops_, recvs, keep = [], {}, []
+        for b in round_blocks:
+            owner = owner_of_block(b, world)
+            if owner == rank:
+                for s in range(world):
+                    if s != rank and counts[s] > 0:
+                        buf = torch.empty((counts[s],) + tuple(shape[1:]), dtype=dtype, device=dev)
+                        recvs[s] = buf
+                        ops_.append(dist.P2POp(dist.irecv, buf, ctx._global(s), ctx.group))
+            elif counts[rank] > 0:
+                x = shard_of(b)
+                keep.append(x)
+                ops_.append(dist.P2POp(dist.isend, x, ctx._global(owner), ctx.group))
+        works = dist.batch_isend_irecv(ops_) if ops_ else []
+        return dict(works=works, recvs=recvs, keep=keep, parts=parts, staged=staged)
+
+    def _finish_block_inputs(self, ctx, pend, counts):
+        """Second half: wait for the posted messages and assemble the owner's sample list."""
+        for w in pend["works"]:
+            w.wait()
+        if not pend["staged"]:
+            torch.cuda.current_stream().synchronize()
+        parts = pend["parts"]
+        for s, buf in pend["recvs"].items():
+            buf = buf.to(self.device) if pend["staged"] else buf
+            parts[s] = [buf[i : i + 1] for i in range(counts[s])]
+        pend["keep"].clear()
         if parts is None:
             return None
-        return [x for s in range(world) if counts[s] > 0 for x in parts[s]]
+        return [x for s in range(ctx.world) if counts[s] > 0 for x in parts[s]]
 
     def _broadcast_packed_block(self, ctx, block, owner):
         """The packed modules of `block` from rank `owner` to every rank (C2's role in this mode: ~110 MiB per Llama-2-7B block)."""

@@ -966,7 +966,7 @@ def test_gptq_sample_sharded_two_ranks_equals_single_process():
     assert first >= 0.99 and worst >= 0.95, (first, worst)
 
 
-def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out):
+def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out, layers=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       INC_MI355X_GPTQ_MULTI_GPU=mode)
     import torch.distributed as dist
@@ -978,7 +978,7 @@ def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out):
     D.init_from_env(backend="gloo")
     ids = calib_ids()
     mine = D.shard_samples(len(ids), rank, world) if ("sample" in mode or mode == "layer") else range(len(ids))
-    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw))
+    model = prepare(tiny_llama(layers=layers), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw))
     rq = model.quantizer.gptq_quantizer
     assert (rq.layer_ctx if mode == "layer" else rq.dist_ctx) is not None
     for j in mine:
@@ -993,7 +993,7 @@ def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out):
     dist.destroy_process_group()
 
 
-def _spawn_multi_gpu(mode, cfg_kw):
+def _spawn_multi_gpu(mode, cfg_kw, layers=2):
     import socket
 
     import torch.multiprocessing as mp
@@ -1004,7 +1004,7 @@ def _spawn_multi_gpu(mode, cfg_kw):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_multi_gpu_worker, args=(2, port, mode, cfg_kw, out), nprocs=2, join=True)
+        mp.spawn(_multi_gpu_worker, args=(2, port, mode, cfg_kw, out, layers), nprocs=2, join=True)
         return {r: dict(v) for r, v in out.items()}
 
 
@@ -1068,12 +1068,12 @@ def test_gptq_sample_and_row_sharded_two_ranks():
     assert first >= 0.99 and worst >= 0.95, (first, worst)
 
 
-def _single_process_independent_blocks(cfg_kw):
+def _single_process_independent_blocks(cfg_kw, layers=2):
     """Mode "layer" in ONE process (prepare(..., independent_blocks=True)): every block calibrated on the float model's activations."""
     from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
 
     ids = calib_ids()
-    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw), independent_blocks=True)
+    model = prepare(tiny_llama(layers=layers), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw), independent_blocks=True)
     assert model.quantizer.gptq_quantizer.independent_blocks
     for x in ids:
         model(x)
@@ -1109,3 +1109,23 @@ def test_gptq_layer_per_gpu_two_ranks_is_bit_identical_to_single_process_given_t
         if ".layers.0." in n:
             for a, c in zip(single[n], exact[n]):
                 assert _same(a, c), n
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("lookahead", ["1", "0"])
+def test_gptq_layer_per_gpu_three_rounds_with_exchange_lookahead(lookahead, monkeypatch):
+    """Five blocks on two ranks = three rounds, the last one partial.  With the look-ahead (INC_MI355X_GPTQ_LAYER_LOOKAHEAD, default on)
+    a round's float forwards and the posting of its block inputs happen one call early, underneath the previous round's
+    quantisation: the messages and the arithmetic are the same, so both ranks must still hold exactly the one-process model."""
+    monkeypatch.setenv("INC_MI355X_GPTQ_LAYER_LOOKAHEAD", lookahead)
+    monkeypatch.setenv("INC_MI355X_GPTQ_ACT_EXCHANGE", "scatter")
+    cfg_kw = dict(use_sym=False)
+    res = _spawn_multi_gpu("layer", cfg_kw, layers=5)
+    single = _single_process_independent_blocks(cfg_kw, layers=5)
+    assert res[0].keys() == res[1].keys() == single.keys() and len(single) == 5 * 7 + 1
+    for n in single:
+        if n == "__logits__":
+            assert torch.equal(res[0][n], single[n]) and torch.equal(res[1][n], single[n])
+            continue
+        for a, b, c in zip(res[0][n], res[1][n], single[n]):
+            assert _same(a, c) and _same(b, c), n
