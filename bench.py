@@ -680,7 +680,9 @@ def main():
     # ranks that really are one process per GPU over RCCL ("nccl"); null when the ranks talk gloo (test runs sharing one device)
     rccl_ranks = (torch.distributed.get_world_size() if dist_backend == "nccl" else None) if world > 1 else 1
 
-    n_blocks = (args.warmup + args.steps) * (world if layer_mode else 1)
+    # (layer mode on N > 1 ranks: one more round of blocks than is timed -- every round also runs the NEXT round's float forwards and
+    # posts its exchange before it quantises, so the last timed round needs a successor to do the same work as the others)
+    n_blocks = (args.warmup + args.steps + (1 if (layer_mode and world > 1) else 0)) * (world if layer_mode else 1)
     note(f"building {n_blocks}-block Llama-2-7B-shaped model on {device}")
     model = build_model(n_blocks, device)  # same seed on every rank: the ranks hold replicas of the one model
     ids = calib_ids(args.samples, args.seq)
