@@ -1222,8 +1222,20 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int jn = lane & 15, oct = lane >> 4;
   const float inv_u = fp8_unit_inverse();
-  const int64_t n0 = (int64_t)blockIdx.x * COLS;
-  const int m0 = (int)blockIdx.y * ROWS;
+  // XCD-aware tile order: workgroup L (dispatch order: x fastest, then y) runs on XCD L % 8.  The tiles are renumbered so that an
+  // XCD owns a CONTIGUOUS range of (row strip, column strip) pairs, row strip major: the 32 column strips of one 64-row strip
+  // share that strip's x rows (512 KiB at K = 4096) out of ONE XCD's L2 instead of every XCD streaming the whole of x (4 MiB at
+  // M = 512, the size of an L2) from the Infinity Cache.
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  {
+    const int nx = (int)gridDim.x, nt = nx * (int)gridDim.y, L = by * nx + bx;
+    const int q = nt / 8, r = nt % 8, xcd = L % 8, idx = L / 8;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective (same form as the d2r kernel's)
+    by = t / nx;
+    bx = t - by * nx;
+  }
+  const int64_t n0 = (int64_t)bx * COLS;
+  const int m0 = by * ROWS;
   const int slice = blockIdx.z;
 
   int64_t ncol[NB];
@@ -1423,7 +1435,7 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
   // publish: every wave drains its write-through stores, then one relaxed agent-scope ticket from thread 0
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  unsigned* const counter = counters + (blockIdx.y * gridDim.x + blockIdx.x);
+  unsigned* const counter = counters + (by * gridDim.x + bx);
   if (tid == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = ticket == (unsigned)(splitk - 1);
