@@ -1209,7 +1209,8 @@ constexpr int STRIP_RING = 3;                                           // opera
 constexpr int STRIP_SMEM_BYTES = STRIP_WAVES * STRIP_RING * 6 * 1024;   // 144 KiB: the operand rings; the epilogue reuses them
 static_assert(STRIP_SMEM_BYTES >= STRIP_WAVES * 64 * 68 * 4, "the reduction buffer (WAVES x 64 x 68 fp32) aliases the rings");
 
-template <bool IS_BF16, int WAVES, int RING>
+// ABL (harness build only, timing-only, WRONG results): bit 0 no x requests, bit 1 no W requests, bit 2 no MFMA / dequantisation
+template <bool IS_BF16, int WAVES, int RING, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
@@ -1296,6 +1297,25 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
     const uint32_t* zb = qzeros + g * NW;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(ring0 + (uint32_t)slot * SLOT);
     uint32_t keep;
+    if constexpr (ABL & 3) {  // timing-only: the same ten-request step with some requests left out (vmcnt bookkeeping is by count, so
+                              // every omitted request is replaced by a 4-byte load of the parameter words)
+      asm volatile("s_mov_b32 %0, m0" : "=&s"(keep));
+#define INC_STRIP_REQ(COND, OFF, BASE, LDSOFF)                                                                                  \
+  if constexpr (COND) asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(OFF), "s"(BASE), "s"(dst), "i"(LDSOFF) : "memory", "scc"); \
+  else asm volatile("global_load_dword %0, %1, %2" : "=&v"(p.z[0]) : "v"(zoff[0]), "s"(zb) : "memory");
+      INC_STRIP_REQ((ABL & 1) == 0, xoff[0], xb, 0x0)
+      INC_STRIP_REQ((ABL & 1) == 0, xoff[1], xb, 0x400)
+      INC_STRIP_REQ((ABL & 1) == 0, xoff[2], xb, 0x800)
+      INC_STRIP_REQ((ABL & 1) == 0, xoff[3], xb, 0xc00)
+      INC_STRIP_REQ((ABL & 2) == 0, woff[0], wb, 0x1000)
+      INC_STRIP_REQ((ABL & 2) == 0, woff[1], wb, 0x1400)
+#undef INC_STRIP_REQ
+      asm volatile("global_load_dwordx2 %0, %4, %6\n\tglobal_load_dwordx2 %1, %5, %6\n\tglobal_load_dword %2, %7, %9\n\tglobal_load_dword %3, %8, %9\n\ts_mov_b32 m0, %10"
+                   : "=&v"(p.s[0]), "=&v"(p.s[1]), "=&v"(p.z[0]), "=&v"(p.z[1])
+                   : "v"(soff[0]), "v"(soff[1]), "s"(sb), "v"(zoff[0]), "v"(zoff[1]), "s"(zb), "s"(keep)
+                   : "memory");
+      return;
+    }
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_nop 4\n\t"
@@ -1391,7 +1411,7 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
           fetch(t, r);
           refresh(p[r], st + r);
           issue(r, p[r], st + r + RING);
-          compute(t);
+          if constexpr ((ABL & 4) == 0) compute(t);
         }
       }
     }
@@ -1678,7 +1698,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   // 32 < M <= 64 on the larger layers too (M = 64, 11008 x 4096: 21 vs 29 us for the streaming kernel, whose x fragments are
   // per-lane 16-byte gathers; at 4096^2 the streaming kernel keeps a 1 us lead).  Harness flags 42 / 40 / 4 / 6 select the tile paths, 83 this kernel for any M > 16.
   const bool strip_ok = !g_idx && bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
-                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || dbg == 83 || dbg == 84);
+                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || (dbg >= 83 && dbg <= 89));
   if (strip_ok) {
     int splitk = strip_splitk(M, N, K);
     const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);
@@ -1693,6 +1713,19 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     float* part = splitk > 1 ? (float*)((char*)workspace + WS_COUNTER_BYTES) : nullptr;
     dim3 grid((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)splitk);
 #ifdef INC_KBENCH
+    {
+      const int f = inc_small_tiles_flag(-1);
+      if (bf && f >= 85 && f <= 89) {  // harness: timing-only ablations of the strip step
+#define INC_STRIP_ABL(A)                                                                                                              \
+  {                                                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)woq_gemm_w4_strip_kernel<true, STRIP_WAVES, STRIP_RING, A>, hipFuncAttributeMaxDynamicSharedMemorySize, STRIP_SMEM_BYTES); \
+    woq_gemm_w4_strip_kernel<true, STRIP_WAVES, STRIP_RING, A><<<grid, 64 * STRIP_WAVES, STRIP_SMEM_BYTES, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, g_shift, splitk); \
+  }
+        if (f == 85) INC_STRIP_ABL(1) else if (f == 86) INC_STRIP_ABL(2) else if (f == 87) INC_STRIP_ABL(3) else if (f == 88) INC_STRIP_ABL(4) else INC_STRIP_ABL(7)
+#undef INC_STRIP_ABL
+        INC_LAUNCH_RETURN();
+      }
+    }
     if (bf && inc_small_tiles_flag(-1) == 84) {  // harness A/B: four waves (one per SIMD) with a six-deep ring
       (void)hipFuncSetAttribute((const void*)woq_gemm_w4_strip_kernel<true, 4, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 6 * 1024);
       woq_gemm_w4_strip_kernel<true, 4, 6><<<grid, 64 * 4, 4 * 6 * 6 * 1024, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, g_shift, splitk);

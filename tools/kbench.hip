@@ -1021,6 +1021,39 @@ int main(int argc, char** argv) {
     fails += run_d2r_case(4096, 4096, 11008, 128, true, false, true, false);
     fails += run_d2r_case(8192, 4096, 4096, 128, false, true, true, false);
   }
+  if (what == "stripabl") {  // timing-only ablations of the mid-M strip kernel (outputs are wrong by construction)
+    for (int64_t M : {128, 512}) {
+      const int64_t N = 4096, K = 4096;
+      Packed W(N, K, 128, true);
+      DevBuf<uint16_t> x((size_t)M * K), y((size_t)M * N);
+      std::vector<uint16_t> hx(x.n);
+      for (auto& v : hx) v = f2bf(rnd_normal());
+      x.upload(hx);
+      const int64_t wsb = inc_woq_gemm_workspace_bytes(M, N, K);
+      DevBuf<char> ws((size_t)(wsb > 0 ? wsb : 16));
+      ws.zero();
+      const int nv = 6, rounds = 5, iters = 20;
+      const int modes[nv] = {0, 85, 86, 87, 88, 89};
+      const char* labels[nv] = {"full step", "- x requests", "- W requests", "- x and W requests", "- dequant + MFMA", "- requests - dequant - MFMA"};
+      std::vector<std::vector<float>> ms(nv);
+      Timer t;
+      for (int r = 0; r < rounds; ++r)
+        for (int vi = 0; vi < nv; ++vi) {
+          const int mi = (vi + r) % nv;
+          inc_debug_set_small_tiles(modes[mi]);
+          INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, ws.p, wsb, nullptr));
+          t.start();
+          for (int i = 0; i < iters; ++i)
+            INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, nullptr, y.p, M, N, K, W.G, 128, 4, ws.p, wsb, nullptr));
+          ms[mi].push_back(t.stop_ms() / iters);
+        }
+      for (int mi = 0; mi < nv; ++mi) {
+        std::sort(ms[mi].begin(), ms[mi].end());
+        printf("STRIPABL M=%ld %-30s median %8.2f us\n", (long)M, labels[mi], ms[mi][ms[mi].size() / 2] * 1e3);
+      }
+      inc_debug_set_small_tiles(0);
+    }
+  }
   if (what == "d2rtl") {
     run_d2r_timeline(4096, 4096, 4096);
     run_d2r_timeline(4096, 4096, 11008);
