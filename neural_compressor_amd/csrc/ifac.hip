@@ -300,7 +300,11 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
     if (ev_main) (void)hipEventDestroy(ev_main);
     return INC_ERR_LAUNCH;
   }
-  if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess) return INC_ERR_LAUNCH;
+  if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess) {
+    if (ev_main) (void)hipEventDestroy(ev_main);
+    if (ev_side) (void)hipEventDestroy(ev_side);
+    return INC_ERR_LAUNCH;
+  }
   // (X needs no initialisation: every product reads only blocks on or below the block diagonal, all written before they are read)
   {
     dim3 grid((unsigned)std::min<int64_t>(ceil_div64(Kp, 256), 64), (unsigned)Kp);
