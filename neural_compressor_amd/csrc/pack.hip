@@ -257,12 +257,16 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
       float s = 0.f;
       int32_t z = 0;
       OT vals[NP];
+      // without g_idx a packed word lies inside ONE group whenever group_size % NP == 0: one division per word instead of a 64-bit
+      // division per element (eight per word: they were most of this kernel's time); other group sizes keep the per-element form
+      const bool word_in_group = (group_size % NP) == 0;
+      const int64_t gword = (kw * NP) / group_size;
 #pragma unroll
       for (int e = 0; e < NP; ++e) {
         const int64_t k = kw * NP + e;
         vals[e] = enc<DT>(0.f);
         if (k < K) {
-          const int64_t g = g_idx ? (int64_t)g_idx[k] : k / group_size;
+          const int64_t g = g_idx ? (int64_t)g_idx[k] : (word_in_group ? gword : k / group_size);
           if (g != gprev) {
             s = f16_bits_to_f32(scales[g * N + n]);
             uint32_t zz = ((qzeros[g * NW + n / NP] >> zsh) & MASK) + 1u;
