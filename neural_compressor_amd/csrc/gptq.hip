@@ -625,6 +625,44 @@ __global__ void gptq_prepare_weight_kernel(const void* __restrict__ w, float* __
     out[i] = (dead && dead[k]) ? 0.f : load_as_f32<DT>(w, i);
   }
 }
+// K % 8 == 0 and 16-byte aligned rows: eight consecutive k of one row per thread -- one 16-byte load of a 16-bit weight (two for
+// fp32), the eight `dead` flags as one 8-byte load, two 16-byte stores; the row / column split once per thread instead of a 64-bit
+// modulo per element
+template <int DT>
+__global__ __launch_bounds__(256) void gptq_prepare_weight_vec_kernel(const void* __restrict__ w, float* __restrict__ out,
+                                                                      const uint8_t* __restrict__ dead, int64_t N, int64_t K) {
+  const int64_t k8 = K >> 3, total = N * k8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / k8, c = (i - n * k8) << 3, base = n * K + c;
+    float v[8];
+    if constexpr (DT == INC_F32) {
+      const float4 a = reinterpret_cast<const float4*>(static_cast<const float*>(w) + base)[0];
+      const float4 b = reinterpret_cast<const float4*>(static_cast<const float*>(w) + base)[1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+      const uint4 q = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(w) + base);
+      const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (DT == INC_BF16) {
+          v[2 * e] = bf16_bits_to_f32((uint16_t)(u[e] & 0xffffu));
+          v[2 * e + 1] = bf16_bits_to_f32((uint16_t)(u[e] >> 16));
+        } else {
+          v[2 * e] = f16_bits_to_f32((uint16_t)(u[e] & 0xffffu));
+          v[2 * e + 1] = f16_bits_to_f32((uint16_t)(u[e] >> 16));
+        }
+      }
+    }
+    if (dead) {
+      const uint2 d = *reinterpret_cast<const uint2*>(dead + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (((e < 4 ? d.x : d.y) >> (8 * (e & 3))) & 0xffu) v[e] = 0.f;
+    }
+    reinterpret_cast<float4*>(out + base)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(out + base)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // the serial column chain for one 128-column block
@@ -1365,10 +1403,13 @@ int inc_gptq_hessian_finalize(float* H, int64_t K, float percdamp, uint8_t* dead
 int inc_gptq_prepare_weight(const void* w, int wdtype, float* out, const uint8_t* dead, int64_t N,
                             int64_t K, inc_stream_t stream) {
   INC_CHECK_ARG(w && out && N > 0 && K > 0);
-  int64_t blocks = ceil_div64(N * K, 256);
+  const bool vec = (K % 8) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+                   (!dead || (reinterpret_cast<uintptr_t>(dead) & 7) == 0);
+  int64_t blocks = ceil_div64(vec ? N * (K / 8) : N * K, 256);
   if (blocks > 8192) blocks = 8192;
   INC_DISPATCH_DTYPE(wdtype, DT, {
-    gptq_prepare_weight_kernel<DT><<<(unsigned)blocks, 256, 0, inc_s(stream)>>>(w, out, dead, N, K);
+    if (vec) gptq_prepare_weight_vec_kernel<DT><<<(unsigned)blocks, 256, 0, inc_s(stream)>>>(w, out, dead, N, K);
+    else gptq_prepare_weight_kernel<DT><<<(unsigned)blocks, 256, 0, inc_s(stream)>>>(w, out, dead, N, K);
   })
   INC_LAUNCH_RETURN();
 }
