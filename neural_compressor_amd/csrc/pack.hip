@@ -143,10 +143,13 @@ __global__ __launch_bounds__(256) void woq_pack_qweight_kernel(const IN_T* __res
 // ------------------------------------------------------------------------------------------
 // optimum-format unpack: qweight [KW,N] -> int_weight [N,K] int16
 // ------------------------------------------------------------------------------------------
+// (like the pack kernel, ONE launch: after its tile of weights a workgroup unpacks its share of the zero points -- the 64 rows
+// of its tile x the groups g = blockIdx.x, blockIdx.x + gridDim.x, ...: stored + 1, values above maxq wrap to 0, modules.py:407-410)
 template <int BITS, bool VEC>
 __global__ __launch_bounds__(256) void woq_unpack_qweight_kernel(const uint32_t* __restrict__ qweight,
                                                                  int16_t* __restrict__ out, int64_t N,
-                                                                 int64_t K, int64_t KW) {
+                                                                 int64_t K, int64_t KW, const uint32_t* __restrict__ qzeros,
+                                                                 int16_t* __restrict__ zp, int64_t G, int64_t NW) {
   constexpr int NP = 32 / BITS;
   constexpr uint32_t MASK = (1u << BITS) - 1u;
   __shared__ uint32_t tile[TILE * TILE_LD];
@@ -194,6 +197,18 @@ __global__ __launch_bounds__(256) void woq_unpack_qweight_kernel(const uint32_t*
 #pragma unroll
       for (int e = 0; e < NP; ++e)
         if (e < left) dst[e] = static_cast<int16_t>((word >> (BITS * e)) & MASK);
+    }
+  }
+  if (zp) {
+    const int ng = (int)((G - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    for (int i = threadIdx.x; i < ng * TILE; i += 256) {
+      const int64_t g = blockIdx.x + (int64_t)(i / TILE) * gridDim.x, nn = n0 + (i % TILE);
+      if (nn < N) {
+        const uint32_t word = qzeros[g * NW + nn / NP];
+        uint32_t z = ((word >> (BITS * (uint32_t)(nn % NP))) & MASK) + 1u;
+        if (z > MASK) z = 0;
+        zp[nn * G + g] = static_cast<int16_t>(z);
+      }
     }
   }
 }
@@ -451,25 +466,20 @@ int inc_woq_unpack(const int32_t* qweight, const int32_t* qzeros, int16_t* int_w
   hipStream_t s = inc_s(stream);
   const int n_pack = 32 / bits;
   const int64_t KW = ceil_div64(K, n_pack), NW = ceil_div64(N, n_pack);
+  const uint32_t* qzp = reinterpret_cast<const uint32_t*>(qzeros);
+  if (zp) INC_CHECK_ARG(qzeros);
   if (int_weight) {
     INC_CHECK_ARG(qweight);
     dim3 grid((unsigned)ceil_div64(KW, TILE), (unsigned)ceil_div64(N, TILE));
     const bool vec = (K % n_pack == 0) && (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(int_weight) & 15) == 0);
     const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
-    if (bits == 4) {
-      if (vec) woq_unpack_qweight_kernel<4, true><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
-      else woq_unpack_qweight_kernel<4, false><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
-    } else if (bits == 8) {
-      if (vec) woq_unpack_qweight_kernel<8, true><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
-      else woq_unpack_qweight_kernel<8, false><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
-    } else {
-      if (vec) woq_unpack_qweight_kernel<2, true><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
-      else woq_unpack_qweight_kernel<2, false><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW);
-    }
-  }
-  if (zp) {
-    INC_CHECK_ARG(qzeros);
-    woq_unpack_qzeros_kernel<<<grid_1d(N * G), 256, 0, s>>>(reinterpret_cast<const uint32_t*>(qzeros), zp, N, G, NW, bits);
+#define INC_UNPACK(B, V) woq_unpack_qweight_kernel<B, V><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW, qzp, zp, G, NW)
+    if (bits == 4) { if (vec) INC_UNPACK(4, true); else INC_UNPACK(4, false); }
+    else if (bits == 8) { if (vec) INC_UNPACK(8, true); else INC_UNPACK(8, false); }
+    else { if (vec) INC_UNPACK(2, true); else INC_UNPACK(2, false); }
+#undef INC_UNPACK
+  } else if (zp) {  // zero points alone
+    woq_unpack_qzeros_kernel<<<grid_1d(N * G), 256, 0, s>>>(qzp, zp, N, G, NW, bits);
   }
   INC_LAUNCH_RETURN();
 }
