@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinc_mi355x.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 INC_OK = 0
 INC_F32, INC_F16, INC_BF16 = 0, 1, 2
@@ -74,7 +74,7 @@ SIGNATURES = {
     "inc_gptq_quantize_layer": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int, _P, c_int64, c_int64, c_int, c_int, c_int,
                                         c_int, c_int, c_int, _P, _P]),
     "inc_chol_diag_block": (c_int, [_P, c_int64, c_int, _P, c_int64, _P, c_int, _P]),
-    "inc_gptq_inverse_factor_workspace_bytes": (c_int64, [c_int64]),
+    "inc_gptq_inverse_factor_workspace_bytes": (c_int64, [c_int64, c_int]),
     "inc_gptq_inverse_factor": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int, _P, _P]),
     "inc_awq_act_abs_sum": (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),
     "inc_awq_weight_scale_workspace_bytes": (c_int64, [c_int64, c_int64, c_int]),

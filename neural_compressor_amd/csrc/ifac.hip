@@ -209,7 +209,212 @@ __global__ __launch_bounds__(256) void f32gemm_kernel(GemmArgs g) {
     }
 }
 
-int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s) {
+
+// ---- opt-in (flags bit 1): the LARGE products with fp32 operands split into three bf16 pieces ---------------------------------------
+// a = a1 + a2 + a3 (each piece the bf16 rounding of what is left: 24+ bits together); a b ~ a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 +
+// a2 b2 -- six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block (the dropped terms are <= 2^-24 |a b|), fp32 accumulation: 768 matrix
+// cycles per 16 k of a wave's 64 x 64 against 2048 for v_mfma_f32_32x32x2_f32.  NOT the exact-fp32 arithmetic of the default
+// path: its distance to the fp64 factor is measured in tests / scripts/chol_time.py.  Splitting inside the GEMM (every tile
+// re-splitting its operands) is VALU-bound and slower than the fp32 kernel (21.2 vs 17.3 ms at K = 11008): a pre-pass writes each
+// operand ONCE as three bf16 planes in the layout the GEMM streams -- [plane][k / 16][row][k % 16], so a 128-row tile of one K-step
+// is 4 KiB contiguous per plane -- and the GEMM itself has no VALU work besides addresses.
+constexpr int X3_KB = 16;
+struct X3Planes {
+  const uint16_t* Ap;
+  const uint16_t* Bp;
+  int64_t a_plane, b_plane;  // elements between the planes of one operand
+  int64_t RpA, RpB;          // rows (padded to 128) of the operands
+};
+__device__ __forceinline__ uint32_t split_hi(float v, float& rest) {  // bf16 rounding (RNE) of v as its 16 bits, rest = v - that
+  const uint32_t b = f32_to_bf16_bits(v);
+  rest = v - bf16_bits_to_f32((uint16_t)b);
+  return b;
+}
+// element (r, k) of the operand = src[r * ld + k] (TR = false) or src[k * ld + r] (TR = true: B of an NN product); rows >= `rows`
+// and k >= `cols` are written as zeros up to the padded extents (Rp rows, kq = gridDim.x * 64 >= cols columns)
+template <bool TR>
+__global__ __launch_bounds__(256) void ifac_split3_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols, uint16_t* __restrict__ dst,
+                                                          int64_t plane, int64_t Rp, int nkb) {
+  __shared__ float tile[TR ? 64 : 1][65];
+  const int t = threadIdx.x, row = t >> 2, q = t & 3;
+  const int r0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  float v[4][4];
+  if constexpr (!TR) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 16 * j + 4 * q;
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < rows && k < cols) w = *reinterpret_cast<const float4*>(src + (int64_t)(r0 + row) * ld + k);
+      v[j][0] = w.x; v[j][1] = w.y; v[j][2] = w.z; v[j][3] = w.w;
+    }
+  } else {
+    const int kk = t >> 4, n4 = t & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + kk + 16 * j;
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < cols && r0 + 4 * n4 < rows) w = *reinterpret_cast<const float4*>(src + (int64_t)k * ld + r0 + 4 * n4);
+      tile[kk + 16 * j][4 * n4 + 0] = w.x; tile[kk + 16 * j][4 * n4 + 1] = w.y; tile[kk + 16 * j][4 * n4 + 2] = w.z; tile[kk + 16 * j][4 * n4 + 3] = w.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[j][e] = tile[16 * j + 4 * q + e][row];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kb = (k0 >> 4) + j;
+    if (kb >= nkb) break;
+    uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float r1, r2, r3;
+      p1[e] = split_hi(v[j][e], r1);
+      p2[e] = split_hi(r1, r2);
+      p3[e] = split_hi(r2, r3);
+    }
+    // the two 8-k halves of a row's 32 bytes swap places on rows with bit 3 set (the GEMM's LDS image is a linear copy of this)
+    uint16_t* d = dst + ((int64_t)kb * Rp + r0 + row) * X3_KB + 4 * (q ^ ((row >> 2) & 2));
+    *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16));
+    *reinterpret_cast<uint2*>(d + plane) = make_uint2(p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16));
+    *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2(p3[0] | (p3[1] << 16), p3[2] | (p3[3] << 16));
+  }
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ibf16x8;
+// C = alpha * A B^T + beta * C over the K-range of the tile (g.A / g.B unused: both operands come as planes, B always as [n][k])
+// C = alpha * A B^T + beta * C over the K-range of the tile (g.A / g.B unused: both operands come as planes, B always as [n][k]).
+// 128 x 128 per workgroup, four waves of 64 x 64; a K-step (16 k) of the tile is 24 x 1 KiB contiguous pieces (2 operands x 3 planes x
+// 4 quarters of 32 rows), six per wave, copied global -> LDS by LDS-DMA (no VGPR staging, no ds_write) into a ring of three stages:
+// the requests of step s + 2 are issued at step s, behind ONE barrier per step (which also retires the stage they overwrite).  With
+// the previous register-staged, two-stage form (requests one step ahead of a 0.4 us step) the loop waited on L2 latency: 136 "fp32"
+// TFLOP/s on the first trailing update of K = 11008 against 100 for the fp32-MFMA kernel.
+__global__ __launch_bounds__(256) void bf16x3_gemm_kernel(GemmArgs g, X3Planes p) {
+  constexpr int TM = 128, TN = 128, MI = 2, NI = 2;
+  constexpr int NS = 3, PLANE = 4096, STAGE = 6 * PLANE;  // bytes
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.N + TN - 1) / TN, tiles_m = (g.M + TM - 1) / TM;
+  int ti, tj;
+  if (g.lower_only) {
+    const int t = blockIdx.x;
+    ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    tj = t - ti * (ti + 1) / 2;
+  } else {
+    const int b = blockIdx.x;
+    if (g.krange == KR_B_LOWER_NN) { tj = b / tiles_m; ti = b - tj * tiles_m; }
+    else if (g.krange == KR_B_LOWER_NT) { tj = b / tiles_m; ti = b - tj * tiles_m; tj = tiles_n - 1 - tj; }
+    else if (g.krange == KR_A_LOWER) { ti = b / tiles_n; tj = b - ti * tiles_n; ti = tiles_m - 1 - ti; }
+    else { ti = b / tiles_n; tj = b - ti * tiles_n; }
+  }
+  const int m0 = ti * TM, n0 = tj * TN;
+  int k_lo = 0, k_hi = g.K;
+  if (g.krange == KR_B_LOWER_NT) k_hi = min(g.K, n0 + TN);
+  else if (g.krange == KR_B_LOWER_NN) k_lo = min(n0, g.K);
+  else if (g.krange == KR_A_LOWER) k_hi = min(g.K, m0 + TM);
+  const int kb_lo = k_lo / X3_KB, kb_hi = (k_hi + X3_KB - 1) / X3_KB;
+  const int nsteps = kb_hi - kb_lo;
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (nsteps > 0) {
+    // this wave's six pieces: q = 6 wave + i -> operand q / 12 (waves 0, 1: A; 2, 3: B), plane (q % 12) / 4, quarter q % 4
+    const uint16_t* pq[6];
+    const int64_t step_w = (wave < 2 ? p.RpA : p.RpB) * X3_KB;  // elements per K-step of this wave's operand
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int q = wave * 6 + i, pl = (q % 12) / 4, qt = q % 4;
+      const uint16_t* base = wave < 2 ? p.Ap + (int64_t)m0 * X3_KB + pl * p.a_plane : p.Bp + (int64_t)n0 * X3_KB + pl * p.b_plane;
+      pq[i] = base + qt * 512 + kb_lo * step_w;
+    }
+    const uint32_t lds_w = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem + wave * 6 * 1024);
+    const uint32_t voff = lane * 16;
+#define INC_X3_DMA(I, STG, KOFF)                                                                                              \
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(pq[I] + (KOFF)), "s"(lds_w + (STG) * STAGE), \
+               "i"((I) * 1024) : "memory", "scc")
+    auto issue = [&](int stg, int step) {  // step clamped: past-the-end requests re-read the last block into a stage nobody reads again
+      const int64_t koff = (int64_t)min(step, nsteps - 1) * step_w;
+      INC_X3_DMA(0, stg, koff); INC_X3_DMA(1, stg, koff); INC_X3_DMA(2, stg, koff);
+      INC_X3_DMA(3, stg, koff); INC_X3_DMA(4, stg, koff); INC_X3_DMA(5, stg, koff);
+    };
+    issue(0, 0);
+    issue(1, 1);
+    // fragment of row r, k-half h of a plane: 32 r + 16 (h ^ ((r >> 3) & 1)) -- the split pre-pass writes the halves in that order, so
+    // that the linear DMA image is conflict-free for ds_read_b128
+    const int fsw = ((lane & 31) * 32) + ((((lane >> 5) ^ ((lane >> 3) & 1)) & 1) * 16);
+    const int fa = wm * 64 * 32 + fsw, fb = 3 * PLANE + wn * 64 * 32 + fsw;
+    int st = 0, st2 = 2;
+    for (int s = 0; s < nsteps; ++s) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // the pieces of step s have landed (those of s + 1 may be in flight)
+      __syncthreads();                                   // ... every wave's; and every wave is done with stage st2
+      issue(st2, s + 2);
+      const char* const sb = smem + st * STAGE;
+      ibf16x8 a[3][MI], b[3][NI];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[pl][i] = *reinterpret_cast<const ibf16x8*>(sb + pl * PLANE + fa + 32 * i * 32);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[pl][j] = *reinterpret_cast<const ibf16x8*>(sb + pl * PLANE + fb + 32 * j * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {  // small terms first
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      st = st == NS - 1 ? 0 : st + 1;
+      st2 = st2 == NS - 1 ? 0 : st2 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail requests must not outlive the workgroup's LDS
+#undef INC_X3_DMA
+  }
+  float* C = g.C;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn * 64 + 32 * j + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        if (row < g.M && col < g.N) {
+          float* c = C + (int64_t)row * g.ldc + col;
+          float v = g.alpha * acc[i][j][r];
+          if (g.beta != 0.f) v += g.beta * *c;
+          *c = v;
+        }
+      }
+    }
+}
+
+// the split pre-pass of one operand into `dst` (3 planes of Rp x kq bf16); returns the bytes it occupies
+int64_t launch_split3(const float* src, int64_t ld, int rows, int cols, bool tr, uint16_t* dst, int64_t* plane_out, int64_t* rp_out, hipStream_t s) {
+  const int64_t Rp = ceil_div64(rows, 128) * 128, nkb = ceil_div64(cols, X3_KB), plane = nkb * Rp * X3_KB;
+  dim3 grid((unsigned)ceil_div64(cols, 64), (unsigned)(Rp / 64));
+  if (tr) ifac_split3_kernel<true><<<grid, 256, 0, s>>>(src, ld, rows, cols, dst, plane, Rp, (int)nkb);
+  else ifac_split3_kernel<false><<<grid, 256, 0, s>>>(src, ld, rows, cols, dst, plane, Rp, (int)nkb);
+  *plane_out = plane;
+  *rp_out = Rp;
+  return 3 * plane * (int64_t)sizeof(uint16_t);
+}
+
+// `planes` (flags bit 1, >= 12 * Kp^2 bytes): the large un-batched products run as bf16 x 3 splits of their operands
+int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s, void* planes = nullptr) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return INC_OK;
   // tile choice: 128 x 128 when that still gives the chip enough workgroups, else 64 x 64 (the chain's small products)
   auto ntiles = [&](int t) {
@@ -227,7 +432,21 @@ int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s) {
   const bool big = ntiles(128) * batch >= 192;
   const int t = big ? 128 : 64;
   dim3 grid((unsigned)ntiles(t), (unsigned)batch);
-  if (big) {
+  if (big && planes && batch == 1 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && (g.K & 3) == 0 && (g.N & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) {
+    X3Planes p;
+    uint16_t* pa = static_cast<uint16_t*>(planes);
+    const int64_t abytes = launch_split3(g.A, g.lda, g.M, g.K, false, pa, &p.a_plane, &p.RpA, s);
+    p.Ap = pa;
+    if (b_nt && g.B == g.A && g.ldb == g.lda && g.N == g.M) {  // syrk form: one operand
+      p.Bp = pa; p.b_plane = p.a_plane; p.RpB = p.RpA;
+    } else {
+      uint16_t* pb = reinterpret_cast<uint16_t*>(static_cast<char*>(planes) + abytes);
+      (void)launch_split3(g.B, g.ldb, g.N, g.K, !b_nt, pb, &p.b_plane, &p.RpB, s);
+      p.Bp = pb;
+    }
+    bf16x3_gemm_kernel<<<grid, 256, 0, s>>>(g, p);
+  } else if (big) {
     if (b_nt) f32gemm_kernel<128, 128, true><<<grid, 256, 0, s>>>(g);
     else f32gemm_kernel<128, 128, false><<<grid, 256, 0, s>>>(g);
   } else {
@@ -270,17 +489,18 @@ struct Seg {
 
 extern "C" {
 
-// A [Kp, Kp] + X [Kp, Kp] + T [Kp, Kp] + 2 x P [Kp, IFAC_OUTER] fp32, Kp = K rounded up to 128
-int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K) {
+// A [Kp, Kp] + X [Kp, Kp] + T [Kp, Kp] + 2 x P [Kp, IFAC_OUTER] fp32, Kp = K rounded up to 128; with flags bit 1 two operands of
+// three bf16 planes each behind them (12 Kp^2 bytes)
+int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K, int flags) {
   if (K <= 0) return 0;
   const int64_t Kp = ceil_div64(K, IFAC_NB) * IFAC_NB;
-  return (3 * Kp * Kp + 2 * Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float);
+  return (3 * Kp * Kp + 2 * Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float) + ((flags & 2) ? 12 * Kp * Kp : 0);
 }
 
 int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace, int64_t workspace_bytes, int32_t* info, int flags,
                             inc_stream_t stream, inc_stream_t aux_stream) {
   INC_CHECK_ARG(H && U && workspace && info && K > 0 && K < (1ll << 30));
-  if (workspace_bytes < inc_gptq_inverse_factor_workspace_bytes(K)) return INC_ERR_WORKSPACE;
+  if (workspace_bytes < inc_gptq_inverse_factor_workspace_bytes(K, flags)) return INC_ERR_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return INC_ERR_BAD_ARG;
   hipStream_t s = inc_s(stream);
   const int64_t Kp = ceil_div64(K, IFAC_NB) * IFAC_NB, ld = Kp;
@@ -288,6 +508,7 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
   float* X = A + Kp * Kp;
   float* T = X + Kp * Kp;  // products C X11 of the doubling levels: the pair (s1, n1, s2, n2) keeps its n2 x n1 product in rows s2.. of T
   float* Pb[2] = {T + Kp * Kp, T + Kp * Kp + Kp * (int64_t)IFAC_OUTER};  // panel L[i > block, block] of outer block b in Pb[b & 1]
+  void* const planes = (flags & 2) ? static_cast<void*>(Pb[1] + Kp * (int64_t)IFAC_OUTER) : nullptr;
   // Look-ahead (aux_stream given, flags bit 0 clear, more than two outer blocks): the main stream runs the CHAIN -- per outer block the
   // eight diagonal kernels with their small products, the block's inverse, the panel solve and the update of the NEXT block's columns
   // -- and the second stream everything the chain does not wait for: the rest of every trailing update and the doubling products of
@@ -314,7 +535,7 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
   auto gemm = [&](hipStream_t st, const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t M, int64_t N, int64_t Kd,
                   float alpha, float beta, int krange, bool lower_only, bool b_nt, int batch = 1, int64_t sa = 0, int64_t sb = 0, int64_t sc = 0) {
     GemmArgs g{a, b, c, lda, ldb, ldc, sa, sb, sc, (int)M, (int)N, (int)Kd, alpha, beta, krange, lower_only ? 1 : 0};
-    const int r = launch_f32gemm(g, b_nt, batch, st);
+    const int r = launch_f32gemm(g, b_nt, batch, st, st == s ? planes : nullptr);  // one plane buffer: the main stream's products only
     if (r != INC_OK) rc = r;
   };
   auto copy_panel = [&](hipStream_t st, const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int cols) {

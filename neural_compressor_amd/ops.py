@@ -655,7 +655,7 @@ def chol_diag_block(A_view, Linv_view, info, tag):
         )
 
 
-def gptq_inverse_factor(H, aux_stream=None):
+def gptq_inverse_factor(H, aux_stream=None, flags=0):
     """Upper Cholesky factor U of H^-1 for the damped SPD fp32 Hessian H [K,K] (gptq.py:1228-1231) as ONE C-ABI call
     (include/inc_mi355x.h: inc_gptq_inverse_factor).  Returns (U, info): `info` is a device int32 that stays 0 unless H
     is not positive definite (no host synchronisation here)."""
@@ -664,14 +664,14 @@ def gptq_inverse_factor(H, aux_stream=None):
     assert H.shape == (K, K) and H.dtype == torch.float32 and H.is_contiguous()
     U = torch.empty((K, K), dtype=torch.float32, device=dev)
     info = torch.empty(1, dtype=torch.int32, device=dev)
-    wsb = int(lib.inc_gptq_inverse_factor_workspace_bytes(K))
+    wsb = int(lib.inc_gptq_inverse_factor_workspace_bytes(K, int(flags)))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     # (no record_stream for `aux_stream`: the call returns with the current stream ordered behind everything it issued on the second
     # one, so the caching allocator's stream-ordered reuse of H / U / the workspace is already safe -- and record_stream would make
     # every call hipMalloc a fresh 1.5 GB workspace at K = 11008)
     aux = aux_stream.cuda_stream if aux_stream is not None else None
     with torch.cuda.device(dev):
-        check(lib.inc_gptq_inverse_factor(_ptr(H), K, _ptr(U), _ptr(ws), wsb, _ptr(info), 0, _stream(), aux), "inc_gptq_inverse_factor")
+        check(lib.inc_gptq_inverse_factor(_ptr(H), K, _ptr(U), _ptr(ws), wsb, _ptr(info), int(flags), _stream(), aux), "inc_gptq_inverse_factor")
     return U, info
 
 

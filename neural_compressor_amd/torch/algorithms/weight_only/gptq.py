@@ -164,6 +164,7 @@ def _chol_side_stream(device):
 
 
 CHOL_PYTHON = os.environ.get("INC_MI355X_CHOL_PYTHON", "0") == "1"
+CHOL_BF16X3 = os.environ.get("INC_MI355X_CHOL_BF16X3", "1") == "1"  # large products of the factorisation as 3-way bf16 splits (0: exact fp32 MFMA)
 CHOL_OUTER = int(os.environ.get("INC_MI355X_CHOL_OUTER", "1024"))  # outer block of the two-level factorisation (columns)
 TRI_DEPTH = int(os.environ.get("INC_MI355X_CHOL_TRI_DEPTH", "2"))    # levels of 2 x 2 splitting in the triangular products
 TRI_MIN = 512                                                        # do not split below this half size
@@ -194,7 +195,8 @@ def inverse_cholesky_upper(H, check=True):
         # GEMMs instead of torch.mm.  INC_MI355X_CHOL_PYTHON=1 keeps the Python + torch.mm form below (its A/B partner in the tests).
         # (second stream: the rest of the trailing updates and the top-level doubling products run underneath the chain of diagonal
         # blocks -- same results as one stream, INC_MI355X_CHOL_LOOKAHEAD=0 keeps everything on the calling stream)
-        U, info = ops.gptq_inverse_factor(H.contiguous(), aux_stream=_chol_side_stream(H.device) if CHOL_LOOKAHEAD else None)
+        U, info = ops.gptq_inverse_factor(H.contiguous(), aux_stream=_chol_side_stream(H.device) if CHOL_LOOKAHEAD else None,
+                                          flags=2 if CHOL_BF16X3 else 0)
         if not check:
             return U, info
         raise_if_not_spd(info)

@@ -10,7 +10,7 @@ import neural_compressor_amd.torch.algorithms.weight_only.gptq as G  # noqa: E40
 
 
 def main():
-    forms = ("cabi", "cabi1", "python")  # cabi1: one stream (no look-ahead)
+    forms = ("cabi1", "x3", "python")  # cabi1: one stream; x3: large products as three-way bf16 splits (experimental)
     args = sys.argv[1:]
     if "--form" in args:
         i = args.index("--form")
@@ -24,11 +24,12 @@ def main():
         H = (X.t() @ X) / X.shape[0]
         H.diagonal().add_(0.01 * H.diagonal().mean())
         H64 = H.double()
-        ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H64)), upper=True) if K <= 4096 else None
+        ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H64)), upper=True) if K <= 11008 else None
         first = None
         for form in forms:
             G.CHOL_PYTHON = form == "python"
             G.CHOL_LOOKAHEAD = form == "cabi"
+            G.CHOL_BF16X3 = form == "x3"
             U = G.inverse_cholesky_upper(H)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -52,7 +52,7 @@ PY
       timeout 300 python scripts/chol_time.py > gpurun_out/chol_time.log 2>&1; tail -12 gpurun_out/chol_time.log ;;
     choltrace)
       rm -rf "$R/gpurun_out/prof_chol"
-      ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_chol" -o c -- python "$R/scripts/chol_time.py" --form ${CHOL_FORM:-cabi} 11008 > "$R/gpurun_out/prof_chol.log" 2>&1 )
+      ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/prof_chol" -o c -- python "$R/scripts/chol_time.py" --form ${CHOL_FORM:-cabi1} ${CHOL_K:-11008} > "$R/gpurun_out/prof_chol.log" 2>&1 )
       echo "choltrace exit $?"; tail -2 gpurun_out/prof_chol.log
       python3 - gpurun_out/prof_chol/c_kernel_trace.csv <<'PY' | tee gpurun_out/chol_trace_summary.txt
 import csv, sys, collections

@@ -721,6 +721,37 @@ def test_inverse_factor_cabi_matches_the_python_form(hip, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K", [4224, 5120])
+def test_inverse_factor_bf16x3_products_are_as_close_to_fp64_as_the_fp32_ones(hip, K):
+    """flags bit 1: the large products with their operands split into three bf16 planes (six bf16 MFMAs per fp32 product).  Not the
+    default path's arithmetic, so the gate is the distance to an fp64 factor of the same matrix: no farther than 1.5 x the exact-fp32
+    form's, and the residual |U H U^T - I| likewise.  K = 5120 has a ragged last outer block and products on both sides of the
+    192-tile threshold; K = 4224 = four full outer blocks + one leaf block."""
+    from neural_compressor_amd import ops
+
+    g = torch.Generator().manual_seed(K)
+    X = torch.randn(2 * K, K, generator=g)
+    H = ((2.0 / X.shape[0]) * X.T @ X)
+    H += 0.01 * H.diagonal().mean() * torch.eye(K)
+    H = H.to(hip)
+    H64 = H.double()
+    ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H64)), upper=True)
+    U0, i0 = ops.gptq_inverse_factor(H)
+    U3, i3 = ops.gptq_inverse_factor(H, flags=2)
+    assert int(i0.item()) == 0 and int(i3.item()) == 0
+    assert torch.equal(U3, torch.triu(U3))
+    assert not torch.equal(U0, U3)  # the switch does something
+    eye = torch.eye(K, device=hip, dtype=torch.float64)
+
+    def dist(U):
+        return float((U.double() - ref).norm() / ref.norm()), float((U.double() @ H64 @ U.double().T - eye).norm() / K ** 0.5)
+
+    (e0, r0), (e3, r3) = dist(U0), dist(U3)
+    assert e3 <= 1.5 * e0 and r3 <= 1.5 * r0, (e0, e3, r0, r3)
+    assert e3 < 2e-6
+
+
+@pytest.mark.gpu
 def test_gptq_fasterquant_raises_on_a_non_positive_definite_hessian(hip):
     """The public GPTQ class used directly (as the reference allows, gptq.py:1089): a Hessian that is not positive definite must
     raise from `fasterquant` like the reference's torch.linalg.cholesky (gptq.py:1228) -- the factorisation's status word is read
