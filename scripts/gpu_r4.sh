@@ -71,7 +71,7 @@ for r in run:
         tile = "128" if "Li128ELi128" in n or "<128, 128" in n else "64"
         k = f"f32gemm<{tile}> {'NT' if ('Lb1' in n or 'true' in n) else 'NN'} " + ("big(>=256 wg)" if g >= 256 else "small(<256 wg)")
     else:
-        k = n.split("(")[0][-40:]
+        k = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:50]
     busy[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[k] += 1
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in run)
 tot = 0; cs, ce = iv[0]
