@@ -46,6 +46,45 @@ struct GemmArgs {
 // = lane & 31, k = lane >> 5), i.e. two consecutive 128-byte LDS rows: conflict-free ds_read_b32), two stages, register prefetch.
 // The fp32 MFMA runs at 1/16 of the bf16 rate (256 flop / clk / CU): 16 KiB of operands per 2048 MFMA cycles -- every other
 // cost is small beside it, which is why the loaders are simple.
+// C <- alpha * acc + beta * C for a wave's MI x NI accumulators of 32 x 32: register r = 4 rq + e of a tile is row 8 rq + 4 (lane >> 5) + e,
+// column lane & 31.  beta != 0: EVERY old value is requested before the first is used (clamped addresses, no branches around the
+// loads) -- the obvious per-element form compiles to 16 MI NI serial load -> wait -> fma -> store round trips per lane, which was
+// longer than the K-loop of the trailing updates (K = 1024).
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* __restrict__ C, f32x16 (&acc)[MI][NI], int row0, int col0, int lane) {
+  const int cl = lane & 31, rh = 4 * (lane >> 5);
+  const bool rmw = g.beta != 0.f;
+  float old[MI][NI][16];
+  if (rmw) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = min(col0 + 32 * j + cl, g.N - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row0 + 32 * i + 8 * (r >> 2) + rh + (r & 3), g.M - 1);
+          old[i][j][r] = C[(int64_t)row * g.ldc + col];
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = col0 + 32 * j + cl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * i + 8 * (r >> 2) + rh + (r & 3);
+        if (row < g.M && col < g.N) {
+          float v = g.alpha * acc[i][j][r];
+          if (rmw) v += g.beta * old[i][j][r];
+          C[(int64_t)row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+
 template <int TM, int TN, bool B_NT>
 __global__ __launch_bounds__(256) void f32gemm_kernel(GemmArgs g) {
   constexpr int MI = TM / 64, NI = TN / 64;
@@ -190,23 +229,7 @@ __global__ __launch_bounds__(256) void f32gemm_kernel(GemmArgs g) {
     }
     __syncthreads();
   }
-  // ---- epilogue: accumulator register r = 4 rq + e of a 32 x 32 tile is row 8 rq + 4 (lane >> 5) + e, column lane & 31 -----------
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int col = n0 + wn * (TN / 2) + 32 * j + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (TM / 2) + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-        if (row < g.M && col < g.N) {
-          float* c = C + (int64_t)row * g.ldc + col;
-          float v = g.alpha * acc[i][j][r];
-          if (g.beta != 0.f) v += g.beta * *c;
-          *c = v;
-        }
-      }
-    }
+  gemm_epilogue<MI, NI>(g, C, acc, m0 + wm * (TM / 2), n0 + wn * (TN / 2), lane);
 }
 
 
@@ -218,6 +241,14 @@ __global__ __launch_bounds__(256) void f32gemm_kernel(GemmArgs g) {
 // re-splitting its operands) is VALU-bound and slower than the fp32 kernel (21.2 vs 17.3 ms at K = 11008): a pre-pass writes each
 // operand ONCE as three bf16 planes in the layout the GEMM streams -- [plane][k / 16][row][k % 16], so a 128-row tile of one K-step
 // is 4 KiB contiguous per plane -- and the GEMM itself has no VALU work besides addresses.
+// compile-time loop: f(std::integral_constant<int, B>) ... f(std::integral_constant<int, E - 1>)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 constexpr int X3_KB = 16;
 struct X3Planes {
   const uint16_t* Ap;
@@ -283,26 +314,39 @@ __global__ __launch_bounds__(256) void ifac_split3_kernel(const float* __restric
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 ibf16x8;
-// C = alpha * A B^T + beta * C over the K-range of the tile (g.A / g.B unused: both operands come as planes, B always as [n][k])
 // C = alpha * A B^T + beta * C over the K-range of the tile (g.A / g.B unused: both operands come as planes, B always as [n][k]).
-// 128 x 128 per workgroup, four waves of 64 x 64; a K-step (16 k) of the tile is 24 x 1 KiB contiguous pieces (2 operands x 3 planes x
-// 4 quarters of 32 rows), six per wave, copied global -> LDS by LDS-DMA (no VGPR staging, no ds_write) into a ring of three stages:
-// the requests of step s + 2 are issued at step s, behind ONE barrier per step (which also retires the stage they overwrite).  With
-// the previous register-staged, two-stage form (requests one step ahead of a 0.4 us step) the loop waited on L2 latency: 136 "fp32"
-// TFLOP/s on the first trailing update of K = 11008 against 100 for the fp32-MFMA kernel.
-__global__ __launch_bounds__(256) void bf16x3_gemm_kernel(GemmArgs g, X3Planes p) {
-  constexpr int TM = 128, TN = 128, MI = 2, NI = 2;
-  constexpr int NS = 3, PLANE = 4096, STAGE = 6 * PLANE;  // bytes
+// TM x 128 per workgroup (TM = 128: four waves, two workgroups per CU; TM = 256: eight waves, one per CU), waves of 64 x 64; a K-step
+// (16 k) of the tile is 1 KiB contiguous pieces (3 planes x TM / 32 of A, 3 x 4 of B), dealt round-robin to the waves and copied
+// global -> LDS by LDS-DMA (no VGPR staging, no ds_write) into a ring of NS stages: the requests of step s + NS - 1 are issued at
+// step s, behind ONE barrier per step (which also retires the stage they overwrite).  With the first, register-staged two-stage
+// form (requests one step ahead of a 0.4 us step) the loop waited on L2 latency: 136 "fp32" TFLOP/s on the first trailing update of
+// K = 11008 against 100 for the fp32-MFMA kernel.  The operand stream is 32 B/clk/CU at 128 x 128; the TM = 256 form (24 B/clk/CU,
+// three steps in flight, one workgroup per CU) measured 2 % SLOWER (profiles/NOTES.md) and is not instantiated.
+template <int TM>
+__global__ __launch_bounds__(TM * 2) void bf16x3_gemm_kernel(GemmArgs g, X3Planes p) {
+  constexpr int TN = 128, MI = 2, NI = 2;
+  constexpr int NW = TM / 32;                         // waves: (TM / 64) x 2
+  constexpr int NS = TM == 128 ? 3 : 4, D = NS - 1;   // stages, steps the DMA runs ahead
+  constexpr int PA = 3 * (TM / 32), PB = 12, P = PA + PB;  // 1-KiB pieces of A, of B, per step
+  constexpr int APLANE = TM * 32, BPLANE = 4096, STAGE = P * 1024;  // bytes
+  constexpr int NPW = (P + NW - 1) / NW, NFULL = P % NW == 0 ? NW : P % NW;  // pieces per wave (waves >= NFULL have one less)
   __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.N + TN - 1) / TN, tiles_m = (g.M + TM - 1) / TM;
   int ti, tj;
   if (g.lower_only) {
     const int t = blockIdx.x;
-    ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    tj = t - ti * (ti + 1) / 2;
+    if constexpr (TM == TN) {
+      ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      while (ti * (ti + 1) / 2 > t) --ti;
+      tj = t - ti * (ti + 1) / 2;
+    } else {  // 256-row blocks x 128-column blocks: row block ti holds column blocks 0 .. 2 ti + 1 -> ti (ti + 1) tiles before it
+      ti = (int)((sqrtf(4.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((ti + 1) * (ti + 2) <= t) ++ti;
+      while (ti * (ti + 1) > t) --ti;
+      tj = t - ti * (ti + 1);
+    }
   } else {
     const int b = blockIdx.x;
     if (g.krange == KR_B_LOWER_NN) { tj = b / tiles_m; ti = b - tj * tiles_m; }
@@ -311,6 +355,7 @@ __global__ __launch_bounds__(256) void bf16x3_gemm_kernel(GemmArgs g, X3Planes p
     else { ti = b / tiles_n; tj = b - ti * tiles_n; }
   }
   const int m0 = ti * TM, n0 = tj * TN;
+  if (n0 >= g.N) return;  // (the last 256-row block of a ragged lower-only product)
   int k_lo = 0, k_hi = g.K;
   if (g.krange == KR_B_LOWER_NT) k_hi = min(g.K, n0 + TN);
   else if (g.krange == KR_B_LOWER_NN) k_lo = min(n0, g.K);
@@ -325,44 +370,53 @@ __global__ __launch_bounds__(256) void bf16x3_gemm_kernel(GemmArgs g, X3Planes p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (nsteps > 0) {
-    // this wave's six pieces: q = 6 wave + i -> operand q / 12 (waves 0, 1: A; 2, 3: B), plane (q % 12) / 4, quarter q % 4
-    const uint16_t* pq[6];
-    const int64_t step_w = (wave < 2 ? p.RpA : p.RpB) * X3_KB;  // elements per K-step of this wave's operand
+    // this wave's pieces: q = wave + NW i.  q < PA: A, plane q / (TM / 32), 32-row slice q % (TM / 32); else B, plane (q - PA) / 4, slice % 4
+    const uint16_t* pq[NPW];
+    int64_t stepq[NPW];
+    uint32_t ldsq[NPW];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int q = wave * 6 + i, pl = (q % 12) / 4, qt = q % 4;
-      const uint16_t* base = wave < 2 ? p.Ap + (int64_t)m0 * X3_KB + pl * p.a_plane : p.Bp + (int64_t)n0 * X3_KB + pl * p.b_plane;
-      pq[i] = base + qt * 512 + kb_lo * step_w;
+    for (int i = 0; i < NPW; ++i) {
+      int q = wave + NW * i;
+      if (q > P - 1) q = P - 1;  // (never issued: see NFULL)
+      const bool isa = q < PA;
+      const int pl = isa ? q / (TM / 32) : (q - PA) / 4, sl = isa ? q % (TM / 32) : (q - PA) % 4;
+      stepq[i] = (isa ? p.RpA : p.RpB) * X3_KB;
+      pq[i] = (isa ? p.Ap + (int64_t)m0 * X3_KB + pl * p.a_plane : p.Bp + (int64_t)n0 * X3_KB + pl * p.b_plane) + sl * 512 + kb_lo * stepq[i];
+      ldsq[i] = __builtin_amdgcn_readfirstlane(lds0 + (isa ? pl * APLANE : 3 * APLANE + pl * BPLANE) + sl * 1024);
     }
-    const uint32_t lds_w = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem + wave * 6 * 1024);
     const uint32_t voff = lane * 16;
-#define INC_X3_DMA(I, STG, KOFF)                                                                                              \
-  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(pq[I] + (KOFF)), "s"(lds_w + (STG) * STAGE), \
-               "i"((I) * 1024) : "memory", "scc")
+#define INC_X3_DMA(I, STG, STEP)                                                                                             \
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(pq[I] + (STEP) * stepq[I]), \
+               "s"(ldsq[I]), "s"((uint32_t)((STG) * STAGE)) : "memory", "scc")
     auto issue = [&](int stg, int step) {  // step clamped: past-the-end requests re-read the last block into a stage nobody reads again
-      const int64_t koff = (int64_t)min(step, nsteps - 1) * step_w;
-      INC_X3_DMA(0, stg, koff); INC_X3_DMA(1, stg, koff); INC_X3_DMA(2, stg, koff);
-      INC_X3_DMA(3, stg, koff); INC_X3_DMA(4, stg, koff); INC_X3_DMA(5, stg, koff);
+      const int64_t st = (int64_t)min(step, nsteps - 1);
+      static_assert(NPW == 5 || NPW == 6, "pieces per wave");
+      INC_X3_DMA(0, stg, st); INC_X3_DMA(1, stg, st); INC_X3_DMA(2, stg, st); INC_X3_DMA(3, stg, st);
+      if constexpr (NPW == 6) INC_X3_DMA(4, stg, st);
+      if (NFULL == NW || wave < NFULL) INC_X3_DMA(NPW - 1, stg, st);
     };
-    issue(0, 0);
-    issue(1, 1);
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, d);
     // fragment of row r, k-half h of a plane: 32 r + 16 (h ^ ((r >> 3) & 1)) -- the split pre-pass writes the halves in that order, so
     // that the linear DMA image is conflict-free for ds_read_b128
     const int fsw = ((lane & 31) * 32) + ((((lane >> 5) ^ ((lane >> 3) & 1)) & 1) * 16);
-    const int fa = wm * 64 * 32 + fsw, fb = 3 * PLANE + wn * 64 * 32 + fsw;
-    int st = 0, st2 = 2;
+    const int fa = wm * 64 * 32 + fsw, fb = 3 * APLANE + wn * 64 * 32 + fsw;
+    int st = 0, st2 = D;
     for (int s = 0; s < nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // the pieces of step s have landed (those of s + 1 may be in flight)
-      __syncthreads();                                   // ... every wave's; and every wave is done with stage st2
-      issue(st2, s + 2);
+      // the pieces of step s have landed (those of the D - 1 steps behind it may be in flight)
+      if (NFULL == NW || wave < NFULL) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * (NPW - 1)) : "memory");
+      __syncthreads();  // ... every wave's; and every wave is done with stage st2 (read at step s - 1)
+      issue(st2, s + D);
       const char* const sb = smem + st * STAGE;
       ibf16x8 a[3][MI], b[3][NI];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[pl][i] = *reinterpret_cast<const ibf16x8*>(sb + pl * PLANE + fa + 32 * i * 32);
+        for (int i = 0; i < MI; ++i) a[pl][i] = *reinterpret_cast<const ibf16x8*>(sb + pl * APLANE + fa + 32 * i * 32);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) b[pl][j] = *reinterpret_cast<const ibf16x8*>(sb + pl * PLANE + fb + 32 * j * 32);
+        for (int j = 0; j < NI; ++j) b[pl][j] = *reinterpret_cast<const ibf16x8*>(sb + pl * BPLANE + fb + 32 * j * 32);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -383,28 +437,13 @@ __global__ __launch_bounds__(256) void bf16x3_gemm_kernel(GemmArgs g, X3Planes p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail requests must not outlive the workgroup's LDS
 #undef INC_X3_DMA
   }
-  float* C = g.C;
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int col = n0 + wn * 64 + 32 * j + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + 32 * i + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-        if (row < g.M && col < g.N) {
-          float* c = C + (int64_t)row * g.ldc + col;
-          float v = g.alpha * acc[i][j][r];
-          if (g.beta != 0.f) v += g.beta * *c;
-          *c = v;
-        }
-      }
-    }
+  gemm_epilogue<MI, NI>(g, g.C, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // the split pre-pass of one operand into `dst` (3 planes of Rp x kq bf16); returns the bytes it occupies
-int64_t launch_split3(const float* src, int64_t ld, int rows, int cols, bool tr, uint16_t* dst, int64_t* plane_out, int64_t* rp_out, hipStream_t s) {
-  const int64_t Rp = ceil_div64(rows, 128) * 128, nkb = ceil_div64(cols, X3_KB), plane = nkb * Rp * X3_KB;
+int64_t launch_split3(const float* src, int64_t ld, int rows, int cols, bool tr, int row_pad, uint16_t* dst, int64_t* plane_out, int64_t* rp_out,
+                      hipStream_t s) {
+  const int64_t Rp = ceil_div64(rows, row_pad) * row_pad, nkb = ceil_div64(cols, X3_KB), plane = nkb * Rp * X3_KB;
   dim3 grid((unsigned)ceil_div64(cols, 64), (unsigned)(Rp / 64));
   if (tr) ifac_split3_kernel<true><<<grid, 256, 0, s>>>(src, ld, rows, cols, dst, plane, Rp, (int)nkb);
   else ifac_split3_kernel<false><<<grid, 256, 0, s>>>(src, ld, rows, cols, dst, plane, Rp, (int)nkb);
@@ -436,16 +475,16 @@ int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s, void*
       ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) {
     X3Planes p;
     uint16_t* pa = static_cast<uint16_t*>(planes);
-    const int64_t abytes = launch_split3(g.A, g.lda, g.M, g.K, false, pa, &p.a_plane, &p.RpA, s);
+    const int64_t abytes = launch_split3(g.A, g.lda, g.M, g.K, false, 128, pa, &p.a_plane, &p.RpA, s);
     p.Ap = pa;
     if (b_nt && g.B == g.A && g.ldb == g.lda && g.N == g.M) {  // syrk form: one operand
       p.Bp = pa; p.b_plane = p.a_plane; p.RpB = p.RpA;
     } else {
       uint16_t* pb = reinterpret_cast<uint16_t*>(static_cast<char*>(planes) + abytes);
-      (void)launch_split3(g.B, g.ldb, g.N, g.K, !b_nt, pb, &p.b_plane, &p.RpB, s);
+      (void)launch_split3(g.B, g.ldb, g.N, g.K, !b_nt, 128, pb, &p.b_plane, &p.RpB, s);
       p.Bp = pb;
     }
-    bf16x3_gemm_kernel<<<grid, 256, 0, s>>>(g, p);
+    bf16x3_gemm_kernel<128><<<grid, 256, 0, s>>>(g, p);
   } else if (big) {
     if (b_nt) f32gemm_kernel<128, 128, true><<<grid, 256, 0, s>>>(g);
     else f32gemm_kernel<128, 128, false><<<grid, 256, 0, s>>>(g);
@@ -490,11 +529,11 @@ struct Seg {
 extern "C" {
 
 // A [Kp, Kp] + X [Kp, Kp] + T [Kp, Kp] + 2 x P [Kp, IFAC_OUTER] fp32, Kp = K rounded up to 128; with flags bit 1 two operands of
-// three bf16 planes each behind them (12 Kp^2 bytes)
+// three bf16 planes each behind them (12 (Kp + 128) Kp bytes: rows padded to the GEMM's 256-row tile)
 int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K, int flags) {
   if (K <= 0) return 0;
   const int64_t Kp = ceil_div64(K, IFAC_NB) * IFAC_NB;
-  return (3 * Kp * Kp + 2 * Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float) + ((flags & 2) ? 12 * Kp * Kp : 0);
+  return (3 * Kp * Kp + 2 * Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float) + ((flags & 2) ? 12 * (Kp + 128) * Kp : 0);
 }
 
 int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace, int64_t workspace_bytes, int32_t* info, int flags,
