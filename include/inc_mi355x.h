@@ -301,8 +301,9 @@ int inc_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, 
  *   (3 Kp^2 + 2048 Kp floats, Kp = K rounded up to 128).
  *   info: device int32, written by the call: 0, or the (1-based) index of the last 128-column diagonal block with a
  *   non-positive pivot (H not positive definite -- the reference's torch.linalg.cholesky raises there); U is
- *   undefined in that case.  flags: bit 0 = ignore aux_stream (one stream); bit 1 = EXPERIMENTAL: the large products with
- *   their fp32 operands split into three bf16 pieces (six bf16 MFMAs per product; not the exact-fp32 arithmetic of the default).                                                                             */
+ *   undefined in that case.  flags: bit 0 = ignore aux_stream (one stream); bit 1 = the large products with
+ *   their fp32 operands split into three bf16 pieces (six bf16 MFMAs per fp32 product: dropped terms <= 2^-24 |a b|, same distance to an
+ *   fp64 factor as the exact-fp32 products of flags = 0, 1.3 - 2 x faster; the Python driver sets it unless INC_MI355X_CHOL_BF16X3=0).                                                                             */
 int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K, int flags);
 int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace, int64_t workspace_bytes, int32_t* info,
                             int flags, inc_stream_t stream, inc_stream_t aux_stream);

@@ -9,6 +9,8 @@
 // algorithm from Python with torch.mm for every product; this file owns all of it:
 //   * f32gemm_kernel        exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: fmaf-chain semantics), NT and NN forms,
 //                           triangular operands skipped by K-range per tile, lower-triangle-only outputs (syrk), batched pairs
+//   * ifac_split3_kernel + bf16x3_gemm_kernel (flags bit 1)  the large products with their operands pre-split into three bf16 planes:
+//                           six bf16 MFMAs per fp32 product, LDS-DMA ring (see the comment in front of them)
 //   * chol_diag_block_kernel (chol.hip) the 128 x 128 diagonal block: factor + inverse of the factor in one workgroup
 //   * ifac_flip_* / ifac_copy_panel: index reversal in / out, panel write-back
 //   * the host side below issues them on the caller's stream (+ an optional second stream for the look-ahead over outer blocks)
