@@ -9,7 +9,7 @@ BENCH_MIN="--no-cpu-baseline --no-gemm --no-extra-configs --no-e2e --no-per-laye
 while [[ $# -gt 0 ]]; do
   case $1 in
     tests)
-      timeout 1700 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+      timeout 1700 python -m pytest tests -m gpu -q -s --timeout=900 -p no:cacheprovider --durations=30 > gpurun_out/pytest_gpu.log 2>&1
       echo "pytest exit $?" | tee -a gpurun_out/pytest_gpu.log
       grep -E "passed|failed|Error|error" gpurun_out/pytest_gpu.log | tail -30
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" | tee -a gpurun_out/smoke.log
