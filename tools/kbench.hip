@@ -987,6 +987,64 @@ static void run_probe() {
   }
 }
 
+// ---- LDS-DMA bandwidth probe: how many bytes per clock does ONE CU pull from L2 / HBM into LDS, as a function of the 1-KiB pieces
+// it keeps in flight?  (The Hessian syrk and the split-product GEMM both need ~32 B/clk/CU and get ~18: is that latency x bytes
+// in flight, or the issue rate of global_load_lds_dwordx4?)  One workgroup per CU (128 KiB of LDS), WAVES waves, each keeps DEPTH
+// pieces in flight (issue one, wait until DEPTH - 1 are outstanding) for `iters` pieces; the source is a `span`-byte window that
+// every workgroup walks from its own offset (span <= 2 MiB: L2-resident after the first pass; span = 4 GiB: streaming from HBM).
+template <int DEPTH>
+__global__ __launch_bounds__(1024) void dmabw_kernel(const char* __restrict__ src, uint64_t span, int iters, uint32_t* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(1024))) char dm_smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dm_smem + wave * 8192);  // 8 slots of 1 KiB per wave
+  const uint32_t voff = lane * 16;
+  uint64_t pos = (((uint64_t)blockIdx.x * nw + wave) * 1024 * 64) & (span - 1);  // workgroups start 64 KiB x waves apart
+  const uint64_t stride = (uint64_t)nw * 1024;                          // a workgroup's waves read consecutive pieces
+  for (int i = 0; i < iters; ++i) {
+    const char* sp = src + pos;
+    const uint32_t dst = lds0 + (i & 7) * 1024;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sp), "s"(dst) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(DEPTH - 1) : "memory");
+    pos = (pos + stride * 61) & (span - 1);  // (span is a power of two) an odd multiple of the stride: neighbouring pieces far apart in time
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = *reinterpret_cast<uint32_t*>(dm_smem);
+}
+static void run_dmabw() {
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  const uint64_t big = (uint64_t)4 << 30;
+  DevBuf<char> buf((size_t)big);
+  HIPCHECK(hipMemset(buf.p, 1, big));
+  DevBuf<uint32_t> sink(4096);
+  const int smem = 128 * 1024;
+  printf("DMABW: one workgroup per CU (%d), 1-KiB pieces by global_load_lds_dwordx4; GB/s per CU and B/clk at 2.1 GHz\n", cus);
+  for (uint64_t span : {(uint64_t)1 << 20, big}) {
+    for (int waves : {4, 8, 16}) {
+      for (int depth : {1, 2, 4, 8}) {
+        const int iters = 2048 / (waves / 4);  // ~the same bytes per workgroup for every wave count
+        auto launch = [&]() {
+#define DM_CASE(D) case D: (void)hipFuncSetAttribute((const void*)dmabw_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+                           dmabw_kernel<D><<<cus, waves * 64, smem>>>(buf.p, span, iters, sink.p); break;
+          switch (depth) { DM_CASE(1) DM_CASE(2) DM_CASE(4) DM_CASE(8) }
+#undef DM_CASE
+        };
+        launch();
+        HIPCHECK(hipDeviceSynchronize());
+        Timer t;
+        t.start();
+        for (int r = 0; r < 5; ++r) launch();
+        const float ms = t.stop_ms() / 5;
+        const double bytes_cu = (double)waves * iters * 1024, gbs = bytes_cu / (ms * 1e-3) / 1e9;
+        printf("DMABW %-9s waves=%2d in-flight=%3d KiB/CU : %7.3f ms  %7.1f GB/s per CU = %5.1f B/clk, chip %6.2f TB/s, latency by Little's law %5.2f us\n",
+               span == big ? "streaming" : "L2 1 MiB", waves, waves * depth, ms, gbs, gbs / 2.1, gbs * cus / 1e3, (double)waves * depth * 1024 / (gbs * 1e3));
+      }
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const std::string what = argc > 1 ? argv[1] : "all";
   hipDeviceProp_t prop;
@@ -1021,6 +1079,7 @@ int main(int argc, char** argv) {
     fails += run_d2r_case(4096, 4096, 11008, 128, true, false, true, false);
     fails += run_d2r_case(8192, 4096, 4096, 128, false, true, true, false);
   }
+  if (what == "dmabw") run_dmabw();
   if (what == "stripabl") {  // timing-only ablations of the mid-M strip kernel (outputs are wrong by construction)
     for (int64_t M : {128, 512}) {
       const int64_t N = 4096, K = 4096;
