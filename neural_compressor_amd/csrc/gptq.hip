@@ -263,17 +263,22 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
   if (f > K - 8) f = K - 8;  // K % 8 == 0 on this path: a chunk past K only feeds rows / columns that are never stored
   const uint32_t voff = (uint32_t)(f * 2);
   const int nk = (int)((T + TOK - 1) / TOK);
-  auto issue = [&](int kt) {
+  auto issue_one = [&](int kt, int i) {
     const int stage = kt & (NST - 1);
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int r = wave * RPW + i;
-      int64_t t = (int64_t)kt * TOK + r;
-      if (t > T - 1) t = T - 1;  // rows past T are zeroed in LDS before they are multiplied (below)
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + r * TR_PITCH);
-      if constexpr ((ABL & 1) == 0) lds_dma_1k(x + t * ldx, dst, voff);
-    }
+    const int r = wave * RPW + i;
+    int64_t t = (int64_t)kt * TOK + r;
+    if (t > T - 1) t = T - 1;  // rows past T are zeroed in LDS before they are multiplied (below)
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + r * TR_PITCH);
+    if constexpr ((ABL & 1) == 0) lds_dma_1k(x + t * ldx, dst, voff);
   };
+  auto issue = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) issue_one(kt, i);
+  };
+  // ABL bit 2 (harness A/B, CORRECT results): the step's RPW requests are not issued back to back at the top of the step but one
+  // behind every (8 * TOK / 32 / RPW)-th row of four MFMAs -- a piece costs its wave 60-185 issue cycles (profiles/NOTES.md)
+  constexpr bool SPREAD = (ABL & 4) != 0;
+  constexpr int SLOTS = 8 * (TOK / 32), SLOT_EVERY = SLOTS / RPW > 0 ? SLOTS / RPW : 1;
   // step `next` has landed when at most the steps after it (up to `last_issued`) are still in this wave's queue
   auto wait_landed = [&](int next, int last_issued) {
     const int younger = last_issued - next;
@@ -308,7 +313,8 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
   __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & (NST - 1);
-    if (kt + D < nk) issue(kt + D);  // its stage was last read in step kt - 1 (barrier passed)
+    const bool more = kt + D < nk;
+    if (!SPREAD && more) issue(kt + D);  // its stage was last read in step kt - 1 (barrier passed)
     if (kt == nk - 1 && (T % TOK) != 0) {
       // token tail: zero the rows past T of this (last) stage; its DMA has landed (counted wait + barrier of the previous step)
       const int first = (int)(T - (int64_t)kt * TOK);
@@ -327,7 +333,7 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
 #pragma unroll
       for (int m = 0; m < 8; ++m) a[m] = frag(st + rbase + m * 32);
 #pragma unroll
-      for (int m = 0; m < 8; ++m)
+      for (int m = 0; m < 8; ++m) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           if constexpr (IS_BF16) {
@@ -342,6 +348,15 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa8, fb8, acc[m][n], 0, 0, 0);
           }
         }
+        if constexpr (SPREAD) {
+          const int slot = kk * 8 + m;
+          if (slot % SLOT_EVERY == SLOT_EVERY - 1 && slot / SLOT_EVERY < RPW) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_one(kt + D, slot / SLOT_EVERY);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
     }
     // every fragment read of this step has returned (the compiler sinks the last MFMAs below the barrier, so this is not
     // implied by program order) and step kt + 1 has landed (younger steps stay in flight)
@@ -1260,9 +1275,18 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
 #define INC_HABL(A) { (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_kernel<true, TR_TOK, TR_NST, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); \
                       hessian_syrk_tr_256_kernel<true, TR_TOK, TR_NST, A><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2); }
           if (habl == 1) INC_HABL(1) else if (habl == 2) INC_HABL(2) else INC_HABL(3)
-#undef INC_HABL
           INC_LAUNCH_RETURN();
         }
+        if (habl == 4 && xdtype == INC_BF16) {  // 50: CORRECT results, the DMA requests spread over the step's MFMA rows
+          INC_HABL(4)
+          INC_LAUNCH_RETURN();
+        }
+        if (habl == 5 && xdtype == INC_BF16) {  // 51: the same with four 32-token stages (three steps in flight)
+          (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_kernel<true, 32, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+          hessian_syrk_tr_256_kernel<true, 32, 4, 4><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);
+          INC_LAUNCH_RETURN();
+        }
+#undef INC_HABL
 #endif
         if (xdtype == INC_BF16) hessian_syrk_tr_256_kernel<true><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);
         else hessian_syrk_tr_256_kernel<false><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);

@@ -713,15 +713,30 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
     const double e = fabs(got - want) / (fabs(want) + 1e-3 * sqrt((double)T));
     if (e > maxrel) maxrel = e;
   }
-  const bool ok = rel < 1e-5 && maxrel < 1e-3;
-  printf("HESSIAN T=%ld K=%ld: rel(256-tile vs 128-tile)=%.2e (%ld entries differ) max rel err vs fp64 on %d samples=%.2e  %s\n", (long)T,
-         (long)K, rel, (long)differ, ns, maxrel, ok ? "OK" : "FAIL");
+  // flag 50: the same tile with its LDS-DMA requests spread over the step's MFMA rows -- same arithmetic, same bits
+  int64_t spread_differ = 0;
+  if (K % 8 == 0) {
+    Hold.zero();
+    inc_debug_set_small_tiles(50);
+    INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, Hold.p, 0.f, 1.f, nullptr));
+    INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, Hold.p, 0.5f, 0.25f, nullptr));
+    inc_debug_set_small_tiles(0);
+    HIPCHECK(hipDeviceSynchronize());
+    ho = Hold.download();
+    for (int64_t i = 0; i < K; ++i)
+      for (int64_t j = i; j < K; ++j)
+        if (h[i * K + j] != ho[i * K + j]) ++spread_differ;
+  }
+  const bool ok = rel < 1e-5 && maxrel < 1e-3 && spread_differ == 0;
+  printf("HESSIAN T=%ld K=%ld: rel(256-tile vs 128-tile)=%.2e (%ld entries differ) max rel err vs fp64 on %d samples=%.2e; spread-DMA tile: %ld entries differ from the default  %s\n", (long)T,
+         (long)K, rel, (long)differ, ns, maxrel, (long)spread_differ, ok ? "OK" : "FAIL");
   if (time_it) {
     Timer t;
-    const int modes[7] = {0, 46, 45, 1, 47, 48, 49};
-    const char* labels[7] = {"256x256 transpose-read 2x64", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles",
-                             "  TR timing-only: no LDS-DMA", "  TR timing-only: no MFMA / frag reads", "  TR timing-only: barriers + epilogue"};
-    for (int mi = 0; mi < 7; ++mi) {
+    const int modes[10] = {0, 50, 51, 46, 45, 1, 47, 48, 49, 0};
+    const char* labels[10] = {"256x256 transpose-read 2x64", "256x256 TR 2x64, DMA spread", "256x256 TR 4x32, DMA spread", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles",
+                             "  TR timing-only: no LDS-DMA", "  TR timing-only: no MFMA / frag reads", "  TR timing-only: barriers + epilogue",
+                             "256x256 transpose-read 2x64 (again)"};
+    for (int mi = 0; mi < 10; ++mi) {
       inc_debug_set_small_tiles(modes[mi]);
       for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
       const int iters = 10;
