@@ -330,10 +330,17 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
       uint4 a[8], b[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) b[n] = frag(st + cbase + n * 32);
+      // ABL bit 3 (harness A/B, CORRECT results): the row fragments are requested two MFMA rows ahead of their use instead of all
+      // eight in front of the first MFMA (a wave then covers its own ds_read latency with its own MFMAs)
+      constexpr bool ROLL = (ABL & 8) != 0;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) a[m] = frag(st + rbase + m * 32);
+      for (int m = 0; m < (ROLL ? 2 : 8); ++m) a[m] = frag(st + rbase + m * 32);
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
+        if constexpr (ROLL) {
+          if (m + 2 < 8) a[m + 2] = frag(st + rbase + (m + 2) * 32);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           if constexpr (IS_BF16) {
@@ -1279,6 +1286,10 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
         }
         if (habl == 4 && xdtype == INC_BF16) {  // 50: CORRECT results, the DMA requests spread over the step's MFMA rows
           INC_HABL(4)
+          INC_LAUNCH_RETURN();
+        }
+        if ((habl == 6 || habl == 7) && xdtype == INC_BF16) {  // 52: spread + row fragments two rows ahead; 53: the rolling fragments alone
+          if (habl == 6) INC_HABL(12) else INC_HABL(8)
           INC_LAUNCH_RETURN();
         }
         if (habl == 5 && xdtype == INC_BF16) {  // 51: the same with four 32-token stages (three steps in flight)

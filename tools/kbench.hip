@@ -713,11 +713,13 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
     const double e = fabs(got - want) / (fabs(want) + 1e-3 * sqrt((double)T));
     if (e > maxrel) maxrel = e;
   }
-  // flag 50: the same tile with its LDS-DMA requests spread over the step's MFMA rows -- same arithmetic, same bits
+  // flags 50 / 52: the same tile with its LDS-DMA requests spread over the step's MFMA rows (and its row fragments requested two rows
+  // ahead) -- same arithmetic, same bits
   int64_t spread_differ = 0;
-  if (K % 8 == 0) {
+  for (int flag : {50, 52}) {
+    if (K % 8 != 0) break;
     Hold.zero();
-    inc_debug_set_small_tiles(50);
+    inc_debug_set_small_tiles(flag);
     INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, Hold.p, 0.f, 1.f, nullptr));
     INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, Hold.p, 0.5f, 0.25f, nullptr));
     inc_debug_set_small_tiles(0);
@@ -732,11 +734,12 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
          (long)K, rel, (long)differ, ns, maxrel, (long)spread_differ, ok ? "OK" : "FAIL");
   if (time_it) {
     Timer t;
-    const int modes[10] = {0, 50, 51, 46, 45, 1, 47, 48, 49, 0};
-    const char* labels[10] = {"256x256 transpose-read 2x64", "256x256 TR 2x64, DMA spread", "256x256 TR 4x32, DMA spread", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles",
+    const int modes[12] = {0, 50, 52, 53, 51, 46, 45, 1, 47, 48, 49, 0};
+    const char* labels[12] = {"256x256 transpose-read 2x64", "256x256 TR 2x64, DMA spread", "256x256 TR 2x64, spread + rolling frags", "256x256 TR 2x64, rolling frags",
+                              "256x256 TR 4x32, DMA spread", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles",
                              "  TR timing-only: no LDS-DMA", "  TR timing-only: no MFMA / frag reads", "  TR timing-only: barriers + epilogue",
                              "256x256 transpose-read 2x64 (again)"};
-    for (int mi = 0; mi < 10; ++mi) {
+    for (int mi = 0; mi < 12; ++mi) {
       inc_debug_set_small_tiles(modes[mi]);
       for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
       const int iters = 10;
