@@ -307,6 +307,11 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
     return v;
   };
 
+  // ABL bit 4 (harness A/B, CORRECT results): static priority for the second-dispatched half of the workgroup (the younger wave of
+  // every SIMD loses each arbitration to the older one, MI355X_MICROARCH.md "Two waves per SIMD")
+  if constexpr ((ABL & 16) != 0) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
   const int pro = nk < D ? nk : D;
   for (int d = 0; d < pro; ++d) issue(d);
   wait_landed(0, pro - 1);
@@ -1286,6 +1291,10 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
         }
         if (habl == 4 && xdtype == INC_BF16) {  // 50: CORRECT results, the DMA requests spread over the step's MFMA rows
           INC_HABL(4)
+          INC_LAUNCH_RETURN();
+        }
+        if ((habl == 8 || habl == 9) && xdtype == INC_BF16) {  // 54: static priority for waves 4-7; 55: that + spread + rolling fragments
+          if (habl == 8) INC_HABL(16) else INC_HABL(28)
           INC_LAUNCH_RETURN();
         }
         if ((habl == 6 || habl == 7) && xdtype == INC_BF16) {  // 52: spread + row fragments two rows ahead; 53: the rolling fragments alone

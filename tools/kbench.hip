@@ -716,7 +716,7 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
   // flags 50 / 52: the same tile with its LDS-DMA requests spread over the step's MFMA rows (and its row fragments requested two rows
   // ahead) -- same arithmetic, same bits
   int64_t spread_differ = 0;
-  for (int flag : {50, 52}) {
+  for (int flag : {50, 52, 55}) {
     if (K % 8 != 0) break;
     Hold.zero();
     inc_debug_set_small_tiles(flag);
@@ -734,12 +734,13 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
          (long)K, rel, (long)differ, ns, maxrel, (long)spread_differ, ok ? "OK" : "FAIL");
   if (time_it) {
     Timer t;
-    const int modes[12] = {0, 50, 52, 53, 51, 46, 45, 1, 47, 48, 49, 0};
-    const char* labels[12] = {"256x256 transpose-read 2x64", "256x256 TR 2x64, DMA spread", "256x256 TR 2x64, spread + rolling frags", "256x256 TR 2x64, rolling frags",
+    const int modes[14] = {0, 50, 52, 53, 54, 55, 51, 46, 45, 1, 47, 48, 49, 0};
+    const char* labels[14] = {"256x256 transpose-read 2x64", "256x256 TR 2x64, DMA spread", "256x256 TR 2x64, spread + rolling frags", "256x256 TR 2x64, rolling frags",
+                              "256x256 TR 2x64, prio 1 for waves 4-7", "256x256 TR 2x64, spread + rolling + prio",
                               "256x256 TR 4x32, DMA spread", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles",
                              "  TR timing-only: no LDS-DMA", "  TR timing-only: no MFMA / frag reads", "  TR timing-only: barriers + epilogue",
                              "256x256 transpose-read 2x64 (again)"};
-    for (int mi = 0; mi < 12; ++mi) {
+    for (int mi = 0; mi < 14; ++mi) {
       inc_debug_set_small_tiles(modes[mi]);
       for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum(x.p, INC_BF16, T, K, K, H.p, 0.5f, 0.5f, nullptr));
       const int iters = 10;
