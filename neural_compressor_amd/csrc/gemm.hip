@@ -1351,13 +1351,16 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
   auto landed = [&](Par& p) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(p.s[0]), "+v"(p.s[1]), "+v"(p.z[0]), "+v"(p.z[1]) : "i"(10 * (RING - 1)) : "memory");
   };
-  auto fetch = [&](Step& t, int slot) {
+  auto fetch_issue = [&](Step& t, int slot) {
     const char* base = strip_smem + wave * (RING * SLOT) + slot * SLOT;
     const int apos = (4 * jn + (oct ^ (jn >> 2))) * 16;  // where row jn, chunk oct of an x fragment landed
 #pragma unroll
     for (int b = 0; b < 4; ++b) t.a[b] = *reinterpret_cast<const uint4*>(base + b * 1024 + apos);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) t.w[nb] = *reinterpret_cast<const uint4*>(base + 4096 + nb * 1024 + lane * 16);
+  };
+  auto fetch = [&](Step& t, int slot) {
+    fetch_issue(t, slot);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot is free for the next DMA once these have returned
   };
 
@@ -1398,7 +1401,38 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
   };
 
   static_assert(RING >= 2 && 10 * (RING - 1) < 64, "vmcnt counts 63 requests at most");
-  if (lo < hi) {
+  // ABL bit 3 (harness A/B, CORRECT results): the LDS reads of step s + 1 are requested before the MFMAs of step s (two fragment
+  // sets) instead of each step waiting for its own reads in front of its MFMAs; bit 4: s_setprio 1 around a step's dequantise + MFMA
+  if constexpr ((ABL & 8) != 0) {
+    if (lo < hi) {
+      Par p[RING];
+      Step t[2];
+#pragma unroll
+      for (int r = 0; r < RING; ++r) issue(r, p[r], lo + r);
+      landed(p[0]);
+      fetch_issue(t[0], 0);
+      for (int st = lo; st < hi; st += 2 * RING) {  // two rounds of the ring per iteration: the fragment set index stays a constant
+#pragma unroll
+        for (int rr = 0; rr < 2 * RING; ++rr) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int r = rr % RING;
+          if (st + rr < hi) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // t[rr & 1] has arrived: slot r is free
+            refresh(p[r], st + rr);
+            issue(r, p[r], st + rr + RING);
+            if (st + rr + 1 < hi) {
+              landed(p[(r + 1) % RING]);
+              fetch_issue(t[(rr + 1) & 1], (r + 1) % RING);
+            }
+            if constexpr ((ABL & 16) != 0) __builtin_amdgcn_s_setprio(1);
+            compute(t[rr & 1]);
+            if constexpr ((ABL & 16) != 0) __builtin_amdgcn_s_setprio(0);
+          }
+        }
+      }
+    }
+  } else if (lo < hi) {
     Par p[RING];  // (indexed by unrolled constants only: registers)
     Step t;
 #pragma unroll
@@ -1411,7 +1445,9 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
           fetch(t, r);
           refresh(p[r], st + r);
           issue(r, p[r], st + r + RING);
+          if constexpr ((ABL & 16) != 0) __builtin_amdgcn_s_setprio(1);
           if constexpr ((ABL & 4) == 0) compute(t);
+          if constexpr ((ABL & 16) != 0) __builtin_amdgcn_s_setprio(0);
         }
       }
     }
@@ -1698,7 +1734,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   // 32 < M <= 64 on the larger layers too (M = 64, 11008 x 4096: 21 vs 29 us for the streaming kernel, whose x fragments are
   // per-lane 16-byte gathers; at 4096^2 the streaming kernel keeps a 1 us lead).  Harness flags 42 / 40 / 4 / 6 select the tile paths, 83 this kernel for any M > 16.
   const bool strip_ok = !g_idx && bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
-                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || (dbg >= 83 && dbg <= 89));
+                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || (dbg >= 83 && dbg <= 92));
   if (strip_ok) {
     int splitk = strip_splitk(M, N, K);
     const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);
@@ -1722,9 +1758,13 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     woq_gemm_w4_strip_kernel<true, STRIP_WAVES, STRIP_RING, A><<<grid, 64 * STRIP_WAVES, STRIP_SMEM_BYTES, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, g_shift, splitk); \
   }
         if (f == 85) INC_STRIP_ABL(1) else if (f == 86) INC_STRIP_ABL(2) else if (f == 87) INC_STRIP_ABL(3) else if (f == 88) INC_STRIP_ABL(4) else INC_STRIP_ABL(7)
-#undef INC_STRIP_ABL
         INC_LAUNCH_RETURN();
       }
+      if (bf && f >= 90 && f <= 92) {  // harness A/B with CORRECT results: 90 LDS reads one step ahead, 91 s_setprio around the compute, 92 both
+        if (f == 90) INC_STRIP_ABL(8) else if (f == 91) INC_STRIP_ABL(16) else INC_STRIP_ABL(24)
+        INC_LAUNCH_RETURN();
+      }
+#undef INC_STRIP_ABL
     }
     if (bf && inc_small_tiles_flag(-1) == 84) {  // harness A/B: four waves (one per SIMD) with a six-deep ring
       (void)hipFuncSetAttribute((const void*)woq_gemm_w4_strip_kernel<true, 4, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 6 * 1024);

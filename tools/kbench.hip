@@ -431,10 +431,10 @@ static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, boo
   HIPCHECK(hipDeviceSynchronize());
   std::vector<float> href = ref.download();
   std::vector<uint16_t> hb = bias.download();
-  const int NV = 4;
-  const int modes[NV] = {M <= 64 ? 83 : 0, 42, M <= 64 ? 0 : 40, 84};
+  const int NV = 7;
+  const int modes[NV] = {M <= 64 ? 83 : 0, 42, M <= 64 ? 0 : 40, 84, 90, 91, 92};
   const char* labels[NV] = {"strip (LDS-DMA rings)", "PC 256-row tile + split-K", M <= 64 ? "streaming kernel (default)" : "3A2B 256-row tile + split-K",
-                            "strip, 4 waves x 6-deep ring"};
+                            "strip, 4 waves x 6-deep ring", "strip, LDS reads 1 ahead", "strip, setprio on compute", "strip, reads ahead + prio"};
   int fails = 0;
   std::vector<uint16_t> first;
   for (int mi = 0; mi < NV; ++mi) {
