@@ -1049,7 +1049,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, const ui
 constexpr int VS = 8;   // largest VSTEPS (sizes the workspace)
 // MB = 16-row blocks of x per workgroup (M <= 16 * MB): batched decode (16 < M <= 64) streams the packed weights ONCE like the
 // M <= 16 case -- every dequantised B fragment feeds MB MFMAs -- instead of parking a 256-row tile that is mostly clamped rows.
-template <bool IS_BF16, bool G128, int VSTEPS, int MB>
+// NT (harness A/B, same results): the packed-weight requests carry the non-temporal hint -- every word is read once by one CU
+template <bool IS_BF16, bool G128, int VSTEPS, int MB, bool NT = false>
 __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
@@ -1075,7 +1076,13 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
   for (int s = 0; s < VS; ++s) {
     int st = step0 + s;
     if (st > steps_total - 1) st = steps_total - 1;  // past-the-end steps re-read the last one and are zeroed via A
-    w[s] = *reinterpret_cast<const uint4*>(qweight + ((int64_t)st * 4 + oct) * N + ncol);
+    if constexpr (NT) {
+      typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+      const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(qweight + ((int64_t)st * 4 + oct) * N + ncol));
+      w[s] = make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+      w[s] = *reinterpret_cast<const uint4*>(qweight + ((int64_t)st * 4 + oct) * N + ncol);
+    }
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
       const int am = 16 * b + jn < M ? 16 * b + jn : M - 1;  // A row (clamped; rows >= M are zeroed below)
@@ -1559,7 +1566,7 @@ constexpr int GEMV16_WAVES = 16;
 constexpr int GEMV16_CH = 12;                                              // K-steps per wave and pass whose loads are issued up front
 constexpr int64_t GEMV16_MAX_K = (int64_t)32 * GEMV16_WAVES * 2 * GEMV16_CH;  // two passes: K <= 12288
 
-template <bool IS_BF16>
+template <bool IS_BF16, bool NT = false>
 __global__ __launch_bounds__(64 * GEMV16_WAVES) void woq_gemv16_w4_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int M, int64_t N, int64_t K,
@@ -1590,7 +1597,7 @@ __global__ __launch_bounds__(64 * GEMV16_WAVES) void woq_gemv16_w4_kernel(
       int st = c0 + s;
       if (st > hi - 1) st = hi - 1;  // steps past the end re-read the last one and are skipped below
       const int64_t g = g_shift >= 0 ? (((int64_t)st * 32) >> g_shift) : 0;
-      w[s] = wcol[(int64_t)st * 4 * N];
+      w[s] = NT ? __builtin_nontemporal_load(wcol + (int64_t)st * 4 * N) : wcol[(int64_t)st * 4 * N];
       sraw[s] = scales[g * N + ncol];
       zraw[s] = qzeros[g * NW + (ncol >> 3)];
       a[s] = *reinterpret_cast<const uint4*>(xrow + (int64_t)st * 32);
@@ -1918,6 +1925,19 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     if (bits == 4) { if (bf) INC_TILE(4, true); else INC_TILE(4, false); }
     else { if (bf) INC_TILE(8, true); else INC_TILE(8, false); }
 #undef INC_TILE
+#ifdef INC_KBENCH
+  } else if (gemv_ok && M <= 16 && K <= GEMV16_MAX_K && bf && dbg == 93) {  // harness: the no-split decode kernel with non-temporal weight loads
+    woq_gemv16_w4_kernel<true, true><<<(unsigned)ceil_div64(N, 16), 64 * GEMV16_WAVES, 0, s>>>(xp, qw, scales, qz, bp, yp, (int)M, N, K, NW, g_shift);
+  } else if (gemv_ok && M <= 16 && bf && dbg == 94 && (g_shift == -1 || g_shift >= 7)) {  // harness: the streaming kernel, non-temporal weight loads
+    const bool vs4 = ceil_div64(N, 64) * ceil_div64(K, 32 * 8 * 4) < 512 && ceil_div64(K, 32 * 4 * 4) <= 64;
+    const int splitk = (int)ceil_div64(K, 32 * (vs4 ? 4 : 8) * 4);
+    if (!workspace || workspace_bytes < WS_COUNTER_BYTES + (int64_t)splitk * M * N * 4) return INC_ERR_WORKSPACE;
+    unsigned* counters = (unsigned*)workspace;
+    float* part = (float*)((char*)workspace + WS_COUNTER_BYTES);
+    dim3 grid((unsigned)ceil_div64(N, 64), (unsigned)splitk);
+    if (vs4) woq_gemv_w4_kernel<true, true, 4, 1, true><<<grid, 256, 0, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, G, g_shift, splitk);
+    else woq_gemv_w4_kernel<true, true, 8, 1, true><<<grid, 256, 0, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW, G, g_shift, splitk);
+#endif
   } else if (gemv_ok && M <= 16 && K <= GEMV16_MAX_K && (dbg == 85 || (dbg == 0 && M <= 4 && N <= 4096 && K <= 4096))) {
     // decode without split-K: one workgroup of 16 waves per 16 columns, the whole of K.  Wins where its N / 16 workgroups are a
     // single round on the chip and x is <= 4 rows (M = 1, 4096^2: 5.9 vs 6.8 us); elsewhere the streaming kernel's 64-column

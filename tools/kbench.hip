@@ -513,10 +513,10 @@ static int run_decode_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bo
   HIPCHECK(hipDeviceSynchronize());
   std::vector<float> href = ref.download();
   std::vector<uint16_t> hb = bias.download();
-  const int modes[2] = {0, 85};
-  const char* labels[2] = {"default dispatch", "16 columns x whole K (no split-K)"};
+  const int modes[5] = {0, 85, 93, 94, 0};
+  const char* labels[5] = {"default dispatch", "16 columns x whole K (no split-K)", "no split-K, non-temporal W loads", "streaming, non-temporal W loads", "default dispatch (again)"};
   int fails = 0;
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < 4; ++mi) {  // (flag 93 needs K <= 12288: the dispatch falls back to the default otherwise)
     inc_debug_set_small_tiles(modes[mi]);
     y.zero();
     INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
@@ -540,12 +540,12 @@ static int run_decode_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bo
   if (time_it) {
     Timer t;
     const int rounds = 5, iters = 200;
-    std::vector<std::vector<float>> ms(2);
+    std::vector<std::vector<float>> ms(5);
     for (int i = 0; i < 50; ++i)
       INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
     for (int r = 0; r < rounds; ++r)
-      for (int vi = 0; vi < 2; ++vi) {
-        const int mi = (vi + r) % 2;
+      for (int vi = 0; vi < 5; ++vi) {
+        const int mi = (vi + r) % 5;
         inc_debug_set_small_tiles(modes[mi]);
         INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
         t.start();
@@ -554,7 +554,7 @@ static int run_decode_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bo
         ms[mi].push_back(t.stop_ms() / iters);
       }
     const double bytes = (double)N * K / 2 + (double)W.G * N * 2 + (double)W.G * (N / 8) * 4 + (double)M * K * 2 + (double)M * N * 2;
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 5; ++mi) {
       std::sort(ms[mi].begin(), ms[mi].end());
       const float med = ms[mi][ms[mi].size() / 2];
       printf("  %-36s median %8.2f us %8.1f GB/s\n", labels[mi], med * 1e3, bytes / med / 1e6);
