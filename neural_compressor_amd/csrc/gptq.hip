@@ -1038,6 +1038,7 @@ constexpr int L2T = 128;  // rows / columns of a lazy-update tile
 
 #ifdef INC_KBENCH  // superseded by the third generation below; harness flag 86, its bitwise A/B partner (tools/kbench colloop / qlayer)
 #include "../../tools/kbench_gptq_2.inc"
+#include "../../tools/kbench_gptq_3.inc"  // harness flag 96: the lazy update with split (bf16 x 3) products -- an experiment, not the product
 #endif  // INC_KBENCH
 
 // ---------------------------------------------------------------------------------------------
@@ -1588,6 +1589,9 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
                 (col_end == K || ((col_end - col_begin) % L2T) == 0));
   if (col_begin == col_end) return INC_OK;
   if (!(count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32))) return INC_ERR_UNSUPPORTED;
+#ifdef INC_KBENCH
+  if (inc_small_tiles_flag(-1) == 96 && launch_lazy_update_x3(w, err, N, K, i1, col_begin, col_end, inc_s(stream))) INC_LAUNCH_RETURN();
+#endif
   if (inc_small_tiles_flag(-1) != 86) {
     launch_lazy_update_v3(w, Hinv, err, N, K, i1, col_begin, col_end, inc_s(stream));
     INC_LAUNCH_RETURN();
@@ -1696,5 +1700,20 @@ done:
   if (rest_done) (void)hipEventDestroy(rest_done);
   return rc;
 }
+
+#ifdef INC_KBENCH
+// harness only (tools/kbench qlayer): operand planes of the split-product lazy update.  `planes` must hold
+// inc_debug_lazy_x3_bytes(N, K) bytes: Hinv^T planes (written here, once per layer) followed by scratch for two sets of Err1 planes.
+int64_t inc_debug_lazy_x3_bytes(int64_t N, int64_t K) { return lazyx3_planes_bytes(K, K) + 2 * lazyx3_planes_bytes(N, 128); }
+int inc_debug_lazy_x3_prepare(const float* Hinv, int64_t N, int64_t K, void* planes, inc_stream_t stream) {
+  LazyX3State& g = g_lazyx3;
+  if (!planes) { g = LazyX3State(); return INC_OK; }
+  uint16_t* hp = static_cast<uint16_t*>(planes);
+  lazyx3_split(Hinv, K, K, K, true, hp, &g.hinv_plane, &g.hinv_rp, inc_s(stream));
+  g.hinv_planes = hp;
+  g.err_planes = reinterpret_cast<uint16_t*>(static_cast<char*>(planes) + lazyx3_planes_bytes(K, K));
+  INC_LAUNCH_RETURN();
+}
+#endif
 
 }  // extern "C"

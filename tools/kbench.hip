@@ -330,6 +330,8 @@ static int run_d2r_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bool 
 
 // ---- per-workgroup timeline of the direct-to-register dequant-GEMM (harness flag 98): where the kernel's span goes ----
 extern "C" int inc_debug_set_d2r_timeline(void* dev_buffer);
+extern "C" int64_t inc_debug_lazy_x3_bytes(int64_t N, int64_t K);
+extern "C" int inc_debug_lazy_x3_prepare(const float* Hinv, int64_t N, int64_t K, void* planes, inc_stream_t stream);
 extern "C" void inc_debug_set_d2r_abl(int abl);
 static void run_d2r_timeline(int64_t M, int64_t N, int64_t K, int abl = 256, const char* label = "full kernel") {
   Packed W(N, K, 128, true);
@@ -938,11 +940,16 @@ static int run_qlayer_case(int64_t N, int64_t K, int gs) {
   Hinv.upload(hh);
   hipStream_t aux;
   HIPCHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-  const int flag[2] = {0, 86};
-  std::vector<uint8_t> codes[2];
-  std::vector<float> scales[2];
-  float ms[2] = {0, 0}, host_ms[2] = {0, 0};
-  for (int m = 0; m < 2; ++m) {
+  // third variant (flag 96, an EXPERIMENT): the lazy update with split (bf16 x 3) products -- not bit-identical by construction; the
+  // count of differing codes and the time are the result
+  const bool x3 = (K % 128) == 0;
+  DevBuf<char> planes((size_t)(x3 ? inc_debug_lazy_x3_bytes(N, K) : 16));
+  const int flag[3] = {0, 86, 96};
+  std::vector<uint8_t> codes[3];
+  std::vector<float> scales[3];
+  float ms[3] = {0, 0, 0}, host_ms[3] = {0, 0, 0};
+  for (int m = 0; m < (x3 ? 3 : 2); ++m) {
+    if (m == 2) INCCHECK(inc_debug_lazy_x3_prepare(Hinv.p, N, K, planes.p, nullptr));
     inc_debug_set_small_tiles(flag[m]);
     DevBuf<float> W((size_t)N * K), sc((size_t)N * G), ze((size_t)N * G), ews((size_t)2 * N * 128);
     DevBuf<uint8_t> C((size_t)N * K);
@@ -966,7 +973,21 @@ static int run_qlayer_case(int64_t N, int64_t K, int gs) {
     scales[m] = sc.download();
   }
   inc_debug_set_small_tiles(0);
+  INCCHECK(inc_debug_lazy_x3_prepare(nullptr, 0, 0, nullptr, nullptr));
   HIPCHECK(hipStreamDestroy(aux));
+  if (x3) {
+    int64_t dc3 = 0, rows3 = 0;
+    double ds3 = 0;
+    for (int64_t r = 0; r < N; ++r) {
+      bool any = false;
+      for (int64_t c = 0; c < K; ++c)
+        if (codes[0][(size_t)r * K + c] != codes[2][(size_t)r * K + c]) { ++dc3; any = true; }
+      rows3 += any;
+    }
+    for (size_t i = 0; i < scales[0].size(); ++i) ds3 = std::max(ds3, (double)fabsf(scales[0][i] - scales[2][i]) / (fabsf(scales[0][i]) + 1e-30));
+    printf("QLAYER N=%ld K=%ld gs=%d [split-product lazy update, EXPERIMENT]: %.3f ms (%.3f exact fp32), %ld of %ld codes differ in %ld rows, max rel scale diff %.2e\n",
+           (long)N, (long)K, gs, ms[2], ms[0], (long)dc3, (long)(N * K), (long)rows3, ds3);
+  }
   int64_t dc = 0, ds = 0;
   for (size_t i = 0; i < codes[0].size(); ++i) dc += codes[0][i] != codes[1][i];
   for (size_t i = 0; i < scales[0].size(); ++i) ds += memcmp(&scales[0][i], &scales[1][i], 4) != 0;
