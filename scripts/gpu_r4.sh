@@ -25,6 +25,15 @@ while [[ $# -gt 0 ]]; do
     kbench)
       shift
       timeout 600 tools/kbench $1 > gpurun_out/kbench_$1.log 2>&1; echo "kbench $1 exit $?"; tail -70 gpurun_out/kbench_$1.log ;;
+    harness)
+      # the variants prepared at the end of round 4 (profiles/NOTES.md "Prepared for round 5"): one log per kbench mode
+      for m in hessian qlayer strip decode; do
+        timeout 300 tools/kbench $m > gpurun_out/kbench_r5_$m.log 2>&1; echo "kbench $m exit $?"
+      done
+      grep -E "spread|rolling|prio|transpose-read 2x64|FAIL" gpurun_out/kbench_r5_hessian.log | tail -40
+      grep -E "QLAYER" gpurun_out/kbench_r5_qlayer.log | tail -12
+      grep -E "median|FAIL" gpurun_out/kbench_r5_strip.log | tail -60
+      grep -E "median|FAIL" gpurun_out/kbench_r5_decode.log | tail -40 ;;
     timeline)
       # one-step timelines (kernel trace + copies) of the bench step, late solve off / on
       for late in 0 1; do
