@@ -1741,7 +1741,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   // 32 < M <= 64 on the larger layers too (M = 64, 11008 x 4096: 21 vs 29 us for the streaming kernel, whose x fragments are
   // per-lane 16-byte gathers; at 4096^2 the streaming kernel keeps a 1 us lead).  Harness flags 42 / 40 / 4 / 6 select the tile paths, 83 this kernel for any M > 16.
   const bool strip_ok = !g_idx && bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
-                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || (dbg >= 83 && dbg <= 92));
+                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || (dbg >= 83 && dbg <= 89) || (dbg >= 100 && dbg <= 102));
   if (strip_ok) {
     int splitk = strip_splitk(M, N, K);
     const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);
@@ -1767,8 +1767,8 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
         if (f == 85) INC_STRIP_ABL(1) else if (f == 86) INC_STRIP_ABL(2) else if (f == 87) INC_STRIP_ABL(3) else if (f == 88) INC_STRIP_ABL(4) else INC_STRIP_ABL(7)
         INC_LAUNCH_RETURN();
       }
-      if (bf && f >= 90 && f <= 92) {  // harness A/B with CORRECT results: 90 LDS reads one step ahead, 91 s_setprio around the compute, 92 both
-        if (f == 90) INC_STRIP_ABL(8) else if (f == 91) INC_STRIP_ABL(16) else INC_STRIP_ABL(24)
+      if (bf && f >= 100 && f <= 102) {  // harness A/B with CORRECT results: 100 LDS reads one step ahead, 101 s_setprio around the compute, 102 both
+        if (f == 100) INC_STRIP_ABL(8) else if (f == 101) INC_STRIP_ABL(16) else INC_STRIP_ABL(24)
         INC_LAUNCH_RETURN();
       }
 #undef INC_STRIP_ABL
@@ -1926,9 +1926,9 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     else { if (bf) INC_TILE(8, true); else INC_TILE(8, false); }
 #undef INC_TILE
 #ifdef INC_KBENCH
-  } else if (gemv_ok && M <= 16 && K <= GEMV16_MAX_K && bf && dbg == 93) {  // harness: the no-split decode kernel with non-temporal weight loads
+  } else if (gemv_ok && M <= 16 && K <= GEMV16_MAX_K && bf && dbg == 103) {  // harness: the no-split decode kernel with non-temporal weight loads
     woq_gemv16_w4_kernel<true, true><<<(unsigned)ceil_div64(N, 16), 64 * GEMV16_WAVES, 0, s>>>(xp, qw, scales, qz, bp, yp, (int)M, N, K, NW, g_shift);
-  } else if (gemv_ok && M <= 16 && bf && dbg == 94 && (g_shift == -1 || g_shift >= 7)) {  // harness: the streaming kernel, non-temporal weight loads
+  } else if (gemv_ok && M <= 16 && bf && dbg == 104 && (g_shift == -1 || g_shift >= 7)) {  // harness: the streaming kernel, non-temporal weight loads
     const bool vs4 = ceil_div64(N, 64) * ceil_div64(K, 32 * 8 * 4) < 512 && ceil_div64(K, 32 * 4 * 4) <= 64;
     const int splitk = (int)ceil_div64(K, 32 * (vs4 ? 4 : 8) * 4);
     if (!workspace || workspace_bytes < WS_COUNTER_BYTES + (int64_t)splitk * M * N * 4) return INC_ERR_WORKSPACE;

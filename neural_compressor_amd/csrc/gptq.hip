@@ -1038,7 +1038,7 @@ constexpr int L2T = 128;  // rows / columns of a lazy-update tile
 
 #ifdef INC_KBENCH  // superseded by the third generation below; harness flag 86, its bitwise A/B partner (tools/kbench colloop / qlayer)
 #include "../../tools/kbench_gptq_2.inc"
-#include "../../tools/kbench_gptq_3.inc"  // harness flag 96: the lazy update with split (bf16 x 3) products -- an experiment, not the product
+#include "../../tools/kbench_gptq_3.inc"  // harness flag 106: the lazy update with split (bf16 x 3) products -- an experiment, not the product
 #endif  // INC_KBENCH
 
 // ---------------------------------------------------------------------------------------------
@@ -1590,7 +1590,7 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
   if (col_begin == col_end) return INC_OK;
   if (!(count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32))) return INC_ERR_UNSUPPORTED;
 #ifdef INC_KBENCH
-  if (inc_small_tiles_flag(-1) == 96 && launch_lazy_update_x3(w, err, N, K, i1, col_begin, col_end, inc_s(stream))) INC_LAUNCH_RETURN();
+  if (inc_small_tiles_flag(-1) == 106 && launch_lazy_update_x3(w, err, N, K, i1, col_begin, col_end, inc_s(stream))) INC_LAUNCH_RETURN();
 #endif
   if (inc_small_tiles_flag(-1) != 86) {
     launch_lazy_update_v3(w, Hinv, err, N, K, i1, col_begin, col_end, inc_s(stream));

@@ -434,7 +434,7 @@ static int run_strip_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, boo
   std::vector<float> href = ref.download();
   std::vector<uint16_t> hb = bias.download();
   const int NV = 7;
-  const int modes[NV] = {M <= 64 ? 83 : 0, 42, M <= 64 ? 0 : 40, 84, 90, 91, 92};
+  const int modes[NV] = {M <= 64 ? 83 : 0, 42, M <= 64 ? 0 : 40, 84, 100, 101, 102};
   const char* labels[NV] = {"strip (LDS-DMA rings)", "PC 256-row tile + split-K", M <= 64 ? "streaming kernel (default)" : "3A2B 256-row tile + split-K",
                             "strip, 4 waves x 6-deep ring", "strip, LDS reads 1 ahead", "strip, setprio on compute", "strip, reads ahead + prio"};
   int fails = 0;
@@ -515,10 +515,10 @@ static int run_decode_case(int64_t M, int64_t N, int64_t K, int gs, bool sym, bo
   HIPCHECK(hipDeviceSynchronize());
   std::vector<float> href = ref.download();
   std::vector<uint16_t> hb = bias.download();
-  const int modes[5] = {0, 85, 93, 94, 0};
+  const int modes[5] = {0, 85, 103, 104, 0};
   const char* labels[5] = {"default dispatch", "16 columns x whole K (no split-K)", "no split-K, non-temporal W loads", "streaming, non-temporal W loads", "default dispatch (again)"};
   int fails = 0;
-  for (int mi = 0; mi < 4; ++mi) {  // (flag 93 needs K <= 12288: the dispatch falls back to the default otherwise)
+  for (int mi = 0; mi < 4; ++mi) {  // (flag 103 needs K <= 12288: the dispatch falls back to the default otherwise)
     inc_debug_set_small_tiles(modes[mi]);
     y.zero();
     INCCHECK(inc_woq_gemm(x.p, INC_BF16, W.qweight.p, W.scales.p, W.qzeros.p, nullptr, bp, y.p, M, N, K, W.G, gs, 4, ws.p, wsb, nullptr));
@@ -940,11 +940,11 @@ static int run_qlayer_case(int64_t N, int64_t K, int gs) {
   Hinv.upload(hh);
   hipStream_t aux;
   HIPCHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-  // third variant (flag 96, an EXPERIMENT): the lazy update with split (bf16 x 3) products -- not bit-identical by construction; the
+  // third variant (flag 106, an EXPERIMENT): the lazy update with split (bf16 x 3) products -- not bit-identical by construction; the
   // count of differing codes and the time are the result
   const bool x3 = (K % 128) == 0;
   DevBuf<char> planes((size_t)(x3 ? inc_debug_lazy_x3_bytes(N, K) : 16));
-  const int flag[3] = {0, 86, 96};
+  const int flag[3] = {0, 86, 106};
   std::vector<uint8_t> codes[3];
   std::vector<float> scales[3];
   float ms[3] = {0, 0, 0}, host_ms[3] = {0, 0, 0};
