@@ -27,7 +27,7 @@ extern "C" {
 
 #define INC_OK 0
 #define INC_ERR_BAD_ARG (-1)     /* null pointer / non-positive size / inconsistent shape          */
-#define INC_ERR_UNSUPPORTED (-2) /* valid request this build does not implement (e.g. bits = 3)    */
+#define INC_ERR_UNSUPPORTED (-2) /* valid request this build does not implement (e.g. bits = 9)    */
 #define INC_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after the launch               */
 #define INC_ERR_WORKSPACE (-4)   /* workspace too small (see *_workspace_bytes)                    */
 
@@ -54,7 +54,8 @@ const char* inc_target_arch(void);         /* "gfx950"                          
  *                   numba packers torch/utils/bit_packer.py:35-278):
  *     packed[r, j] = OR_e ((raw[r, j*n_pack + e] & (2^bits-1)) << (bits*e)),  n_pack = cbits/bits
  *   raw: int32 [rows, cols]; packed: [rows, ceil(cols/n_pack)] words of `cbits` bits.
- *   bits in {2,4,8}; cbits in {8,16,32,64}.
+ *   bits in 1..8 (every width the reference's configs tune, torch/quantization/config.py:211; 3 / 5 / 6 / 7 leave the
+ *   word's high bits unused, modules.py:231); cbits in {8,16,32,64}, cbits >= bits.
  * inc_unpack_rows == INCWeightOnlyLinear.unpack_tensor (modules.py:587, :468, :558):
  *     out[r, j*n_pack+e] = (packed[r,j] << (cbits-bits*(e+1))) >>arith (cbits-bits), then & mask
  *     iff mask_sign != 0 (the reference masks iff the module has `qzeros`); out: int16.
@@ -108,7 +109,9 @@ int inc_dequant_ints(const int16_t* int_weight, const void* scales, int scale_dt
  * == INCWeightOnlyLinear.forward (modules.py:594-610) == F.linear(x, recover(), bias), without
  *   ever materialising the dense weight.  x [M,K] and y [M,N] of dtype `xdtype` (INC_BF16 or
  *   INC_F16), fp32 accumulate; weights dequantised to `xdtype` in registers.
- *   bias [N] of `xdtype` or NULL.  bits in {4, 8}.  g_idx [K] int32 or NULL: the group of every k
+ *   bias [N] of `xdtype` or NULL.  bits in 1..8: 4 and 8 take the fast kernels below; 1 / 2 / 3 / 5 / 6 / 7 (n_pack = 32 / bits
+ *   fields per word, modules.py:231) take the 128x128 tile kernel's per-element form (any group_size, any g_idx).
+ *   g_idx [K] int32 or NULL: the group of every k
  *   (act_order / HF desc_act checkpoints, modules.py:341-344, 427-431); with a g_idx the general 128x128 tile
  *   kernel (or the M <= 16 split-K kernel) looks scale / zero up per element.  A g_idx that permutes whole groups
  *   is faster through a K-sorted copy of the words and a gather of x, which MI355XWeightOnlyLinear does once per module.

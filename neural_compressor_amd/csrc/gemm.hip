@@ -42,9 +42,15 @@ __global__ __launch_bounds__(256) void woq_gemm_tile_kernel(
     const int32_t* __restrict__ g_idx, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
     int64_t M, int64_t N, int64_t K, int64_t KW, int64_t NW, int group_size, int x_vec_ok) {
   constexpr int NP = 32 / BITS;        // k per packed word
-  constexpr int WPT = GK / NP;         // packed rows per K-step
-  constexpr int BW = (WPT * GN) / 256; // words per thread per K-step (4-bit: 4, 8-bit: 8)
-  constexpr int DW = NP / 2;           // dwords per dequantised word
+  // 4 / 8 bits: a K-step is a whole number of words and a thread dequantises whole words.  Every other width the reference's
+  // configs tune (1, 2, 3, 5, 6, 7: n_pack = 32 // bits, modules.py:231 -- 10 / 6 / 5 / 4 fields with unused high bits for 3 / 5 / 6
+  // / 7) takes the ANYW form: a thread owns 32 consecutive k of one column, fetches the <= MAXW words they live in and places
+  // every field by its own k (per-element group lookup, so any group_size and any g_idx).
+  constexpr bool ANYW = !(BITS == 4 || BITS == 8);
+  constexpr int MAXW = (31 + NP - 1) / NP + 1;  // words a run of 32 k can touch
+  constexpr int WPT = ANYW ? 1 : GK / NP;         // packed rows per K-step
+  constexpr int BW = ANYW ? MAXW : (WPT * GN) / 256; // words per thread per K-step (4-bit: 4, 8-bit: 8)
+  constexpr int DW = ANYW ? 1 : NP / 2;           // dwords per dequantised word
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint16_t* smem = reinterpret_cast<uint16_t*>(smem_raw);
   constexpr int OPER = GM * GP;  // elements per operand stage (GM == GN)
@@ -100,18 +106,24 @@ __global__ __launch_bounds__(256) void woq_gemm_tile_kernel(
                            (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
       }
     }
+    if constexpr (ANYW) {
+      const int64_t kwf = (k0 + 32 * (tid >> 7)) / NP;  // first word of this thread's 32 k
 #pragma unroll
-    for (int i = 0; i < BW; ++i) {
-      const int64_t kw = k0 / NP + (tid >> 7) + 2 * i;
-      if (ncol < N && kw < KW) {
-        wb[i] = qweight[kw * N + ncol];
-        const int64_t kk = kw * NP;
-        const int64_t g = g_idx ? (int64_t)g_idx[kk] : kk / group_size;
-        gq[i] = load_group<BITS>(scales, qzeros, g, ncol, N, NW);
-      } else {
-        wb[i] = 0;
-        gq[i].s = 0.f;
-        gq[i].z = 0;
+      for (int i = 0; i < BW; ++i) wb[i] = (ncol < N && kwf + i < KW) ? qweight[(kwf + i) * N + ncol] : 0u;
+    } else {
+#pragma unroll
+      for (int i = 0; i < BW; ++i) {
+        const int64_t kw = k0 / NP + (tid >> 7) + 2 * i;
+        if (ncol < N && kw < KW) {
+          wb[i] = qweight[kw * N + ncol];
+          const int64_t kk = kw * NP;
+          const int64_t g = g_idx ? (int64_t)g_idx[kk] : kk / group_size;
+          gq[i] = load_group<BITS>(scales, qzeros, g, ncol, N, NW);
+        } else {
+          wb[i] = 0;
+          gq[i].s = 0.f;
+          gq[i].z = 0;
+        }
       }
     }
   };
@@ -123,21 +135,53 @@ __global__ __launch_bounds__(256) void woq_gemm_tile_kernel(
       const int c = tid + 256 * i;
       *reinterpret_cast<uint4*>(As + (c >> 3) * GP + (c & 7) * 8) = xa[i];
     }
+    if constexpr (ANYW) {
+      constexpr uint32_t MASK = (1u << BITS) - 1u;
+      const int kl0 = 32 * (tid >> 7);                 // first k of this thread inside the K-step
+      const int64_t kbeg = fetched_k0 + kl0;
+      const int64_t kwf = kbeg / NP;
+      uint16_t* dst = Bs + bn * GP;
+      if (ncol >= N || kbeg + 32 > K) {                // columns past N / the K tail multiply as zeros
 #pragma unroll
-    for (int i = 0; i < BW; ++i) {
-      const int kwl = (tid >> 7) + 2 * i;
-      uint32_t d[DW];
-      if (g_idx && ncol < N && fetched_k0 / NP + kwl < KW)
-        dequant_word_gidx<BITS, IS_BF16>(wb[i], scales, qzeros, g_idx, fetched_k0 + (int64_t)kwl * NP, K, ncol, N, NW, d);
-      else
-        dequant_word<BITS, IS_BF16>(wb[i], gq[i], d);
-      if constexpr (DW == 4) {
-        *reinterpret_cast<uint4*>(Bs + bn * GP + kwl * NP) = make_uint4(d[0], d[1], d[2], d[3]);
-      } else if constexpr (DW == 2) {
-        *reinterpret_cast<uint2*>(Bs + bn * GP + kwl * NP) = make_uint2(d[0], d[1]);
-      } else {
+        for (int q8 = 0; q8 < 4; ++q8) *reinterpret_cast<uint4*>(dst + kl0 + 8 * q8) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (ncol < N) {
+        int gprev = -1;
+        GroupQ gcur;
+        gcur.s = 0.f;
+        gcur.z = 0;
 #pragma unroll
-        for (int h = 0; h < DW; ++h) *reinterpret_cast<uint32_t*>(Bs + bn * GP + kwl * NP + 2 * h) = d[h];
+        for (int i = 0; i < BW; ++i) {
+#pragma unroll
+          for (int e = 0; e < NP; ++e) {
+            const int64_t k = (kwf + i) * NP + e;
+            if (k >= kbeg && k < kbeg + 32 && k < K) {
+              const int g = g_idx ? g_idx[k] : (int)((uint32_t)k / (uint32_t)group_size);  // (K < 2^31: inc_woq_gemm checks)
+              if (g != gprev) {
+                gcur = load_group<BITS>(scales, qzeros, g, ncol, N, NW);
+                gprev = g;
+              }
+              const int q = (int)((wb[i] >> (BITS * e)) & MASK);
+              const float v = (float)(int8_t)(q - gcur.z) * gcur.s;
+              dst[k - fetched_k0] = IS_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BW; ++i) {
+        const int kwl = (tid >> 7) + 2 * i;
+        uint32_t d[DW];
+        if (g_idx && ncol < N && fetched_k0 / NP + kwl < KW)
+          dequant_word_gidx<BITS, IS_BF16>(wb[i], scales, qzeros, g_idx, fetched_k0 + (int64_t)kwl * NP, K, ncol, N, NW, d);
+        else
+          dequant_word<BITS, IS_BF16>(wb[i], gq[i], d);
+        if constexpr (DW == 4) {
+          *reinterpret_cast<uint4*>(Bs + bn * GP + kwl * NP) = make_uint4(d[0], d[1], d[2], d[3]);
+        } else {
+          *reinterpret_cast<uint2*>(Bs + bn * GP + kwl * NP) = make_uint2(d[0], d[1]);
+        }
       }
     }
   };
@@ -1706,14 +1750,16 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
                  int64_t N, int64_t K, int64_t G, int group_size, int bits, void* workspace,
                  int64_t workspace_bytes, inc_stream_t stream) {
   INC_CHECK_ARG(x && qweight && scales && qzeros && y && M > 0 && N > 0 && K > 0 && G > 0 && group_size > 0);
-  if (!(bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  if (bits < 1 || bits > 8) return INC_ERR_UNSUPPORTED;
   // g_idx (per-element groups: GPTQ act_order / HF desc_act): the general tile kernels below look the group up per k; the
   // 256-row kernels assume contiguous groups (the module sorts K by group once and calls them without g_idx, modules.py)
   if (!(xdtype == INC_BF16 || xdtype == INC_F16)) return INC_ERR_UNSUPPORTED;
   const int np = 32 / bits;
   // a packed word must not straddle two groups unless g_idx is given per element... (word-granular
   // group lookup): require group boundaries on word boundaries.
-  if (!g_idx && (group_size % np) != 0 && group_size < K) return INC_ERR_UNSUPPORTED;
+  const bool anyw = !(bits == 4 || bits == 8);  // 1 / 2 / 3 / 5 / 6 / 7 bits: the tile kernel's per-element form, any group_size
+  if (!anyw && !g_idx && (group_size % np) != 0 && group_size < K) return INC_ERR_UNSUPPORTED;
+  if (anyw && K >= ((int64_t)1 << 31)) return INC_ERR_UNSUPPORTED;
   const int64_t KW = ceil_div64(K, np), NW = ceil_div64(N, np);
   hipStream_t s = inc_s(stream);
   const uint16_t* xp = (const uint16_t*)x;
@@ -1740,6 +1786,32 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
   // producer / consumer kernel fills the chip with <= 2 slabs and wins (M = 512, N = 11008: 71 vs 81 us; tools/kbench strip).
   // 32 < M <= 64 on the larger layers too (M = 64, 11008 x 4096: 21 vs 29 us for the streaming kernel, whose x fragments are
   // per-lane 16-byte gathers; at 4096^2 the streaming kernel keeps a 1 us lead).  Harness flags 42 / 40 / 4 / 6 select the tile paths, 83 this kernel for any M > 16.
+  if (anyw) {
+    const int x_vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const size_t smem = (size_t)2 * 2 * GM * GP * sizeof(uint16_t);
+    const unsigned grid = (unsigned)(ceil_div64(M, GM) * ceil_div64(N, GN));
+#define INC_TILE_W(B)                                                                                                                 \
+  {                                                                                                                                   \
+    static std::atomic<uint64_t> aset{0};                                                                                             \
+    if (inc_attr_needed(aset)) {                                                                                                      \
+      (void)hipFuncSetAttribute((const void*)woq_gemm_tile_kernel<B, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
+      (void)hipFuncSetAttribute((const void*)woq_gemm_tile_kernel<B, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
+      inc_attr_done(aset);                                                                                                            \
+    }                                                                                                                                 \
+    if (bf) woq_gemm_tile_kernel<B, true><<<grid, 256, smem, s>>>(xp, qw, scales, qz, g_idx, bp, yp, M, N, K, KW, NW, group_size, x_vec_ok);  \
+    else woq_gemm_tile_kernel<B, false><<<grid, 256, smem, s>>>(xp, qw, scales, qz, g_idx, bp, yp, M, N, K, KW, NW, group_size, x_vec_ok);    \
+  }
+    switch (bits) {
+      case 1: INC_TILE_W(1) break;
+      case 2: INC_TILE_W(2) break;
+      case 3: INC_TILE_W(3) break;
+      case 5: INC_TILE_W(5) break;
+      case 6: INC_TILE_W(6) break;
+      default: INC_TILE_W(7) break;
+    }
+#undef INC_TILE_W
+    INC_LAUNCH_RETURN();
+  }
   const bool strip_ok = !g_idx && bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
                         ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || (dbg >= 83 && dbg <= 89) || (dbg >= 100 && dbg <= 102));
   if (strip_ok) {

@@ -230,6 +230,10 @@ constexpr int TR_PITCH = 1056;
 constexpr int TR_TOK = 64;
 constexpr int TR_NST = 2;
 constexpr int TR_STAGE = TR_TOK * TR_PITCH;  // 67 584 B
+// Product form of the tile (round 5, tools/kbench hessian, profiles/r5/kbench_hessian.log): bit 5 = the step's 16 MFMA rows run as ONE
+// rolling fragment pipeline, bit 4 = static priority for waves 4-7.  Same MFMAs in the same order as the round-4 form (ABL 0,
+// harness flag 59): bit-identical H, 2-8 % less time per launch.
+constexpr int TR_ABL = 48;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -238,10 +242,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-// ABL (harness build only, timing-only, WRONG results): bit 0 no LDS-DMA, bit 1 no fragment reads and no MFMA
+// ABL bits 0 / 1 (harness build only, timing-only, WRONG results): no LDS-DMA / no fragment reads and no MFMA; bits 2 / 3 (harness
+// A/B partners, correct results): requests spread over the step / row fragments two rows ahead; bits 4 / 5: see TR_ABL.
 // `slab` != nullptr: the raw sums of this token range go to slab[256][256] instead of into H (a tile of the launch's last, partly
 // filled round computed by several workgroups: hessian_tail_finalize_kernel adds the ranges in order)
-template <bool IS_BF16, int TOK, int NST, int ABL = 0>
+template <bool IS_BF16, int TOK, int NST, int ABL = TR_ABL>
 __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
                                                      float* __restrict__ H, float beta, float alpha, int nt, int block, int nblocks,
                                                      float* __restrict__ slab = nullptr) {
@@ -307,8 +312,8 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
     return v;
   };
 
-  // ABL bit 4 (harness A/B, CORRECT results): static priority for the second-dispatched half of the workgroup (the younger wave of
-  // every SIMD loses each arbitration to the older one, MI355X_MICROARCH.md "Two waves per SIMD")
+  // ABL bit 4: static priority for the second-dispatched half of the workgroup (the younger wave of every SIMD loses each
+  // arbitration to the older one, MI355X_MICROARCH.md "Two waves per SIMD")
   if constexpr ((ABL & 16) != 0) {
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   }
@@ -329,8 +334,44 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
       }
       __syncthreads();
     }
+    // ABL bit 5: ONE rolling pipeline over the step's 8 * TOK / 32 MFMA rows -- the row fragment of row r + 2 and (at row 4 of a
+    // 32-token sub-step) the column fragments of the NEXT sub-step are requested before row r's MFMAs, so only the step's first six
+    // fragment reads are exposed (round 4: all twelve of every sub-step in front of its first MFMA)
+    if constexpr ((ABL & 32) != 0) {
+      constexpr int NKK = TOK / 32, ROWS = 8 * NKK;
+      const uint32_t st0 = lds0 + cur * STAGE;
+      uint4 bq[2][4], aq[3];
 #pragma unroll
-    for (int kk = 0; kk < ((ABL & 2) ? 0 : TOK / 32); ++kk) {
+      for (int n = 0; n < 4; ++n) bq[0][n] = frag(st0 + cbase + n * 32);
+      aq[0] = frag(st0 + rbase);
+      aq[1] = frag(st0 + rbase + 32);
+#pragma unroll
+      for (int row = 0; row < ROWS; ++row) {
+        const int kk = row / 8, m = row % 8;
+        if (row + 2 < ROWS) aq[(row + 2) % 3] = frag(st0 + ((row + 2) / 8) * 32 * TR_PITCH + rbase + ((row + 2) % 8) * 32);
+        if (m == 4 && kk + 1 < NKK) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n) bq[(kk + 1) & 1][n] = frag(st0 + (kk + 1) * 32 * TR_PITCH + cbase + n * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if constexpr (IS_BF16) {
+            bf16x8 fa8, fb8;
+            __builtin_memcpy(&fa8, &aq[row % 3], 16);
+            __builtin_memcpy(&fb8, &bq[kk & 1][n], 16);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa8, fb8, acc[m][n], 0, 0, 0);
+          } else {
+            f16x8 fa8, fb8;
+            __builtin_memcpy(&fa8, &aq[row % 3], 16);
+            __builtin_memcpy(&fb8, &bq[kk & 1][n], 16);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa8, fb8, acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < ((ABL & (2 | 32)) ? 0 : TOK / 32); ++kk) {
       const uint32_t st = lds0 + cur * STAGE + kk * 32 * TR_PITCH;
       uint4 a[8], b[4];
 #pragma unroll
@@ -405,7 +446,7 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
     }
 }
 
-template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST, int ABL = 0>
+template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST, int ABL = TR_ABL>
 __global__ __launch_bounds__(512) void hessian_syrk_tr_256_kernel(const uint16_t* __restrict__ x, int64_t T, int64_t K, int64_t ldx,
                                                                   float* __restrict__ H, float beta, float alpha, int nt) {
   hessian_syrk_tr_tile<IS_BF16, TOK, NST, ABL>(x, T, K, ldx, H, beta, alpha, nt, (int)blockIdx.x, (int)gridDim.x);
@@ -454,7 +495,7 @@ __device__ __forceinline__ void hessian_segment(int64_t T, int tok, int seg, int
   tcount = t1 > t0 ? t1 - t0 : 0;
 }
 
-template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST>
+template <bool IS_BF16, int TOK = TR_TOK, int NST = TR_NST, int ABL = TR_ABL>
 __global__ __launch_bounds__(512) void hessian_syrk_tr_256_multi_kernel(HessianBatch args, int64_t T) {
   const int gb = (int)blockIdx.x + args.block0;  // index in the whole call's grid
   int b = gb, seg = 0;
@@ -470,14 +511,14 @@ __global__ __launch_bounds__(512) void hessian_syrk_tr_256_multi_kernel(HessianB
     if (i < args.n && b >= args.first[i]) p = i;
   p = __builtin_amdgcn_readfirstlane(p);
   if (!split) {
-    hessian_syrk_tr_tile<IS_BF16, TOK, NST>(args.x[p], T, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p], args.nt[p],
+    hessian_syrk_tr_tile<IS_BF16, TOK, NST, ABL>(args.x[p], T, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p], args.nt[p],
                                   b - args.first[p], args.first[p + 1] - args.first[p]);
   } else {
     int64_t t0, tc;
     hessian_segment(T, TOK, seg, args.nseg, t0, tc);
     float* slab = args.slab + ((int64_t)(gb - args.full)) * (H2 * H2);
     if (tc > 0)
-      hessian_syrk_tr_tile<IS_BF16, TOK, NST>(args.x[p] + t0 * args.ldx[p], tc, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p],
+      hessian_syrk_tr_tile<IS_BF16, TOK, NST, ABL>(args.x[p] + t0 * args.ldx[p], tc, args.K[p], args.ldx[p], args.H[p], args.beta[p], args.alpha[p],
                                     args.nt[p], b - args.first[p], args.first[p + 1] - args.first[p], slab);
     else
       for (int i = threadIdx.x; i < H2 * H2; i += 512) slab[i] = 0.f;
@@ -1302,6 +1343,14 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
           if (habl == 6) INC_HABL(12) else INC_HABL(8)
           INC_LAUNCH_RETURN();
         }
+        if (habl == 13 && xdtype == INC_BF16) {  // 59: the round-4 form of the tile (A/B partner of TR_ABL)
+          INC_HABL(0)
+          INC_LAUNCH_RETURN();
+        }
+        if (habl >= 10 && habl <= 12 && xdtype == INC_BF16) {  // 56: rolling fragments + priority; 57: one rolling pipeline per step; 58: that + priority
+          if (habl == 10) INC_HABL(24) else if (habl == 11) INC_HABL(32) else INC_HABL(48)
+          INC_LAUNCH_RETURN();
+        }
         if (habl == 5 && xdtype == INC_BF16) {  // 51: the same with four 32-token stages (three steps in flight)
           (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_kernel<true, 32, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
           hessian_syrk_tr_256_kernel<true, 32, 4, 4><<<ntiles2, 512, smem3, s>>>(xp, T, K, ldx, H, beta, alpha, nt2);
@@ -1423,6 +1472,20 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       if (cus <= 0 || (cus % 8) != 0) cus = 256;
     }
+#ifdef INC_KBENCH
+    {  // harness flags 53 / 54 / 56 / 57 / 58: the tile variants of the single-problem launch, in the batched launch
+      const int f = inc_small_tiles_flag(-1);
+      const int mabl = f == 53 ? 8 : f == 54 ? 16 : f == 56 ? 24 : f == 57 ? 32 : f == 58 ? 48 : f == 59 ? 64 : 0;  // (64 = ABL 0)
+      if (mabl && xdtype == INC_BF16) {
+#define INC_HMV(A) { (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_multi_kernel<true, TR_TOK, TR_NST, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); \
+                     a.block0 = 0; hessian_syrk_tr_256_multi_kernel<true, TR_TOK, TR_NST, A><<<grid, 512, smem3, s>>>(a, T); }
+        if (mabl == 8) INC_HMV(8) else if (mabl == 16) INC_HMV(16) else if (mabl == 24) INC_HMV(24) else if (mabl == 32) INC_HMV(32) else if (mabl == 64) INC_HMV(0) else INC_HMV(48)
+#undef INC_HMV
+        if (a.nseg > 1) hessian_tail_finalize_kernel<<<4 * (first - a.full), 512, 0, s>>>(a);
+        INC_LAUNCH_RETURN();
+      }
+    }
+#endif
     const int chunk = per_round ? cus : grid;
     for (int b0 = 0; b0 < grid; b0 += chunk) {
       a.block0 = b0;

@@ -1,4 +1,6 @@
-// pack.hip -- K1/K2/K3: INT2/4/8 bit packing, unpacking and group-wise dequantisation (recover).
+// pack.hip -- K1/K2/K3: bit packing, unpacking and group-wise dequantisation (recover) for every width 1..8 the reference's
+// configs tune (torch/quantization/config.py:211; n_pack = compress_bits // bits, modules.py:231 -- 3 / 5 / 6 / 7 bits leave the
+// word's high bits unused).
 //
 // Replaces the Python loops of INCWeightOnlyLinear.{pack,unpack,recover,pack_tensor,unpack_tensor}
 // (reference neural_compressor/torch/algorithms/weight_only/modules.py:321-592) and the numba
@@ -15,7 +17,7 @@ constexpr int TILE = 64;           // 64 rows (n) x 64 packed words (kw) per wor
 constexpr int TILE_LD = TILE + 1;  // +1 dword pad: conflict-free column reads
 
 // ------------------------------------------------------------------------------------------
-// generic row packer / unpacker (any bits in {2,4,8} x container in {8,16,32,64})
+// generic row packer / unpacker (any bits 1..8 x container in {8,16,32,64}; n_pack = cbits / bits fields per word)
 // ------------------------------------------------------------------------------------------
 template <typename UT>
 __global__ void pack_rows_kernel(const int32_t* __restrict__ raw, UT* __restrict__ packed,
@@ -121,9 +123,11 @@ __global__ __launch_bounds__(256) void woq_pack_qweight_kernel(const IN_T* __res
     }
   }
   if (qzeros) {
-    constexpr int WPT = TILE / NP;  // words of qzeros per group and tile
+    // words of qzeros per group that START inside this tile's 64 columns (NP need not divide 64: 3 / 5 / 6 / 7 bits)
+    const int64_t j0 = (n0 + NP - 1) / NP, j1 = (n0 + TILE + NP - 1) / NP;
+    const int WPT = (int)(j1 - j0);
     for (int i = threadIdx.x; i < ng * WPT; i += 256) {
-      const int64_t g = blockIdx.x + (int64_t)(i / WPT) * gridDim.x, j = n0 / NP + (i % WPT);
+      const int64_t g = blockIdx.x + (int64_t)(i / WPT) * gridDim.x, j = j0 + (i % WPT);
       if (j < NW) {
         uint32_t word = 0;
 #pragma unroll
@@ -256,10 +260,11 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
   constexpr int NP = 32 / BITS;
   constexpr uint32_t MASK = (1u << BITS) - 1u;
   constexpr int KWT = DQ_KT / NP;                      // packed rows per tile
+  constexpr int KT = KWT * NP;                         // k-extent of the tile: 128, or 120 / 126 / 125 / 124 for 3 / 5 / 6 / 7 bits
   constexpr int LD = DQ_KT + (DT == INC_F32 ? 4 : 8);  // padded row pitch (elements): 16-byte aligned rows, 4-bank skew per row
   __shared__ __attribute__((aligned(16))) OT tile[TILE * LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t k0 = (int64_t)blockIdx.x * DQ_KT, n0 = (int64_t)blockIdx.y * TILE;
+  const int64_t k0 = (int64_t)blockIdx.x * KT, n0 = (int64_t)blockIdx.y * TILE;
   const int64_t kw0 = k0 / NP;
   const int64_t n = n0 + lane;
   // phase 1: lane = n (coalesced packed reads), waves stride over the packed rows of the tile
@@ -318,14 +323,16 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
     const int64_t k = k0 + c8;
     OT* dst = out + nn * K + k;
     const OT* src = &tile[row * LD + c8];
-    bool done = false;
+    bool done = c8 >= KT;  // (a tile of an odd width is narrower than 128)
+    if (done) continue;
+    const bool whole = c8 + 8 <= KT && k + 8 <= K && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
     if constexpr (DT != INC_F32) {
-      if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+      if (whole) {
         *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);  // (16-byte aligned: c8 * 2 bytes, LD * 2 = 272)
         done = true;
       }
     } else {
-      if (k + 8 <= K && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+      if (whole) {
         reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(src)[0];
         reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(src)[1];
         done = true;
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
     if (!done) {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        if (k + e < K) dst[e] = src[e];
+        if (c8 + e < KT && k + e < K) dst[e] = src[e];
     }
   }
 }
@@ -396,7 +403,7 @@ const char* inc_error_string(int code) {
 int inc_pack_rows(const int32_t* raw, void* packed, int64_t rows, int64_t cols, int bits, int cbits,
                   inc_stream_t stream) {
   INC_CHECK_ARG(raw && packed && rows > 0 && cols > 0);
-  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  if (bits < 1 || bits > 8) return INC_ERR_UNSUPPORTED;
   if (!(cbits == 8 || cbits == 16 || cbits == 32 || cbits == 64) || cbits < bits) return INC_ERR_UNSUPPORTED;
   const int n_pack = cbits / bits;
   const int64_t pcols = ceil_div64(cols, n_pack);
@@ -414,7 +421,7 @@ int inc_pack_rows(const int32_t* raw, void* packed, int64_t rows, int64_t cols, 
 int inc_unpack_rows(const void* packed, int16_t* out, int64_t rows, int64_t packed_cols, int bits,
                     int cbits, int mask_sign, inc_stream_t stream) {
   INC_CHECK_ARG(packed && out && rows > 0 && packed_cols > 0);
-  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  if (bits < 1 || bits > 8) return INC_ERR_UNSUPPORTED;
   if (!(cbits == 8 || cbits == 16 || cbits == 32 || cbits == 64) || cbits < bits) return INC_ERR_UNSUPPORTED;
   const int n_pack = cbits / bits;
   const int grid = grid_1d(rows * packed_cols);
@@ -433,12 +440,12 @@ int inc_woq_pack(const void* int_weight, int in_bytes, const float* scales, cons
                  int64_t G, int bits, int shift, inc_stream_t stream) {
   INC_CHECK_ARG(int_weight && qweight && N > 0 && K > 0 && G > 0);
   INC_CHECK_ARG(in_bytes == 4 || in_bytes == 1);
-  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  if (bits < 1 || bits > 8) return INC_ERR_UNSUPPORTED;
   hipStream_t s = inc_s(stream);
   const int n_pack = 32 / bits;
   const int64_t KW = ceil_div64(K, n_pack), NW = ceil_div64(N, n_pack);
   dim3 grid((unsigned)ceil_div64(KW, TILE), (unsigned)ceil_div64(N, TILE));
-  const bool vec = in_bytes == 4 && (K % n_pack == 0) && (K % 4 == 0) &&
+  const bool vec = in_bytes == 4 && (n_pack % 4 == 0) && (K % n_pack == 0) && (K % 4 == 0) &&
                    ((reinterpret_cast<uintptr_t>(int_weight) & 15) == 0);
   uint32_t* qw = reinterpret_cast<uint32_t*>(qweight);
   const float* sc_in = (scales && scales_out) ? scales : nullptr;
@@ -453,7 +460,21 @@ int inc_woq_pack(const void* int_weight, int in_bytes, const float* scales, cons
   } else {                                                                                              \
     woq_pack_qweight_kernel<B, int8_t, false><<<grid, 256, 0, s>>>((const int8_t*)int_weight, INC_PACK_ARGS);           \
   }
-  if (bits == 4) { INC_PACK_LAUNCH(4) } else if (bits == 8) { INC_PACK_LAUNCH(8) } else { INC_PACK_LAUNCH(2) }
+  // (widths whose n_pack is not a multiple of 4 have no 16-byte path: `vec` is false for them)
+#define INC_PACK_LAUNCH_ODD(B)                                                                          \
+  if (in_bytes == 4) woq_pack_qweight_kernel<B, int32_t, false><<<grid, 256, 0, s>>>((const int32_t*)int_weight, INC_PACK_ARGS); \
+  else woq_pack_qweight_kernel<B, int8_t, false><<<grid, 256, 0, s>>>((const int8_t*)int_weight, INC_PACK_ARGS);
+  switch (bits) {
+    case 4: INC_PACK_LAUNCH(4) break;
+    case 8: INC_PACK_LAUNCH(8) break;
+    case 2: INC_PACK_LAUNCH(2) break;
+    case 1: INC_PACK_LAUNCH(1) break;
+    case 3: INC_PACK_LAUNCH_ODD(3) break;
+    case 5: INC_PACK_LAUNCH_ODD(5) break;
+    case 6: INC_PACK_LAUNCH_ODD(6) break;
+    default: INC_PACK_LAUNCH(7) break;
+  }
+#undef INC_PACK_LAUNCH_ODD
 #undef INC_PACK_LAUNCH
 #undef INC_PACK_ARGS
   INC_LAUNCH_RETURN();
@@ -462,7 +483,7 @@ int inc_woq_pack(const void* int_weight, int in_bytes, const float* scales, cons
 int inc_woq_unpack(const int32_t* qweight, const int32_t* qzeros, int16_t* int_weight, int16_t* zp,
                    int64_t N, int64_t K, int64_t G, int bits, inc_stream_t stream) {
   INC_CHECK_ARG(N > 0 && K > 0 && G > 0);
-  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  if (bits < 1 || bits > 8) return INC_ERR_UNSUPPORTED;
   hipStream_t s = inc_s(stream);
   const int n_pack = 32 / bits;
   const int64_t KW = ceil_div64(K, n_pack), NW = ceil_div64(N, n_pack);
@@ -471,12 +492,19 @@ int inc_woq_unpack(const int32_t* qweight, const int32_t* qzeros, int16_t* int_w
   if (int_weight) {
     INC_CHECK_ARG(qweight);
     dim3 grid((unsigned)ceil_div64(KW, TILE), (unsigned)ceil_div64(N, TILE));
-    const bool vec = (K % n_pack == 0) && (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(int_weight) & 15) == 0);
+    const bool vec = (n_pack % 8 == 0 || n_pack == 4) && (K % n_pack == 0) && (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(int_weight) & 15) == 0);
     const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
 #define INC_UNPACK(B, V) woq_unpack_qweight_kernel<B, V><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW, qzp, zp, G, NW)
-    if (bits == 4) { if (vec) INC_UNPACK(4, true); else INC_UNPACK(4, false); }
-    else if (bits == 8) { if (vec) INC_UNPACK(8, true); else INC_UNPACK(8, false); }
-    else { if (vec) INC_UNPACK(2, true); else INC_UNPACK(2, false); }
+    switch (bits) {
+      case 4: if (vec) INC_UNPACK(4, true); else INC_UNPACK(4, false); break;
+      case 8: if (vec) INC_UNPACK(8, true); else INC_UNPACK(8, false); break;
+      case 2: if (vec) INC_UNPACK(2, true); else INC_UNPACK(2, false); break;
+      case 1: if (vec) INC_UNPACK(1, true); else INC_UNPACK(1, false); break;
+      case 7: if (vec) INC_UNPACK(7, true); else INC_UNPACK(7, false); break;  // (n_pack = 4)
+      case 3: INC_UNPACK(3, false); break;
+      case 5: INC_UNPACK(5, false); break;
+      default: INC_UNPACK(6, false); break;
+    }
 #undef INC_UNPACK
   } else if (zp) {  // zero points alone
     woq_unpack_qzeros_kernel<<<grid_1d(N * G), 256, 0, s>>>(qzp, zp, N, G, NW, bits);
@@ -488,24 +516,31 @@ int inc_woq_dequant(const int32_t* qweight, const uint16_t* scales, const int32_
                     const int32_t* g_idx, void* out, int out_dtype, int64_t N, int64_t K, int64_t G,
                     int group_size, int bits, inc_stream_t stream) {
   INC_CHECK_ARG(qweight && scales && qzeros && out && N > 0 && K > 0 && G > 0 && group_size > 0);
-  if (!(bits == 2 || bits == 4 || bits == 8)) return INC_ERR_UNSUPPORTED;
+  if (bits < 1 || bits > 8) return INC_ERR_UNSUPPORTED;
   hipStream_t s = inc_s(stream);
   const int n_pack = 32 / bits;
   const int64_t KW = ceil_div64(K, n_pack), NW = ceil_div64(N, n_pack);
-  dim3 grid((unsigned)ceil_div64(K, DQ_KT), (unsigned)ceil_div64(N, TILE));
+  dim3 grid((unsigned)ceil_div64(K, (DQ_KT / n_pack) * n_pack), (unsigned)ceil_div64(N, TILE));
   const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
   const uint32_t* qz = reinterpret_cast<const uint32_t*>(qzeros);
 #define INC_DQ_LAUNCH(B, D) \
   woq_dequant_kernel<B, D><<<grid, 256, 0, s>>>(qw, scales, qz, g_idx, (typename out_elem<D>::type*)out, N, K, KW, NW, group_size)
+#define INC_DQ_BITS(D)                                                                                                       \
+  switch (bits) {                                                                                                            \
+    case 4: INC_DQ_LAUNCH(4, D); break; case 8: INC_DQ_LAUNCH(8, D); break; case 2: INC_DQ_LAUNCH(2, D); break;              \
+    case 1: INC_DQ_LAUNCH(1, D); break; case 3: INC_DQ_LAUNCH(3, D); break; case 5: INC_DQ_LAUNCH(5, D); break;              \
+    case 6: INC_DQ_LAUNCH(6, D); break; default: INC_DQ_LAUNCH(7, D); break;                                                 \
+  }
   if (out_dtype == INC_F32) {
-    if (bits == 4) INC_DQ_LAUNCH(4, INC_F32); else if (bits == 8) INC_DQ_LAUNCH(8, INC_F32); else INC_DQ_LAUNCH(2, INC_F32);
+    INC_DQ_BITS(INC_F32)
   } else if (out_dtype == INC_F16) {
-    if (bits == 4) INC_DQ_LAUNCH(4, INC_F16); else if (bits == 8) INC_DQ_LAUNCH(8, INC_F16); else INC_DQ_LAUNCH(2, INC_F16);
+    INC_DQ_BITS(INC_F16)
   } else if (out_dtype == INC_BF16) {
-    if (bits == 4) INC_DQ_LAUNCH(4, INC_BF16); else if (bits == 8) INC_DQ_LAUNCH(8, INC_BF16); else INC_DQ_LAUNCH(2, INC_BF16);
+    INC_DQ_BITS(INC_BF16)
   } else {
     return INC_ERR_UNSUPPORTED;
   }
+#undef INC_DQ_BITS
 #undef INC_DQ_LAUNCH
   INC_LAUNCH_RETURN();
 }

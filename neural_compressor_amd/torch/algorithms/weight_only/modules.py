@@ -102,7 +102,8 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         **kwargs,
     ):
         super().__init__(in_features, out_features, dtype, bits, group_size, device, scale_dtype=scale_dtype, **kwargs)
-        assert bits in (2, 4, 8), f"bits={bits}: the HIP packers implement 2, 4 and 8 bits"
+        if not (isinstance(bits, int) and 1 <= bits <= 8):  # the widths the reference's configs tune (config.py:211)
+            raise ValueError(f"bits={bits}: weight-only widths are 1..8 (n_pack = compress_bits // bits, reference modules.py:231)")
         dev = _hip_device(device)
         self.use_optimum_format = use_optimum_format
         self._lut = None
@@ -308,7 +309,7 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
             y = ops.woq_gemm(x2d, self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features,
                              self.group_size, self.bits, g_idx=self.g_idx)
         else:
-            # 2-bit / odd widths, non-optimum layouts: HIP dequant + dense library GEMM
+            # non-optimum layouts (compression_dim / int8-16-64 containers, NF4 / FP4 code books): HIP dequant + dense library GEMM
             w = self.recover(dtype=x2d.dtype)
             b = None if self.bias is None else self.bias.to(x2d.dtype)
             y = torch.nn.functional.linear(x2d, w, b)
@@ -327,7 +328,9 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         if getattr(self, "_plan_key", None) == key:
             return self._plan
         plan = "dense"
-        fusable = self.use_optimum_format and self.bits in (4, 8) and self.group_size % self.n_pack == 0
+        # 4 / 8 bits: whole words per group (the fast kernels); every other width 1..7 runs inc_woq_gemm's per-element tile form,
+        # which takes any group size (n_pack = 10 / 6 / 5 for 3 / 5 / 6 bits never divides one)
+        fusable = self.use_optimum_format and (self.group_size % self.n_pack == 0 if self.bits in (4, 8) else True)
         self._k_order = self._qweight_sorted = None
         if fusable:
             K, gs = self.in_features, self.group_size

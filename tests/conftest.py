@@ -30,6 +30,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_bits():
+    """INCWeightOnlyLinear at the widths other than 2 / 4 / 8, from the unmodified reference (tests/golden/make_golden_bits.py)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "woq_bits_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def rtn_model_golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "rtn_opt125m_like.npz"))
 

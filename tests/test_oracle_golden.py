@@ -46,6 +46,38 @@ def test_pack_rows_all_containers(golden, bits, cbits):
     assert np.array_equal(O.unpack_rows(packed, bits, cbits, mask_sign=False), golden[f"rows_b{bits}_c{cbits}_unpack_signed"])
 
 
+BITS_CASES = [(b, sch) for b in (1, 2, 3, 5, 6, 7) for sch in ("sym", "asym") if not (b == 1 and sch == "sym")]
+
+
+@pytest.mark.parametrize("bits,scheme", BITS_CASES)
+def test_module_pack_unpack_recover_every_width(golden_bits, bits, scheme):
+    """Widths other than 2 / 4 / 8 (reference modules.py:231 n_pack = 32 // bits: 3 / 5 / 6 / 7 bits leave high bits unused)."""
+    g, tag, N, K, gs = golden_bits, f"b{bits}{scheme}", 21, 150, 32
+    zp = g[f"{tag}_zp"] if f"{tag}_zp" in g.files else None
+    qw, qz, sc = O.woq_pack_optimum(g[f"{tag}_int"], g[f"{tag}_scale"], zp, bits)
+    assert np.array_equal(qw, g[f"{tag}_qweight"])
+    assert np.array_equal(qz, g[f"{tag}_qzeros"])
+    assert np.array_equal(sc.view(np.uint16), g[f"{tag}_scales16"].view(np.uint16))
+    iw, z = O.woq_unpack_optimum(qw, qz, N, K, sc.shape[0], bits)
+    assert np.array_equal(iw, g[f"{tag}_unpack_int"])
+    assert np.array_equal(z, g[f"{tag}_unpack_zp"])
+    assert np.array_equal(O.woq_recover(qw, sc, qz, N, K, bits, gs), g[f"{tag}_recover"])
+    # the reference's CPU forward: fp32 F.linear on the fp16 recovered weight (modules.py:594-610)
+    y = O.woq_linear(torch.from_numpy(g[f"{tag}_x"]), qw, sc, qz, None, N, K, bits, gs, compute_dtype=torch.float32,
+                     dense=torch.from_numpy(g[f"{tag}_recover"]).float())
+    assert float((y - torch.from_numpy(g[f"{tag}_y"])).norm() / torch.from_numpy(g[f"{tag}_y"]).norm()) <= 1e-6
+
+
+@pytest.mark.parametrize("bits", [1, 3, 5, 6, 7])
+@pytest.mark.parametrize("cbits", [8, 16, 32, 64])
+def test_pack_rows_odd_widths_all_containers(golden_bits, bits, cbits):
+    g = golden_bits
+    packed = O.pack_rows(g["rows_raw"], bits, cbits)
+    assert np.array_equal(packed, g[f"rows_b{bits}_c{cbits}"])
+    assert np.array_equal(O.unpack_rows(packed, bits, cbits, mask_sign=False), g[f"rows_b{bits}_c{cbits}_unpack_signed"])
+    assert np.array_equal(O.unpack_rows(packed, bits, cbits, mask_sign=True), g[f"rows_b{bits}_c{cbits}_unpack_masked"])
+
+
 QT_CASES = {
     "qt_sym4_g32": dict(bits=4, group_size=32, scheme="sym"),
     "qt_asym4_g32": dict(bits=4, group_size=32, scheme="asym"),

@@ -718,7 +718,7 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
   // flags 50 / 52: the same tile with its LDS-DMA requests spread over the step's MFMA rows (and its row fragments requested two rows
   // ahead) -- same arithmetic, same bits
   int64_t spread_differ = 0;
-  for (int flag : {50, 52, 55}) {
+  for (int flag : {50, 52, 55, 56, 59}) {
     if (K % 8 != 0) break;
     Hold.zero();
     inc_debug_set_small_tiles(flag);
@@ -736,10 +736,10 @@ static int run_hessian_case(int64_t T, int64_t K, bool time_it) {
          (long)K, rel, (long)differ, ns, maxrel, (long)spread_differ, ok ? "OK" : "FAIL");
   if (time_it) {
     Timer t;
-    const int modes[14] = {0, 50, 52, 53, 54, 55, 51, 46, 45, 1, 47, 48, 49, 0};
-    const char* labels[14] = {"256x256 transpose-read 2x64", "256x256 TR 2x64, DMA spread", "256x256 TR 2x64, spread + rolling frags", "256x256 TR 2x64, rolling frags",
-                              "256x256 TR 2x64, prio 1 for waves 4-7", "256x256 TR 2x64, spread + rolling + prio",
-                              "256x256 TR 4x32, DMA spread", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles",
+    const int modes[14] = {0, 59, 53, 54, 56, 57, 50, 46, 45, 1, 47, 48, 49, 0};
+    const char* labels[14] = {"256x256 TR 2x64 (pipeline + prio)", "256x256 TR 2x64, round-4 form", "256x256 TR 2x64, rolling frags", "256x256 TR 2x64, prio 1 for waves 4-7", "256x256 TR 2x64, rolling + prio",
+                              "256x256 TR 2x64, one pipeline per step",
+                              "256x256 TR 2x64, DMA spread", "256x256 transpose-read 4x32", "256x256 register transpose", "128x128 tiles",
                              "  TR timing-only: no LDS-DMA", "  TR timing-only: no MFMA / frag reads", "  TR timing-only: barriers + epilogue",
                              "256x256 transpose-read 2x64 (again)"};
     for (int mi = 0; mi < 14; ++mi) {
@@ -808,9 +808,10 @@ static int run_hessian_multi_case(int64_t T) {
     inc_debug_set_small_tiles(0);
   }
   Timer t;
-  const int nm = 4;
-  const int modes[nm] = {0, 44, 46, 45};
-  const char* labels[nm] = {"transpose-read 2x64", "  - tail split", "transpose-read 4x32", "register transpose"};
+  const int nm = 10;
+  const int modes[nm] = {0, 59, 53, 54, 56, 57, 44, 46, 45, 0};
+  const char* labels[nm] = {"transpose-read 2x64", "  round-4 form", "  rolling frags", "  prio 1 for waves 4-7", "  rolling + prio", "  one pipeline per step",
+                            "  - tail split", "transpose-read 4x32", "register transpose", "transpose-read 2x64 (again)"};
   for (int mi = 0; mi < nm; ++mi) {
     inc_debug_set_small_tiles(modes[mi]);
     for (int i = 0; i < 2; ++i) INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, hws.p, (int64_t)hws.n, nullptr));
