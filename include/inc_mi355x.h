@@ -298,15 +298,18 @@ int inc_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, 
  *   lower tiles only), the diagonal blocks by the inc_chol_diag_block kernel.  The chain (diagonal blocks, block
  *   inverses, panel solves, the update of the next block's columns) is issued on `stream`; with `aux_stream` (may be
  *   NULL) the rest of every trailing update and the top-level doubling products run there underneath the chain (two
- *   transient HIP events; the call returns with `stream` ordered behind everything).  Same results either way;
- *   deterministic.
+ *   transient HIP events; the call returns with `stream` ordered behind everything).  Deterministic.  With flags = 0 the
+ *   two-stream form is bit-identical to the one-stream form; with flags bit 1 it is NOT: the side stream's products stay exact
+ *   fp32 (one plane buffer, owned by the main stream), so the factor differs from the one-stream form within the distance
+ *   bit 1 is gated by (both <= 1e-6 relative from an fp64 factor).
  *   workspace: >= inc_gptq_inverse_factor_workspace_bytes(K, flags) bytes, 16-byte aligned, contents undefined on return
- *   (3 Kp^2 + 2048 Kp floats, Kp = K rounded up to 128).
+ *   (3 Kp^2 + 2048 Kp floats, Kp = K rounded up to 128; + 6 (Kp + 256)(Kp + 128) bytes of bf16 planes with flags bit 1:
+ *   2.2 GB at K = 11008, 14.8 GB at K = 28672).
  *   info: device int32, written by the call: 0, or the (1-based) index of the last 128-column diagonal block with a
  *   non-positive pivot (H not positive definite -- the reference's torch.linalg.cholesky raises there); U is
  *   undefined in that case.  flags: bit 0 = ignore aux_stream (one stream); bit 1 = the large products with
  *   their fp32 operands split into three bf16 pieces (six bf16 MFMAs per fp32 product: dropped terms <= 2^-24 |a b|, same distance to an
- *   fp64 factor as the exact-fp32 products of flags = 0, 1.3 - 2 x faster; the Python driver sets it unless INC_MI355X_CHOL_BF16X3=0).                                                                             */
+ *   fp64 factor as the exact-fp32 products of flags = 0, 1.3 - 2 x faster; the Python driver's default).                */
 int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K, int flags);
 int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace, int64_t workspace_bytes, int32_t* info,
                             int flags, inc_stream_t stream, inc_stream_t aux_stream);

@@ -460,21 +460,12 @@ __global__ __launch_bounds__(256) void chol_diag_block_v2_kernel(float* __restri
 
 }  // namespace
 
-// A/B switch read once from the environment (INC_MI355X_CHOL_LEAF_V1=1: the first-generation diagonal-block kernel everywhere)
-static bool leaf_v1_forced() {
-  static const bool forced = [] {
-    const char* e = getenv("INC_MI355X_CHOL_LEAF_V1");
-    return e && e[0] == '1';
-  }();
-  return forced;
-}
-
 // launcher shared with ifac.hip (inc_gptq_inverse_factor issues one of these per 128 columns)
 int inc_launch_chol_diag_block(float* A, int64_t lda, int n, float* Linv, int64_t ldi, int32_t* info, int tag, hipStream_t s) {
   // full, 16-byte-aligned blocks (every block of inc_gptq_inverse_factor): the second-generation kernel; ragged / unaligned ones
   // (the stand-alone entry point on a small matrix): the first generation.  Harness flag 201 forces the first generation (A/B).
   if (n == CB && (lda % 4) == 0 && (ldi % 4) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Linv)) & 15) == 0 &&
-      inc_small_tiles_flag(-1) != 201 && !leaf_v1_forced()) {
+      inc_small_tiles_flag(-1) != 201) {
     const size_t smem2 = (size_t)(2 * CB * LP + 64 * 68 + CB) * sizeof(float);
     static std::atomic<uint64_t> attr2_set{0};
     if (inc_attr_needed(attr2_set)) {

@@ -1461,19 +1461,8 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
       INC_LAUNCH_RETURN();
     }
 #endif
-    // INC_MI355X_HESSIAN_ROUND_LAUNCHES=1 (A/B switch, read once): one launch per round of one-tile-per-CU instead of one launch
-    // for the whole grid -- the tiles of a round then START together, which bounds how far the tiles sharing X panels in an XCD's L2
-    // drift apart (every tile is computed exactly as before)
-    static const bool per_round = [] { const char* e = getenv("INC_MI355X_HESSIAN_ROUND_LAUNCHES"); return e && e[0] == '1'; }();
-    int cus = 256;
-    {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (cus <= 0 || (cus % 8) != 0) cus = 256;
-    }
 #ifdef INC_KBENCH
-    {  // harness flags 53 / 54 / 56 / 57 / 58: the tile variants of the single-problem launch, in the batched launch
+    {  // harness flags 53 / 54 / 56 / 57 / 58 / 59: the tile variants of the single-problem launch, in the batched launch
       const int f = inc_small_tiles_flag(-1);
       const int mabl = f == 53 ? 8 : f == 54 ? 16 : f == 56 ? 24 : f == 57 ? 32 : f == 58 ? 48 : f == 59 ? 64 : 0;  // (64 = ABL 0)
       if (mabl && xdtype == INC_BF16) {
@@ -1486,7 +1475,17 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
       }
     }
 #endif
-    const int chunk = per_round ? cus : grid;
+    // (one launch per round of one-tile-per-CU, so that the tiles sharing X panels in an XCD's L2 restart together, measured 1 %
+    // slower than this single launch: profiles/NOTES.md round 4; harness flag 43 keeps it as an A/B partner)
+    int chunk = grid;
+#ifdef INC_KBENCH
+    if (inc_small_tiles_flag(-1) == 43) {
+      int dev = 0, cus = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      chunk = (cus <= 0 || (cus % 8) != 0) ? 256 : cus;
+    }
+#endif
     for (int b0 = 0; b0 < grid; b0 += chunk) {
       a.block0 = b0;
       const int g = grid - b0 < chunk ? grid - b0 : chunk;

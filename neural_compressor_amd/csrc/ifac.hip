@@ -9,8 +9,10 @@
 // algorithm from Python with torch.mm for every product; this file owns all of it:
 //   * f32gemm_kernel        exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: fmaf-chain semantics), NT and NN forms,
 //                           triangular operands skipped by K-range per tile, lower-triangle-only outputs (syrk), batched pairs
-//   * ifac_split3_kernel + bf16x3_gemm_kernel (flags bit 1)  the large products with their operands pre-split into three bf16 planes:
-//                           six bf16 MFMAs per fp32 product, LDS-DMA ring (see the comment in front of them)
+//   * ifac_split3_kernel + bf16x3_gemm_kernel (flags bit 1: the Python driver's DEFAULT)  the large products of the MAIN stream with
+//                           their operands pre-split into three bf16 planes: six bf16 MFMAs per fp32 product, LDS-DMA ring (see the
+//                           comment in front of them); products issued on the optional second stream stay exact fp32 (one plane
+//                           buffer), so one- and two-stream forms are bit-identical for flags = 0 only
 //   * chol_diag_block_kernel (chol.hip) the 128 x 128 diagonal block: factor + inverse of the factor in one workgroup
 //   * ifac_flip_* / ifac_copy_panel: index reversal in / out, panel write-back
 //   * the host side below issues them on the caller's stream (+ an optional second stream for the look-ahead over outer blocks)
@@ -454,8 +456,8 @@ int64_t launch_split3(const float* src, int64_t ld, int rows, int cols, bool tr,
   return 3 * plane * (int64_t)sizeof(uint16_t);
 }
 
-// `planes` (flags bit 1, >= 12 * Kp^2 bytes): the large un-batched products run as bf16 x 3 splits of their operands
-int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s, void* planes = nullptr) {
+// `planes` (flags bit 1, `planes_bytes` of them): the large un-batched products whose split operands fit run as bf16 x 3 splits
+int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s, void* planes = nullptr, int64_t planes_bytes = 0) {
   if (g.M <= 0 || g.N <= 0 || batch <= 0) return INC_OK;
   // tile choice: 128 x 128 when that still gives the chip enough workgroups, else 64 x 64 (the chain's small products)
   auto ntiles = [&](int t) {
@@ -473,13 +475,17 @@ int launch_f32gemm(const GemmArgs& g, bool b_nt, int batch, hipStream_t s, void*
   const bool big = ntiles(128) * batch >= 192;
   const int t = big ? 128 : 64;
   dim3 grid((unsigned)ntiles(t), (unsigned)batch);
-  if (big && planes && batch == 1 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && (g.K & 3) == 0 && (g.N & 3) == 0 &&
+  const bool syrk_form = b_nt && g.B == g.A && g.ldb == g.lda && g.N == g.M;
+  // bytes of the split operands: 3 planes x rows (padded to 128) x k (padded to 16) x 2 bytes each
+  const int64_t kpad = ceil_div64(g.K, X3_KB) * X3_KB;
+  const int64_t need = 6 * kpad * (ceil_div64(g.M, 128) * 128 + (syrk_form ? 0 : ceil_div64(g.N, 128) * 128));
+  if (big && planes && need <= planes_bytes && batch == 1 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && (g.K & 3) == 0 && (g.N & 3) == 0 &&
       ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) == 0) {
     X3Planes p;
     uint16_t* pa = static_cast<uint16_t*>(planes);
     const int64_t abytes = launch_split3(g.A, g.lda, g.M, g.K, false, 128, pa, &p.a_plane, &p.RpA, s);
     p.Ap = pa;
-    if (b_nt && g.B == g.A && g.ldb == g.lda && g.N == g.M) {  // syrk form: one operand
+    if (syrk_form) {  // one operand
       p.Bp = pa; p.b_plane = p.a_plane; p.RpB = p.RpA;
     } else {
       uint16_t* pb = reinterpret_cast<uint16_t*>(static_cast<char*>(planes) + abytes);
@@ -530,12 +536,17 @@ struct Seg {
 
 extern "C" {
 
-// A [Kp, Kp] + X [Kp, Kp] + T [Kp, Kp] + 2 x P [Kp, IFAC_OUTER] fp32, Kp = K rounded up to 128; with flags bit 1 two operands of
-// three bf16 planes each behind them (12 (Kp + 128) Kp bytes: rows padded to the GEMM's 256-row tile)
+// the split operands of the largest product: every product of the factorisation has k (rows_A + rows_B) <= Kp^2 elements (a merge of
+// spans n1 + n2 <= Kp multiplies [n2, n1] by [n1, n1]; the trailing syrk is one operand [<= Kp, 1024]) -> 6 bytes per element, rows
+// padded to 128 and k to 16
+static int64_t ifac_plane_bytes(int64_t Kp) { return 6 * (Kp + 256) * (Kp + 128); }
+
+// A [Kp, Kp] + X [Kp, Kp] + T [Kp, Kp] + 2 x P [Kp, IFAC_OUTER] fp32, Kp = K rounded up to 128; with flags bit 1 the three bf16 planes of
+// the largest product's operands behind them (ifac_plane_bytes: 6 Kp^2; 12 Kp^2 until round 5)
 int64_t inc_gptq_inverse_factor_workspace_bytes(int64_t K, int flags) {
   if (K <= 0) return 0;
   const int64_t Kp = ceil_div64(K, IFAC_NB) * IFAC_NB;
-  return (3 * Kp * Kp + 2 * Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float) + ((flags & 2) ? 12 * (Kp + 128) * Kp : 0);
+  return (3 * Kp * Kp + 2 * Kp * (int64_t)IFAC_OUTER) * (int64_t)sizeof(float) + ((flags & 2) ? ifac_plane_bytes(Kp) : 0);
 }
 
 int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace, int64_t workspace_bytes, int32_t* info, int flags,
@@ -576,7 +587,7 @@ int inc_gptq_inverse_factor(const float* H, int64_t K, float* U, void* workspace
   auto gemm = [&](hipStream_t st, const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t M, int64_t N, int64_t Kd,
                   float alpha, float beta, int krange, bool lower_only, bool b_nt, int batch = 1, int64_t sa = 0, int64_t sb = 0, int64_t sc = 0) {
     GemmArgs g{a, b, c, lda, ldb, ldc, sa, sb, sc, (int)M, (int)N, (int)Kd, alpha, beta, krange, lower_only ? 1 : 0};
-    const int r = launch_f32gemm(g, b_nt, batch, st, st == s ? planes : nullptr);  // one plane buffer: the main stream's products only
+    const int r = launch_f32gemm(g, b_nt, batch, st, st == s ? planes : nullptr, planes ? ifac_plane_bytes(Kp) : 0);  // one plane buffer: the main stream's products only
     if (r != INC_OK) rc = r;
   };
   auto copy_panel = [&](hipStream_t st, const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int cols) {

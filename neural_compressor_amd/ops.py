@@ -425,9 +425,9 @@ def gptq_hessian_accum(H, x2d, beta, alpha):
     return H
 
 
-# INC_MI355X_HESSIAN_TAIL_SPLIT=0: every tile of the batched Hessian launch is one workgroup (the last round of a launch then runs on a
-# fraction of the CUs)
-HESSIAN_TAIL_SPLIT = __import__("os").environ.get("INC_MI355X_HESSIAN_TAIL_SPLIT", "1") == "1"
+# False: every tile of the batched Hessian launch is one workgroup (the last round of a launch then runs on a fraction of the CUs);
+# a module attribute for A/B runs, not an environment switch
+HESSIAN_TAIL_SPLIT = True
 _hessian_ws_cache = {}
 
 
@@ -668,7 +668,8 @@ def gptq_inverse_factor(H, aux_stream=None, flags=0):
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     # (no record_stream for `aux_stream`: the call returns with the current stream ordered behind everything it issued on the second
     # one, so the caching allocator's stream-ordered reuse of H / U / the workspace is already safe -- and record_stream would make
-    # every call hipMalloc a fresh 1.5 GB workspace at K = 11008)
+    # every call hipMalloc a fresh workspace: 2.2 GB at K = 11008, 14.8 GB at K = 28672 with the split products' planes; the
+    # caching allocator keeps one per stream that factorises, so the driver's concurrent factor streams each hold theirs)
     aux = aux_stream.cuda_stream if aux_stream is not None else None
     with torch.cuda.device(dev):
         check(lib.inc_gptq_inverse_factor(_ptr(H), K, _ptr(U), _ptr(ws), wsb, _ptr(info), int(flags), _stream(), aux), "inc_gptq_inverse_factor")

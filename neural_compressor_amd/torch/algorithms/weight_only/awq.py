@@ -46,6 +46,7 @@ import time
 
 # INC_MI355X_AWQ_TIMING=1: wall-clock per phase (device-synchronised) on the converted model as `awq_phase_s` -- diagnostics only
 PHASE_TIMING = os.environ.get("INC_MI355X_AWQ_TIMING", "0") == "1"
+PREFIX_REPLAY = True  # replay the recorded float outputs of unchanged prefix modules in the search forwards (tests compare with False)
 
 
 @contextlib.contextmanager
@@ -676,7 +677,7 @@ class ActAwareWeightQuant:
     # Linear starts (for gate/up: input_layernorm, self_attn, post_attention_layernorm) see the same inputs and weights at
     # every grid point, so their recorded float outputs are replayed instead of being recomputed -- the same kernels on the
     # same data would reproduce them bit for bit (checked once per set of replayed children against a full forward).
-    # INC_MI355X_AWQ_PREFIX_REPLAY=0 runs every forward in full.
+    # (PREFIX_REPLAY = False runs every forward in full: the tests' A/B partner.)
     def _float_block_outputs(self, block):
         fb = getattr(self, "_float_block", None)
         if fb is not None and fb["block"] is block:
@@ -728,7 +729,7 @@ class ActAwareWeightQuant:
 
     def _prefix_replay(self, block, changed):
         fb = getattr(self, "_float_block", None)
-        if os.environ.get("INC_MI355X_AWQ_PREFIX_REPLAY", "1") != "1" or fb is None or fb["block"] is not block:
+        if not PREFIX_REPLAY or fb is None or fb["block"] is not block:
             return None
         changed_names = {fb["leaves"].get(id(m)) for m in changed}
         if None in changed_names:

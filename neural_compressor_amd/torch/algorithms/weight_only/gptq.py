@@ -86,11 +86,9 @@ def find_layers(module, layers=SUPPORTED_LAYERS, name=""):
 # Hinv = cholesky(cholesky_inverse(cholesky(H)), upper=True)  (reference gptq.py:1228-1230), restructured
 # ---------------------------------------------------------------------------------------------------
 CHOL_NB = 128
-LOOKAHEAD = os.environ.get("INC_MI355X_GPTQ_LOOKAHEAD", "1") == "1"
 # the capture pass of a block (forward with the Hessian hooks; its OUTPUT is discarded, reference gptq.py:690-702) stops at the
 # last hooked Linear instead of also running that Linear and whatever follows it
-CAPTURE_EARLY_STOP = os.environ.get("INC_MI355X_GPTQ_CAPTURE_EARLY_STOP", "1") == "1"
-FUSE_FIND_PARAMS = os.environ.get("INC_MI355X_GPTQ_FUSE_FIND_PARAMS", "1") == "1"
+CAPTURE_EARLY_STOP = True
 
 
 class _CaptureDone(Exception):
@@ -100,13 +98,12 @@ class _CaptureDone(Exception):
 _LOOKAHEAD_STREAMS = {}
 
 
-ONE_CALL = os.environ.get("INC_MI355X_GPTQ_ONE_CALL", "1") != "0"  # the column loop through inc_gptq_quantize_layer
 # The solve of the block's LAST Linear(s) in forward order (Llama: down_proj, whose K = 11008 factorisation is the critical path of
 # the solve phase) runs on a stream of its own and the second forward starts without it: a pre-hook on those modules makes the
 # forward's stream wait for the solve when it gets there (attention + gate / up run underneath the factorisation).  Same launches,
-# same operands: bit-identical results.  INC_MI355X_GPTQ_LATE_SOLVE=0 keeps every solve in front of the second forward.
-LATE_SOLVE = os.environ.get("INC_MI355X_GPTQ_LATE_SOLVE", "1") == "1"
-LAYER_LOOKAHEAD = os.environ.get("INC_MI355X_GPTQ_LAYER_LOOKAHEAD", "1") == "1"  # mode "layer": next round's exchange under this round's solve
+# same operands: bit-identical results (a module attribute: tests compare it with every solve in front of the second forward).
+LATE_SOLVE = True
+LAYER_LOOKAHEAD = True  # mode "layer": next round's exchange under this round's solve (tests set it to compare)
 _TRACE_RANGES = os.environ.get("INC_MI355X_TRACE_RANGES", "0") == "1"  # roctx ranges around the phases of a block (scripts/step_timeline.py)
 
 
@@ -150,7 +147,7 @@ def _lookahead_stream(device):
 # and 25-33 ms in others against a steady 17.0 ms on one stream (scripts/chol_time.py; a second stream masked to 224 CUs with
 # hipExtStreamCreateWithCUMask, ops.cu_masked_stream, was slower still: 30 ms), and inside a GPTQ step four factorisations and the
 # column loops already share the chip.
-CHOL_LOOKAHEAD = os.environ.get("INC_MI355X_CHOL_LOOKAHEAD", "0") == "1"
+CHOL_LOOKAHEAD = False
 _CHOL_SIDE_STREAMS = {}
 
 
@@ -163,12 +160,9 @@ def _chol_side_stream(device):
     return st
 
 
-CHOL_PYTHON = os.environ.get("INC_MI355X_CHOL_PYTHON", "0") == "1"
-CHOL_BF16X3 = os.environ.get("INC_MI355X_CHOL_BF16X3", "1") == "1"  # large products of the factorisation as 3-way bf16 splits (0: exact fp32 MFMA)
-CHOL_OUTER = int(os.environ.get("INC_MI355X_CHOL_OUTER", "1024"))  # outer block of the two-level factorisation (columns)
-TRI_DEPTH = int(os.environ.get("INC_MI355X_CHOL_TRI_DEPTH", "2"))    # levels of 2 x 2 splitting in the triangular products
-TRI_MIN = 512                                                        # do not split below this half size
-_EXACT_TRIO = os.environ.get("INC_MI355X_CHOLESKY_TRIO", "0") == "1"
+# large products of the factorisation as three-way bf16 splits (inc_gptq_inverse_factor flags bit 1); False: exact-fp32 MFMA products.
+# A module attribute, not an environment switch: tests / scripts that compare the two forms set it.
+CHOL_BF16X3 = True
 
 
 @torch.no_grad()
@@ -185,143 +179,22 @@ def inverse_cholesky_upper(H, check=True):
       * panel solve  L[i>j, j] = A[i>j, j] @ inv(L_jj)^T  and trailing update  A[i>j, i>j] -= L_panel L_panel^T: fp32 GEMMs,
         two-level (128 inside an outer block of CHOL_OUTER columns, one deep update per outer block, lower triangle only);
       * Lr^-1 by recursive doubling: inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]], all pairs of a level independent.
-    The GEMMs are the fp32 library GEMMs torch dispatches to (plumbing, like torch.linalg was before); a non-positive
-    pivot raises like torch.linalg.cholesky does.  `check=False` returns (U, info) without reading `info` back (no
-    host synchronisation): the caller checks it later with `raise_if_not_spd`.
+    All of it is ONE C-ABI call (inc_gptq_inverse_factor, csrc/ifac.hip + chol.hip: this library's own MFMA GEMMs); the Python +
+    torch.mm form of rounds 1-3 and the rocSOLVER trio live in tests/ab_partners.py as its A/B partners.  A non-positive pivot
+    raises like torch.linalg.cholesky does.  `check=False` returns (U, info) without reading `info` back (no host
+    synchronisation): the caller checks it later with `raise_if_not_spd`.
     """
     assert H.dim() == 2 and H.shape[0] == H.shape[1] and H.dtype == torch.float32
-    if H.is_cuda and not CHOL_PYTHON:
-        # the whole factorisation behind the C-ABI (csrc/ifac.hip): the same blocked algorithm with this library's own fp32 MFMA
-        # GEMMs instead of torch.mm.  INC_MI355X_CHOL_PYTHON=1 keeps the Python + torch.mm form below (its A/B partner in the tests).
-        # (second stream: the rest of the trailing updates and the top-level doubling products run underneath the chain of diagonal
-        # blocks -- same results as one stream, INC_MI355X_CHOL_LOOKAHEAD=0 keeps everything on the calling stream)
+    if H.is_cuda:
+        # (second stream, CHOL_LOOKAHEAD: the rest of the trailing updates and the top-level doubling products run underneath the
+        # chain of diagonal blocks -- same results as one stream, unstable in time: off)
         U, info = ops.gptq_inverse_factor(H.contiguous(), aux_stream=_chol_side_stream(H.device) if CHOL_LOOKAHEAD else None,
                                           flags=2 if CHOL_BF16X3 else 0)
         if not check:
             return U, info
         raise_if_not_spd(info)
         return U
-    K = H.shape[0]
-    nb = CHOL_NB
-    Kp = -(-K // nb) * nb
-    dev = H.device
-    if Kp == K:
-        A = torch.flip(H, (0, 1)).contiguous()
-    else:  # pad with an identity block: chol(blockdiag(Hr, I)) = blockdiag(Lr, I)
-        A = torch.zeros((Kp, Kp), dtype=torch.float32, device=dev)
-        A[:K, :K] = torch.flip(H, (0, 1))
-        A.diagonal()[K:] = 1.0
-    X = torch.zeros((Kp, Kp), dtype=torch.float32, device=dev)
-    info = torch.zeros(1, dtype=torch.int32, device=dev)
-
-    def mm_tri_right(C, T, out, depth):
-        # out = C @ T for a LOWER-triangular T without multiplying its zero half: T = [[a, 0], [b, c]] ->
-        # [C1 a + C2 b, C2 c], a and c recursively (each level drops a quarter of the remaining flops)
-        n = T.shape[0]
-        h = (n // 2 // nb) * nb
-        if depth == 0 or h < TRI_MIN or h == 0:
-            torch.mm(C, T, out=out)
-            return
-        mm_tri_right(C[:, :h], T[:h, :h], out[:, :h], depth - 1)
-        out[:, :h].addmm_(C[:, h:], T[h:, :h])
-        mm_tri_right(C[:, h:], T[h:, h:], out[:, h:], depth - 1)
-
-    def mm_tri_left(T, B, out, depth, alpha=1.0):
-        # out = alpha * T @ B for a LOWER-triangular T: [[a, 0], [b, c]] @ [B1; B2] = [a B1; b B1 + c B2]
-        n = T.shape[0]
-        h = (n // 2 // nb) * nb
-        if depth == 0 or h < TRI_MIN or h == 0:
-            torch.mm(T, B, out=out)
-            if alpha != 1.0:
-                out.mul_(alpha)
-            return
-        mm_tri_left(T[:h, :h], B[:h], out[:h], depth - 1, alpha)
-        mm_tri_left(T[h:, h:], B[h:], out[h:], depth - 1, alpha)
-        out[h:].addmm_(T[h:, :h], B[:h], alpha=alpha)
-
-    def invert_by_doubling(segs):
-        # Lr^-1 of the span covered by `segs` = [(start, size), ...], whose diagonal blocks of X already hold the inverses.
-        # Both factors of  X21 = -X22 (C X11)  are lower-triangular inverses: the products skip their zero halves (two levels
-        # of 2 x 2 splitting: 62 % of the flops of a full GEMM; more than half of the factorisation's flops are in here).
-        while len(segs) > 1:
-            nxt = []
-            for p in range(0, len(segs) - 1, 2):
-                (s1, n1), (s2, n2) = segs[p], segs[p + 1]
-                C = A[s2:s2 + n2, s1:s1 + n1]
-                T = torch.empty((n2, n1), dtype=torch.float32, device=dev)
-                mm_tri_right(C, X[s1:s1 + n1, s1:s1 + n1], T, TRI_DEPTH)
-                mm_tri_left(X[s2:s2 + n2, s2:s2 + n2], T, X[s2:s2 + n2, s1:s1 + n1], TRI_DEPTH, alpha=-1.0)
-                nxt.append((s1, n1 + n2))
-            if len(segs) % 2:
-                nxt.append(segs[-1])
-            segs = nxt
-        return segs[0]
-
-    # Two-level blocking (only the LOWER triangle of A is read or kept up to date): an outer block of CHOL_OUTER columns is
-    # factored with 128-wide steps confined to its own diagonal block, its factor is inverted by doubling, and then ONE panel
-    # solve and ONE trailing update of depth CHOL_OUTER serve the rest of the matrix -- 11 deep GEMMs at K = 11008 instead of 86
-    # rank-128 updates of the whole trailing matrix (which ran at a third of the library's fp32 GEMM rate and made the K = 11008
-    # factorisation the critical path of a block: 46 ms, profiles/r2d).
-    outer = max(nb, (CHOL_OUTER // nb) * nb)
-    tag = 0
-    top = []
-    # Look-ahead over the outer blocks (INC_MI355X_CHOL_LOOKAHEAD=1): the next outer block needs only the FIRST column
-    # chunk of this block's trailing update (it holds that block's diagonal block and its whole panel).  The other chunks run on
-    # a second stream underneath the next block's factorisation -- a chain of one-workgroup diagonal kernels and small GEMMs that
-    # leaves the chip idle (kernel trace at K = 11008: 9.9 ms of chol_diag_block + 13.7 ms of GEMMs back to back) -- and are
-    # awaited before the next trailing update, which accumulates into the same columns.  Same GEMMs, same operands: same bits.
-    main = torch.cuda.current_stream(dev) if H.is_cuda else None
-    side = _chol_side_stream(dev) if (CHOL_LOOKAHEAD and H.is_cuda and Kp > 2 * outer) else None
-    pending = None  # event: the remaining chunks of the previous trailing update are done
-    keep = []       # operands still read by the side stream
-    for B in range(0, Kp, outer):
-        n2 = min(outer, Kp - B)
-        D = A[B:B + n2, B:B + n2]
-        XD = X[B:B + n2, B:B + n2]
-        for j in range(0, n2, nb):
-            tag += 1
-            ops.chol_diag_block(D[j:j + nb, j:j + nb], XD[j:j + nb, j:j + nb], info, tag)
-            if j + nb < n2:
-                panel = D[j + nb:, j:j + nb]                       # [m, nb] strided view
-                lp = torch.mm(panel, XD[j:j + nb, j:j + nb].t())   # L_panel = A_panel @ inv(L_jj)^T
-                panel.copy_(lp)
-                D[j + nb:, j + nb:].addmm_(lp, lp.t(), alpha=-1.0)
-        top.append(invert_by_doubling([(B + j, nb) for j in range(0, n2, nb)]))
-        if B + n2 < Kp:
-            panel = A[B + n2:, B:B + n2]                            # [M, n2]
-            lp = torch.mm(panel, XD.t())                            # L_panel = A_panel @ inv(L_DD)^T  (XD^T upper-triangular)
-            panel.copy_(lp)
-            M = Kp - (B + n2)
-            chunk = max(outer, -(-M // 6 // nb) * nb)                # lower triangle only: <= 6 column chunks, each from its diagonal down
-            if pending is not None:
-                main.wait_event(pending)                            # the previous update's remaining chunks wrote these columns
-                pending = None
-            first = True
-            for c0 in range(0, M, chunk):
-                c1 = min(c0 + chunk, M)
-                if side is not None and not first:
-                    if c0 == chunk:
-                        ready = torch.cuda.Event()
-                        ready.record(main)                          # lp and the first chunk are complete
-                        side.wait_event(ready)
-                    with torch.cuda.stream(side):
-                        A[B + n2 + c0:, B + n2 + c0:B + n2 + c1].addmm_(lp[c0:], lp[c0:c1].t(), alpha=-1.0)
-                else:
-                    A[B + n2 + c0:, B + n2 + c0:B + n2 + c1].addmm_(lp[c0:], lp[c0:c1].t(), alpha=-1.0)
-                first = False
-            if side is not None and M > chunk:
-                pending = torch.cuda.Event()
-                pending.record(side)
-                keep.append(lp)
-    if pending is not None:
-        main.wait_event(pending)
-    invert_by_doubling(top)
-    del keep
-    U = torch.flip(X[:K, :K], (0, 1)).contiguous()
-    if not check:
-        return U, info
-    raise_if_not_spd(info)
-    return U
+    raise RuntimeError("inverse_cholesky_upper needs a HIP tensor: the factorisation is inc_gptq_inverse_factor (there is no CPU path)")
 
 
 def raise_if_not_spd(info):
@@ -354,8 +227,8 @@ class HessianAccumulator:
     # copied into the staging buffer -- once the accumulator has SEEN that the model leaves such an input alone: the first
     # eligible batch is still copied, and its version counter is compared when the update is launched (after the forward);
     # only if it is unchanged do the later forwards skip the copy.  A model that edits a Linear's input in place later in
-    # the same forward therefore simply keeps the copying path.  INC_MI355X_HESSIAN_ZERO_COPY=0 forces the copy.
-    ZERO_COPY = os.environ.get("INC_MI355X_HESSIAN_ZERO_COPY", "1") == "1"
+    # the same forward therefore simply keeps the copying path.  (A class attribute: tests set it to False to force the copy.)
+    ZERO_COPY = True
 
     def __init__(self, columns, device):
         self.columns = columns
@@ -484,9 +357,10 @@ class HessianAccumulator:
                 for h in self._handles:
                     h.wait()
                 self._handles = None
-            if self._ready is not None:  # factorised on a side stream (prefactor): order this stream behind it
+            if self._ready is not None:
+                # factorised on a side stream (prefactor): order THIS stream behind it.  The event stays: layers that share the
+                # accumulator may be solved on different streams (the late solve), and every one of them has to wait
                 torch.cuda.current_stream().wait_event(self._ready)
-                self._ready = None
             return self.finalized[1:]
         self.flush()
         self._stage = None
@@ -501,14 +375,7 @@ class HessianAccumulator:
         if act_order:
             perm = torch.argsort(torch.diagonal(H), descending=True)
             H = H[perm][:, perm].contiguous()
-        if _EXACT_TRIO:  # the reference's three factorisations through rocSOLVER (INC_MI355X_CHOLESKY_TRIO=1)
-            L = torch.linalg.cholesky(H)
-            Hi = torch.cholesky_inverse(L)
-            del L
-            Hinv = torch.linalg.cholesky(Hi, upper=True).contiguous()
-            del Hi
-        else:
-            Hinv, self._info = inverse_cholesky_upper(H, check=False)
+        Hinv, self._info = inverse_cholesky_upper(H, check=False)
         self.H = None
         self.finalized = (key, Hinv, dead, perm)
         return Hinv, dead, perm
@@ -562,8 +429,6 @@ class HessianAccumulator:
         `inverse_factor` waits on the handles when a solve first needs the factor)."""
         if ctx.rank == owner:
             Hinv, dead, perm = self.inverse_factor(percdamp, act_order)
-            if self._info is None:  # (the rocSOLVER trio raises on its own)
-                self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
         else:
             self.flush()
             self._stage, self.H = None, None
@@ -613,6 +478,25 @@ class GPTQ:
 
     def add_batch(self, inp, out=None):
         self.acc.add_batch(inp)
+
+    lookahead = True  # the column loop's second stream (bit-identical either way; tests compare)
+
+    def column_loop(self, w32, Hinv, scale, zero, loop_scale, loop_zero, codes, Q, gs, kernel_gs, blocksize, bits, sym, dynamic_groups, mse):
+        """The loop of gptq.py:1250-1304 as ONE C-ABI call: per 128 columns `[find_params] -> chain -> next-128 update` on this
+        stream and the rest of the trailing update on a second stream underneath the next chain (look-ahead: every column still
+        receives its updates in block order from the same 128-column tiles, so W, the codes and Q are bit-identical to the
+        one-stream loop).  tests/ab_partners.python_column_loop issues the same launches one by one from Python (its A/B partner)."""
+        N, K = w32.shape
+        flags = (ops.GPTQ_DYNAMIC_GROUPS if dynamic_groups else 0) | (ops.GPTQ_MSE if mse else 0)
+        look = self.lookahead and K % QBLOCK == 0 and blocksize % QBLOCK == 0 and K >= 3 * QBLOCK and w32.is_cuda
+        side = _lookahead_stream(w32.device) if look else None
+        err_ws = torch.empty((2, N, QBLOCK), dtype=torch.float32, device=w32.device)
+        if side is not None:
+            for t in (w32, Hinv, scale, zero, loop_scale, loop_zero, codes, Q, err_ws):
+                t.record_stream(side)
+        ops.gptq_quantize_layer(w32, Hinv, scale, zero, None if loop_scale is scale else loop_scale,
+                                None if loop_scale is scale else loop_zero, codes, Q, err_ws, gs, kernel_gs, blocksize, bits, sym, flags,
+                                aux_stream=side)
 
     def fasterquant(self, W, blocksize=128, percdamp=0.01, groupsize=-1, act_order=False, hybrid_order=False,
                     fp8_aware=False, static_groups=False):
@@ -671,92 +555,13 @@ class GPTQ:
 
         codes = torch.empty((N, K), dtype=torch.uint8, device=W.device)
         Q = torch.empty((N, K), dtype=weight_dtype, device=W.device)
-        err = torch.empty((N, QBLOCK), dtype=torch.float32, device=W.device)
         dynamic_groups = groupsize != -1 and not static_groups
         kernel_gs = gs if groupsize != -1 else 0
         if loop_scale is not scale:
             kernel_gs = 1
         blocksize = int(blocksize) if blocksize and blocksize > 0 else K
-        i1 = 0 if N > 0 else K
-        # Look-ahead (INC_MI355X_GPTQ_LOOKAHEAD=0 disables): the 128-step quantisation chain of block b+1 only needs the NEXT 128
-        # columns of block b's lazy update; the rest of that update (the bulk of the trailing matrix) runs on a second stream
-        # underneath it.  Every column still receives its updates in block order (rest(b-1) is awaited before next(b)), from
-        # the same 128-column tiles: W, the codes and Q are bit-identical to the one-stream loop.
-        lookahead = (LOOKAHEAD and N > 0 and K % QBLOCK == 0 and blocksize % QBLOCK == 0 and K >= 3 * QBLOCK and W.is_cuda)
-        if ONE_CALL and N > 0:
-            # the whole loop below as ONE C-ABI call (inc_gptq_quantize_layer issues the same launches in the same order from C++:
-            # bit-identical W / codes / Q; INC_MI355X_GPTQ_ONE_CALL=0 keeps the Python loop, which the tests compare it with)
-            flags = (ops.GPTQ_DYNAMIC_GROUPS if dynamic_groups else 0) | (ops.GPTQ_MSE if mse else 0)
-            flags |= 0 if FUSE_FIND_PARAMS else ops.GPTQ_NO_FUSED_PARAMS
-            main = torch.cuda.current_stream(W.device)
-            side = _lookahead_stream(W.device) if lookahead else None
-            err_ws = torch.empty((2, N, QBLOCK), dtype=torch.float32, device=W.device)
-            if side is not None:
-                for t in (w32, Hinv, scale, zero, loop_scale, loop_zero, codes, Q, err_ws):
-                    t.record_stream(side)
-            ops.gptq_quantize_layer(w32, Hinv, scale, zero, None if loop_scale is scale else loop_scale,
-                                    None if loop_scale is scale else loop_zero, codes, Q, err_ws, gs, kernel_gs, blocksize, bits, sym, flags,
-                                    aux_stream=side)
-            i1 = K
-            lookahead = False
-        if lookahead:
-            main = torch.cuda.current_stream(W.device)
-            side = _lookahead_stream(W.device)
-            errs = (err, torch.empty_like(err))
-            side.wait_stream(main)  # w32 / Hinv / scales were produced on the main stream
-            rest_done = None
-            blk = 0
-        # find_params fused into the quantisation launch (one kernel less per 128 columns of the serial chain): only when the
-        # reference block IS the 128-column block and every group lies inside it -- with a larger reference block the second
-        # half's parameters must come from W BEFORE the first half's lazy update (gptq.py:1266-1272 reads the global W)
-        fuse_params = (FUSE_FIND_PARAMS and dynamic_groups and not mse and blocksize == QBLOCK and gs in (32, 64, QBLOCK)
-                       and K % QBLOCK == 0 and loop_scale is scale and N > 0)
-        while i1 < K:
-            ref_end = min((i1 // blocksize + 1) * blocksize, K)  # end of the reference's block (gptq.py:1250)
-            count = min(QBLOCK, ref_end - i1)
-            if dynamic_groups and i1 % blocksize == 0 and not fuse_params:
-                # groups that START inside this reference block read the global W as it is now (gptq.py:1266-1272)
-                g_first = -(-i1 // gs)
-                g_last = (ref_end - 1) // gs
-                if g_last >= g_first:
-                    if lookahead and rest_done is not None and (g_last + 1) * gs > i1 + QBLOCK:
-                        # the groups read here reach past this 128-column block (group_size or block_size > 128): those columns
-                        # are still being updated by the previous block's remainder on the second stream
-                        main.wait_event(rest_done)
-                    ops.gptq_find_params(w32, g_first * gs, gs, g_last - g_first + 1, bits, sym, scale, zero, g_first, mse=mse)
-            def quant_block(e):
-                if fuse_params:
-                    if not ops.gptq_quant_block_params(w32, Hinv, scale, zero, codes, Q, e, i1, count, gs, bits, sym):
-                        raise RuntimeError("inc_gptq_quant_block_params refused a full 128-column block")
-                else:
-                    ops.gptq_quant_block(w32, Hinv, loop_scale, loop_zero, codes, Q, e, i1, count, kernel_gs, bits)
-
-            if not lookahead:
-                quant_block(err)
-                ops.gptq_lazy_update(w32, Hinv, err, i1, count)
-                i1 += count
-                continue
-            e = errs[blk & 1]
-            quant_block(e)
-            i2 = i1 + count
-            if i2 < K:
-                if rest_done is not None:
-                    main.wait_event(rest_done)  # rest(b-1) wrote the columns next(b) is about to update (and read Err of b-1)
-                nxt_end = min(i2 + QBLOCK, K)
-                if not ops.gptq_lazy_update_cols(w32, Hinv, e, i1, count, i2, nxt_end):
-                    raise RuntimeError("inc_gptq_lazy_update_cols refused a full 128-column block")
-                if nxt_end < K:
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    with torch.cuda.stream(side):
-                        side.wait_event(ready)
-                        ops.gptq_lazy_update_cols(w32, Hinv, e, i1, count, nxt_end, K)
-                        rest_done = torch.cuda.Event()
-                        rest_done.record(side)
-            i1 += count
-            blk += 1
-        if lookahead:
-            main.wait_stream(side)  # w32 and both Err buffers are free again
+        if N > 0:
+            self.column_loop(w32, Hinv, scale, zero, loop_scale, loop_zero, codes, Q, gs, kernel_gs, blocksize, bits, sym, dynamic_groups, mse)
         logger.debug("fasterquant %dx%d issued in %.3fs", N, K, time.time() - tick)
 
         if ctx is not None:
@@ -836,8 +641,6 @@ class RAWGPTQuantizer(object):
         # (samples sharded), without it every rank is expected to have seen all samples.
         self.row_shard_solve = kwargs.get("row_shard_solve", None)
         mode = os.environ.get("INC_MI355X_GPTQ_MULTI_GPU", "")
-        if os.environ.get("INC_MI355X_GPTQ_SAMPLE_SHARDED", "0") == "1" and not mode:
-            mode = "sample"
         if mode and (self.hessian_allreduce is None and self.row_shard_solve is None):
             import torch.distributed as dist
 
@@ -1296,15 +1099,22 @@ class RAWGPTQuantizer(object):
         round_blocks = rounds_blocks(start)
         # 1. + 2. this round's inputs: posted by the previous call (look-ahead) or produced now
         pend = st.pop("prefetched", None)
-        if pend is None or pend["start"] != start:
+        if pend is not None and pend["start"] != start:
+            # the look-ahead forwards of ANOTHER round have already advanced this rank's hidden states and its messages are posted:
+            # recomputing here would calibrate on the wrong activations.  Rounds must be walked in order.
+            st["prefetched"] = pend
+            raise RuntimeError(f"independent_round({start}): the exchange of round {pend['start']} is already posted (look-ahead); "
+                               "rounds must be called in order, or independent_finish() first")
+        if pend is None:
             pend = post(round_blocks, forwards(round_blocks))
         tp = mark("forward_s", tp)
-        # look-ahead (INC_MI355X_GPTQ_LAYER_LOOKAHEAD=0 disables): the NEXT round's float forwards run now and its block inputs are
+        # look-ahead (LAYER_LOOKAHEAD): the NEXT round's float forwards run now and its block inputs are
         # posted (batch_isend_irecv, asynchronous under RCCL) before this round's block is quantised, so they cross xGMI underneath the
         # quantisation instead of in front of it.  Same forwards on the same data, same messages: identical results.
         if ctx is not None and LAYER_LOOKAHEAD and start + world < len(blocks) and st["exchange"] == "scatter":
             nxt = rounds_blocks(start + world)
             st["prefetched"] = post(nxt, forwards(nxt))
+            tp = mark("lookahead_forward_s", tp)  # (the NEXT round's forwards: its own key, not part of this round's exchange time)
         mine = pend["mine"]
         full = pend["full"] if "full" in pend else self._finish_block_inputs(ctx, pend, st["counts"])
         del pend
@@ -1337,9 +1147,18 @@ class RAWGPTQuantizer(object):
         from ....distributed import owner_of_block
 
         ctx = self.layer_ctx
+        self._drain_prefetched()
         if ctx is not None:
             for b in range(len(blocks)):
                 self._broadcast_packed_block(ctx, blocks[b], owner_of_block(b, ctx.world))
+
+    def _drain_prefetched(self):
+        """Wait for (and drop) a look-ahead exchange that no round consumed -- a run that stops after some rounds (bench.py times K
+        rounds) must not leave posted point-to-point operations and their buffers behind."""
+        st = getattr(self, "_layer_state", None)
+        pend = st.pop("prefetched", None) if st else None
+        if pend is not None and "full" not in pend and self.layer_ctx is not None:
+            self._finish_block_inputs(self.layer_ctx, pend, st["counts"])
 
     def _view_all_samples(self, hidden, n_total):
         """Point the calibration cache at `hidden` (n_total samples): every other cached argument is the first local batch's,
@@ -1736,10 +1555,12 @@ class RAWGPTQuantizer(object):
                         torch.cuda.current_stream(self.device).wait_event(late_event)
 
                     gates = [layers[n].register_forward_pre_hook(gate) for n in late]
-                with _phase("gptq.second_forward"):
-                    self._run_block(block, on_output=replace)
-                for h in gates:
-                    h.remove()
+                try:
+                    with _phase("gptq.second_forward"):
+                        self._run_block(block, on_output=replace)
+                finally:  # a forward that raises must not leave the gates on the user's modules
+                    for h in gates:
+                        h.remove()
             if late is not None:
                 main.wait_event(late_event)  # (a block whose forward never reached those modules)
                 with _phase("gptq.solve_wait"):

@@ -89,7 +89,7 @@ def test_prefix_replay_detects_in_place_use_of_a_recorded_output(monkeypatch):
 
 
 def test_prefix_replay_can_be_switched_off(monkeypatch):
-    monkeypatch.setenv("INC_MI355X_AWQ_PREFIX_REPLAY", "0")
+    monkeypatch.setattr(A, "PREFIX_REPLAY", False)
     q, block = _quantizer_with_block(2)
     with torch.no_grad():
         q._float_block_outputs(block)

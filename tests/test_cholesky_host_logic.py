@@ -1,6 +1,7 @@
-"""Host logic of `inverse_cholesky_upper` (two-level blocking, triangular-aware doubling) on the CPU.
+"""Host logic of the blocked inverse-Cholesky factor (two-level blocking, triangular-aware doubling) on the CPU, on the Python + torch.mm
+form of the algorithm (tests/ab_partners.py: the A/B partner of inc_gptq_inverse_factor, which runs the same blocking from C++).
 
-The only device kernel of the factorisation is `inc_chol_diag_block` (a 128 x 128 diagonal block: factor + inverse of the
+The only device kernel of that form is `inc_chol_diag_block` (a 128 x 128 diagonal block: factor + inverse of the
 factor).  Here it is replaced by a torch.linalg stand-in, so that everything AROUND it -- outer blocks, panel solves, lower-only
 trailing updates, recursive doubling with triangular products, padding -- is checked against the definition the reference
 uses:  U = cholesky(cholesky_inverse(cholesky(H)), upper=True)  (reference gptq.py:1228-1230), in fp64.
@@ -9,7 +10,7 @@ uses:  U = cholesky(cholesky_inverse(cholesky(H)), upper=True)  (reference gptq.
 import pytest
 import torch
 
-import neural_compressor_amd.torch.algorithms.weight_only.gptq as G
+from tests import ab_partners as P
 
 
 def _stand_in(A_view, Linv_view, info, tag):
@@ -19,10 +20,8 @@ def _stand_in(A_view, Linv_view, info, tag):
     Linv_view.copy_(torch.linalg.inv(L).float())
 
 
-@pytest.fixture()
-def host_chol(monkeypatch):
-    monkeypatch.setattr(G.ops, "chol_diag_block", _stand_in)
-    return G
+def _factor(H, outer, depth, tri_min):
+    return P.inverse_cholesky_upper_python(H, check=False, outer=outer, tri_depth=depth, tri_min=tri_min, diag_block=_stand_in)
 
 
 def _spd(K, seed):
@@ -40,12 +39,9 @@ def _spd(K, seed):
     (1500, 512, 1, 128),    # ragged last outer block, one level of triangular splitting
     (2200, 1024, 3, 128),   # deeper splitting than the matrix allows everywhere
 ])
-def test_two_level_factorisation_matches_the_reference_definition(host_chol, monkeypatch, K, outer, depth, tri_min):
-    monkeypatch.setattr(G, "CHOL_OUTER", outer)
-    monkeypatch.setattr(G, "TRI_DEPTH", depth)
-    monkeypatch.setattr(G, "TRI_MIN", tri_min)
+def test_two_level_factorisation_matches_the_reference_definition(K, outer, depth, tri_min):
     H = _spd(K, K)
-    U, info = G.inverse_cholesky_upper(H.clone(), check=False)
+    U, info = _factor(H.clone(), outer, depth, tri_min)
     assert int(info.item()) == 0
     ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H.double())), upper=True)
     assert U.shape == (K, K) and torch.equal(torch.triu(U), U), "U is upper triangular"
@@ -57,13 +53,10 @@ def test_two_level_factorisation_matches_the_reference_definition(host_chol, mon
     assert float(resid.norm() / K ** 0.5) < 1e-4
 
 
-def test_block_sizes_do_not_change_the_result_beyond_rounding(host_chol, monkeypatch):
+def test_block_sizes_do_not_change_the_result_beyond_rounding():
     H = _spd(900, 7)
     outs = []
     for outer, depth in ((128, 0), (512, 2), (1024, 2)):
-        monkeypatch.setattr(G, "CHOL_OUTER", outer)
-        monkeypatch.setattr(G, "TRI_DEPTH", depth)
-        monkeypatch.setattr(G, "TRI_MIN", 128)
-        outs.append(G.inverse_cholesky_upper(H.clone(), check=False)[0])
+        outs.append(_factor(H.clone(), outer, depth, 128)[0])
     for U in outs[1:]:
         assert float((U - outs[0]).norm() / outs[0].norm()) < 2e-6

@@ -916,7 +916,7 @@ def test_save_load_default_awq_keeps_mul_linear(tmp_path):
 
 def _sample_sharded_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                      INC_MI355X_GPTQ_SAMPLE_SHARDED="1")
+                      INC_MI355X_GPTQ_MULTI_GPU="sample")
     import torch.distributed as dist
 
     from neural_compressor_amd import distributed as D
@@ -976,6 +976,10 @@ def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out, layers=2):
 
     torch.cuda.set_device(0)
     D.init_from_env(backend="gloo")
+    if os.environ.get("TEST_GPTQ_LAYER_LOOKAHEAD") is not None:  # (the parent test's A/B choice: a module attribute, not a product switch)
+        import neural_compressor_amd.torch.algorithms.weight_only.gptq as G
+
+        G.LAYER_LOOKAHEAD = os.environ["TEST_GPTQ_LAYER_LOOKAHEAD"] == "1"
     ids = calib_ids()
     mine = D.shard_samples(len(ids), rank, world) if ("sample" in mode or mode == "layer") else range(len(ids))
     model = prepare(tiny_llama(layers=layers), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw))
@@ -1114,10 +1118,10 @@ def test_gptq_layer_per_gpu_two_ranks_is_bit_identical_to_single_process_given_t
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("lookahead", ["1", "0"])
 def test_gptq_layer_per_gpu_three_rounds_with_exchange_lookahead(lookahead, monkeypatch):
-    """Five blocks on two ranks = three rounds, the last one partial.  With the look-ahead (INC_MI355X_GPTQ_LAYER_LOOKAHEAD, default on)
+    """Five blocks on two ranks = three rounds, the last one partial.  With the look-ahead (gptq.LAYER_LOOKAHEAD, default on)
     a round's float forwards and the posting of its block inputs happen one call early, underneath the previous round's
     quantisation: the messages and the arithmetic are the same, so both ranks must still hold exactly the one-process model."""
-    monkeypatch.setenv("INC_MI355X_GPTQ_LAYER_LOOKAHEAD", lookahead)
+    monkeypatch.setenv("TEST_GPTQ_LAYER_LOOKAHEAD", lookahead)  # read by _multi_gpu_worker in the spawned ranks
     monkeypatch.setenv("INC_MI355X_GPTQ_ACT_EXCHANGE", "scatter")
     cfg_kw = dict(use_sym=False)
     res = _spawn_multi_gpu("layer", cfg_kw, layers=5)

@@ -646,10 +646,11 @@ def test_awq_stats(hip, golden):
 def test_inverse_cholesky_upper_vs_reference_trio(hip, K, form, monkeypatch):
     """`form`: the whole factorisation as ONE C-ABI call (inc_gptq_inverse_factor: this library's own fp32 MFMA GEMMs) or the
     Python + torch.mm form of rounds 1-3 (its A/B partner); K = 2432 spans three outer blocks with a short last one."""
-    from neural_compressor_amd.torch.algorithms.weight_only import gptq as G
     from neural_compressor_amd.torch.algorithms.weight_only.gptq import inverse_cholesky_upper
+    from tests.ab_partners import inverse_cholesky_upper_python
 
-    monkeypatch.setattr(G, "CHOL_PYTHON", form == "python")
+    if form == "python":
+        inverse_cholesky_upper = inverse_cholesky_upper_python  # noqa: F811  (tests/ab_partners.py)
     g = torch.Generator().manual_seed(K)
     X = torch.randn(4 * K, K, generator=g, dtype=torch.float64)
     H64 = (2.0 / X.shape[0]) * X.T @ X
@@ -672,10 +673,11 @@ def test_inverse_cholesky_upper_vs_reference_trio(hip, K, form, monkeypatch):
 
 @pytest.mark.parametrize("form", ["cabi", "python"])
 def test_inverse_cholesky_upper_rejects_non_spd(hip, form, monkeypatch):
-    from neural_compressor_amd.torch.algorithms.weight_only import gptq as G
     from neural_compressor_amd.torch.algorithms.weight_only.gptq import inverse_cholesky_upper
+    from tests.ab_partners import inverse_cholesky_upper_python
 
-    monkeypatch.setattr(G, "CHOL_PYTHON", form == "python")
+    if form == "python":
+        inverse_cholesky_upper = inverse_cholesky_upper_python  # noqa: F811
     H = torch.eye(256)
     H[200, 200] = -1.0
     with pytest.raises(torch.linalg.LinAlgError):
@@ -697,8 +699,9 @@ def test_inverse_factor_cabi_matches_the_python_form(hip, monkeypatch):
     H = ((2.0 / X.shape[0]) * X.T @ X)
     H += 0.01 * H.diagonal().mean() * torch.eye(K)
     H = H.to(hip)
-    monkeypatch.setattr(G, "CHOL_PYTHON", True)
-    Up = G.inverse_cholesky_upper(H)
+    from tests.ab_partners import inverse_cholesky_upper_python
+
+    Up = inverse_cholesky_upper_python(H)
     Uc, info = ops.gptq_inverse_factor(H)
     assert int(info.item()) == 0
     assert float((Uc - Up).abs().max() / Up.abs().max()) <= 2e-5
@@ -784,10 +787,13 @@ def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize
     X = torch.randn(6, 96, K, generator=g)
     outs = []
     # (look-ahead, one C-ABI call): inc_gptq_quantize_layer with / without its second stream, then the Python loop that issues the
-    # same launches one by one (INC_MI355X_GPTQ_ONE_CALL=0) with / without look-ahead -- all four must agree bit for bit
+    # same launches one by one (tests/ab_partners.python_column_loop) with / without look-ahead -- all four must agree bit for bit
+    from tests.ab_partners import python_column_loop
+
+    product_loop = G.GPTQ.column_loop
     for look, one_call in ((True, True), (False, True), (True, False), (False, False)):
-        monkeypatch.setattr(G, "LOOKAHEAD", look)
-        monkeypatch.setattr(G, "ONE_CALL", one_call)
+        monkeypatch.setattr(G.GPTQ, "lookahead", look)
+        monkeypatch.setattr(G.GPTQ, "column_loop", product_loop if one_call else python_column_loop(look))
         layer = torch.nn.Linear(K, N, bias=False).to(hip)
         layer.weight.data.copy_(W)
         gq = G.GPTQ(layer, device=hip)
@@ -823,6 +829,14 @@ def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize
     # a row whose code flipped at a tie carries a different W into its later groups (dynamic groups read "W as it is now"): the scales
     # are compared where the codes agree -- there they are the same arithmetic on the same numbers
     assert rel_fro(a[1].cpu()[rows_equal], ref["scale"][rows_equal]) <= 1e-6
+    # ... and in the rows that did flip: every group that ENDS before the row's first differing code saw identical inputs, so its
+    # scale is held to the same bound (a find_params regression on those rows would otherwise go unseen)
+    diff = a[0].cpu().to(torch.int32) != ref_codes
+    first = torch.where(diff.any(dim=1), diff.float().argmax(dim=1), torch.full((N,), K))
+    gw = K // G_
+    clean = (torch.arange(G_).view(1, -1) + 1) * gw <= first.view(-1, 1)  # [N, G]: group lies wholly before the first flip
+    sa, sr = a[1].cpu()[clean], ref["scale"][clean]
+    assert float((sa - sr).abs().max() / sr.abs().max()) <= 1e-6
 
 
 GQW_CASES = {
