@@ -684,7 +684,7 @@ def bench_e2e(device, args, rank, world, note):
     mine = D.shard_samples(len(ids), rank, world) if world > 1 else range(len(ids))
     cfg = GPTQConfig(bits=4, group_size=128, use_sym=True, block_size=128, percdamp=0.01, act_order=False)
     torch.cuda.synchronize()
-    if world > 1:
+    if D.live():
         torch.distributed.barrier()
     t0 = time.perf_counter()
     with torch.no_grad():
@@ -694,7 +694,7 @@ def bench_e2e(device, args, rank, world, note):
         t1 = time.perf_counter()
         model = convert(model)
     torch.cuda.synchronize()
-    if world > 1:
+    if D.live():
         torch.distributed.barrier()
     wall = D.barrier_max_time(time.perf_counter() - t0, device=device)
     packed = sum(isinstance(m, MI355XWeightOnlyLinear) for m in model.modules())
@@ -810,18 +810,21 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # --layer-on-one-gpu: the layer-per-GPU mode with a "world" of one rank (no exchange) -- the per-round terms of the N-GPU projection
-    layer_mode = args.mgpu_mode == "layer" and (world > 1 or args.layer_on_one_gpu)
-    if world > 1:
+    # `live`: the multi-GPU paths run -- N > 1 ranks, or ONE rank with INC_MI355X_DIST_SINGLE_RANK=1 (RCCL bring-up on a 1-GPU box: the
+    # process group, the collective wrappers and the drivers' exchange / broadcast code execute over a world of one rank)
+    live = D.live()
+    layer_mode = args.mgpu_mode == "layer" and (live or args.layer_on_one_gpu)
+    if live:
         # ONE model, N ranks.  layer: one block per rank on the float model's activations; exact: samples sharded, Hessians reduced to
         # their owner rank, factors broadcast, row-sharded solves
         os.environ["INC_MI355X_GPTQ_MULTI_GPU"] = "layer" if layer_mode else "sample+rows"
-    dist_backend = torch.distributed.get_backend() if world > 1 else None
+    dist_backend = torch.distributed.get_backend() if live else None
     # ranks that really are one process per GPU over RCCL ("nccl"); null when the ranks talk gloo (test runs sharing one device)
-    rccl_ranks = (torch.distributed.get_world_size() if dist_backend == "nccl" else None) if world > 1 else 1
+    rccl_ranks = (torch.distributed.get_world_size() if dist_backend == "nccl" else None) if live else 1
 
     # (layer mode on N > 1 ranks: one more round of blocks than is timed -- every round also runs the NEXT round's float forwards and
     # posts its exchange before it quantises, so the last timed round needs a successor to do the same work as the others)
-    n_blocks = (args.warmup + args.steps + (1 if (layer_mode and world > 1) else 0)) * (world if layer_mode else 1)
+    n_blocks = (args.warmup + args.steps + (1 if (layer_mode and live) else 0)) * (world if layer_mode else 1)
     note(f"building {n_blocks}-block Llama-2-7B-shaped model on {device}")
     model = build_model(n_blocks, device)  # same seed on every rank: the ranks hold replicas of the one model
     ids = calib_ids(args.samples, args.seq)
@@ -834,7 +837,7 @@ def main():
             model(ids[j].to(device))
     note(f"calibration inputs captured ({len(mine)} of {len(ids)} samples on this rank)")
     rq = model.quantizer.gptq_quantizer
-    assert ((rq.layer_ctx if layer_mode else rq.dist_ctx) is not None) == (world > 1)
+    assert ((rq.layer_ctx if layer_mode else rq.dist_ctx) is not None) == live
     rq.remove_prepare_for_calibration()
     if layer_mode:
         rq.independent_setup()
@@ -871,7 +874,7 @@ def main():
             torch.cuda.synchronize()
             note(f"warmup step {i} done")
         torch.cuda.synchronize()
-        if world > 1:
+        if live:
             torch.distributed.barrier()
         clock.enabled = True
         if layer_mode and os.environ.get("INC_MI355X_BENCH_ROUND_TIMING", "1" if world == 1 else "0") == "1":
@@ -886,7 +889,7 @@ def main():
         if trace:
             ops.trace_marker(1)
         torch.cuda.synchronize()
-        if world > 1:
+        if live:
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
         clock.enabled = False
@@ -984,7 +987,7 @@ def main():
     torch.cuda.empty_cache()
     if not args.no_e2e:
         result["e2e"] = bench_e2e(device, args, rank, world, note)
-        if world > 1 and result["e2e"]["blocks"] == model_blocks:
+        if live and result["e2e"]["blocks"] == model_blocks:
             # N > 1: the whole job is what `e2e` ran -- capture on every rank, ceil(32 / N) rounds (or 32 sharded blocks), AND the
             # broadcasts of the packed blocks at the end, max over ranks between two barriers.  The round time stays in ms_per_step.
             result["value"] = result["e2e"]["wall_s"]
@@ -992,7 +995,7 @@ def main():
             result["rounds_only_s"] = round(value, 3)
     result.setdefault("value_is", value_is)
     big = [(4096, 4096, 4096), (4096, 11008, 4096), (4096, 4096, 11008), (8192, 4096, 4096)]
-    if not args.no_gemm and world > 1:
+    if not args.no_gemm and live:
         # north_star: the 4096x4096 / 11008x4096 linears "at 1, 2, 4 and 8 GPUs": the forward does not shard, so every rank runs the
         # four BASELINE shapes as a replica at the same time (replicas, reported separately); per-GPU and aggregate
         torch.distributed.barrier()
@@ -1041,7 +1044,7 @@ def main():
             for r in result["dequant_gemm"] if r["M"] >= 1024]
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if live:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

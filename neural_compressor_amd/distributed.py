@@ -42,12 +42,24 @@ import torch
 import torch.distributed as dist
 
 
+# Bring-up switch: keep every multi-GPU code path LIVE on a world of ONE rank (process group initialised, CalibrationGroup built, the
+# drivers' collectives issued).  On a 1-GPU box this runs RCCL's init with `device_id`, the collective wrappers, the asynchronous
+# broadcast handles and the packed-block broadcasts for real (scripts/rccl_single_rank.py, `bench.py --gpus 1 --mgpu-mode ...`), so
+# that the first 8-GPU run is not also RCCL's first run.  Off: a world of one rank takes the plain single-GPU path.
+SINGLE_RANK_GROUP = os.environ.get("INC_MI355X_DIST_SINGLE_RANK", "0") == "1"
+
+
+def live(group=None):
+    """True when the multi-GPU paths should run: an initialised group of more than one rank (or of one rank under SINGLE_RANK_GROUP)."""
+    return bool(dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or SINGLE_RANK_GROUP))
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or SINGLE_RANK_GROUP) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -209,7 +221,7 @@ def shard_samples(n_samples, rank, world):
 
 def barrier_max_time(seconds, device=None):
     """max over ranks of a local wall-clock measurement (bench.py contract)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not live():
         return seconds
     if dist.get_backend() == "gloo":
         device = "cpu"

@@ -644,7 +644,9 @@ class RAWGPTQuantizer(object):
         if mode and (self.hessian_allreduce is None and self.row_shard_solve is None):
             import torch.distributed as dist
 
-            live = bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+            from ....distributed import live as _dist_live
+
+            live = _dist_live()
             assert mode in ("sample", "rows", "sample+rows", "layer"), f"INC_MI355X_GPTQ_MULTI_GPU={mode!r}"
             self.hessian_allreduce = live and mode in ("sample", "sample+rows")
             self.row_shard_solve = live and mode in ("rows", "sample+rows")
@@ -659,16 +661,16 @@ class RAWGPTQuantizer(object):
 
             assert not (self.hessian_allreduce or self.row_shard_solve), "independent_blocks excludes the sample / rows modes"
             if dist.is_available() and dist.is_initialized():
-                from ....distributed import CalibrationGroup
+                from ....distributed import SINGLE_RANK_GROUP, CalibrationGroup
 
                 ctx = CalibrationGroup(None if self.independent_blocks is True else self.independent_blocks)
-                self.layer_ctx = ctx if ctx.world > 1 else None
+                self.layer_ctx = ctx if (ctx.world > 1 or SINGLE_RANK_GROUP) else None
         self.dist_ctx = None
         if self.row_shard_solve:
-            from ....distributed import CalibrationGroup
+            from ....distributed import SINGLE_RANK_GROUP, CalibrationGroup
 
             self.dist_ctx = CalibrationGroup(None if self.row_shard_solve is True else self.row_shard_solve)
-            if self.dist_ctx.world == 1:
+            if self.dist_ctx.world == 1 and not SINGLE_RANK_GROUP:
                 self.dist_ctx = None
 
     # -- config handling (reference :330-398) --------------------------------------------------------

@@ -103,6 +103,15 @@ PY
         INC_MI355X_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --mgpu-mode $mode --steps 2 --warmup 1 --samples 32 --seq 1024 --no-cpu-baseline --no-extra-configs --e2e-blocks 4 > gpurun_out/bench_n2_$mode.log 2> gpurun_out/bench_n2_$mode.err
         echo "bench --gpus 2 ($mode) exit $?"; tail -c 2500 gpurun_out/bench_n2_$mode.log; tail -8 gpurun_out/bench_n2_$mode.err
       done ;;
+    rccl1)
+      # RCCL bring-up on this 1-GPU box: a one-rank nccl group through the package's wrappers and both multi-GPU drivers, then
+      # bench.py's own multi-GPU paths (both modes) over that group
+      INC_MI355X_DIST_SINGLE_RANK=1 timeout 600 python scripts/rccl_single_rank.py > gpurun_out/rccl_single_rank.log 2>&1; echo "rccl_single_rank exit $?"; tail -8 gpurun_out/rccl_single_rank.log
+      for mode in layer exact; do
+        INC_MI355X_DIST_SINGLE_RANK=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 timeout 900 python bench.py --gpus 1 --mgpu-mode $mode --steps 2 --warmup 1 \
+          --no-cpu-baseline --no-extra-configs --no-per-layer --e2e-blocks 4 > gpurun_out/bench_rccl1_$mode.log 2> gpurun_out/bench_rccl1_$mode.err
+        echo "bench --gpus 1 over a one-rank RCCL group ($mode) exit $?"; tail -c 1500 gpurun_out/bench_rccl1_$mode.log; tail -5 gpurun_out/bench_rccl1_$mode.err
+      done ;;
     *) echo "unknown action $1" ;;
   esac
   shift

@@ -226,6 +226,11 @@ def _first_mismatch_report(codes_gpu, ref, rows, sym, bits):
                 clean=~neq.any(1), ref_codes=ref_codes)
 
 
+# budgets of the end-to-end run (own factorisation) = 2 x measured (profiles/r5/parity_report.txt; the same on both kinds of pool host):
+# (differing rows, differing-code fraction); measured 2 rows / 1.45e-4, 3 / 1.10e-4, 18 / 3.67e-3, ties <= 3.3e-6 steps
+OWN_FACTOR_BUDGET = {"o_proj 4096x4096": (4, 3.0e-4), "gate+up stacked 22016x4096": (6, 2.5e-4), "down_proj 4096x11008": (36, 7.5e-3)}
+
+
 @pytest.mark.parametrize("name,N,K,nsample", [("o_proj 4096x4096", 4096, 4096, 384), ("gate+up stacked 22016x4096", 22016, 4096, 384),
                                               ("down_proj 4096x11008", 4096, 11008, 256)])
 def test_fasterquant_baseline_shapes_vs_oracle(hip, name, N, K, nsample):
@@ -262,9 +267,11 @@ def test_fasterquant_baseline_shapes_vs_oracle(hip, name, N, K, nsample):
     print(f"\n[fasterquant {name}, injected Hinv] {nsample} sampled rows x {K} columns: {rep['total']} codes differ "
           f"({rep['frac']:.2e}) in {rep['rows']} rows; every first difference is a +-1 flip, largest distance of the oracle's own "
           f"value from the rounding boundary there {rep['tie']:.2e} steps; max scale rel diff on the {int(clean.sum())} identical rows {s_rel:.2e}")
-    assert rep["tie"] <= 2e-3, "a code differs where the oracle's value was not at a rounding tie"
-    assert rep["rows"] <= 0.25 * nsample and rep["frac"] <= 5e-3
-    assert s_rel <= 1e-3
+    # measured: 0 codes differ at all three shapes, scales bit-identical.  Gate: at most two rows may flip at a tie closer than 1e-5
+    # steps (the oracle's CPU GEMM order is the host's MKL's), nothing else
+    assert rep["tie"] <= 1e-5, "a code differs where the oracle's value was not at a rounding tie"
+    assert rep["rows"] <= 2 and rep["frac"] <= 5e-4
+    assert s_rel <= 1e-6
     # the first reference block is untouched by any lazy update: bit-exact codes AND scales there, flips or not
     assert torch.equal(codes[rows][:, :128].cpu().to(torch.int32), rep["ref_codes"][:, :128])
     assert torch.equal(s_gpu[:, 0], s_ref[:, 0])
@@ -279,9 +286,10 @@ def test_fasterquant_baseline_shapes_vs_oracle(hip, name, N, K, nsample):
     s2 = float(((scale2[rows].cpu()[clean2] - s_ref[clean2]).abs() / s_ref[clean2]).max()) if bool(clean2.any()) else 0.0
     print(f"[fasterquant {name}, own factorisation] {rep2['total']} codes differ ({rep2['frac']:.2e}) in {rep2['rows']} rows; "
           f"largest first-difference tie distance {rep2['tie']:.2e} steps; max scale rel diff on identical rows {s2:.2e}")
-    assert rep2["tie"] <= 5e-3
-    assert rep2["rows"] <= 0.35 * nsample and rep2["frac"] <= 1e-2
-    assert s2 <= 1e-3
+    max_rows, max_frac = OWN_FACTOR_BUDGET[name]
+    assert rep2["tie"] <= 1e-5, "a code differs where the oracle's value was not at a rounding tie"
+    assert rep2["rows"] <= max_rows and rep2["frac"] <= max_frac, (rep2["rows"], rep2["frac"])
+    assert s2 <= 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------

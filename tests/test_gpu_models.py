@@ -382,6 +382,12 @@ def test_gptq_options_tiny_llama_vs_reference(tag, kw):
         # (profiles/r4/parity_report.txt: true_seq 0.99778 / 0.97788, mse 1.00000 / 1.00000) minus a margin
         lo0, lo1 = GPTQ_OPTION_BUDGET[tag]
         assert rep[0]["code_match"] >= lo0 and rep[1]["code_match"] >= lo1, rep
+        if tag == "true_seq":
+            # not a budget: block 0's q / k / v are solved BEFORE any packed forward runs (their inputs are the float embeddings), so
+            # they must equal the reference's words exactly; only the groups behind a packed forward may move
+            for n, m in mods.items():
+                if ".layers.0.self_attn." in n and n.rsplit(".", 1)[-1] in ("q_proj", "k_proj", "v_proj"):
+                    assert np.array_equal(m.qweight.cpu().numpy(), g[f"{n}.qweight"]), n
         assert first >= 0.95 and worst >= 0.88, (first, worst)
     with torch.no_grad():
         y = q(ids[0].to("cuda")).logits.float().cpu()

@@ -399,9 +399,18 @@ def test_gptq_column_loop_with_injected_hinv(hip, golden, tag):
         assert np.array_equal(Q.cpu().numpy(), ref_Q)
     else:
         # the lazy update is a GEMM whose summation order differs from MKL's: allow rounding-tie flips
-        assert match >= 0.995, f"only {match:.4f} of the codes match"
-        assert rel_fro(scale.cpu(), torch.from_numpy(ref_scale)) <= 1e-3
-        assert rel_fro(Q.cpu(), torch.from_numpy(ref_Q)) <= 2e-2  # a flipped code moves one weight by one step
+        print(f"\n[column loop {tag}, oracle Hinv] codes identical {match:.6f}, scale rel-Frobenius {rel_fro(scale.cpu(), torch.from_numpy(ref_scale)):.2e}, "
+              f"Q rel-Frobenius {rel_fro(Q.cpu(), torch.from_numpy(ref_Q)):.2e}")
+        # measured (profiles/r5/parity_report.txt): codes identical 1.000000, scales 0 / 8e-8, Q 0 / 9e-8 with the oracle's Hinv.
+        # Gates: with every code equal the scales and Q are the same arithmetic (1e-6); a host whose MKL sums the oracle's update in
+        # another order may flip a rounding tie: at most 0.1 % of the codes, each moving one weight by one step
+        assert match >= 0.999, f"only {match:.4f} of the codes match"
+        if match == 1.0:
+            assert rel_fro(scale.cpu(), torch.from_numpy(ref_scale)) <= 1e-6
+            assert rel_fro(Q.cpu(), torch.from_numpy(ref_Q)) <= 1e-6
+        else:
+            assert rel_fro(scale.cpu(), torch.from_numpy(ref_scale)) <= 1e-3
+            assert rel_fro(Q.cpu(), torch.from_numpy(ref_Q)) <= 1e-2
         # first block is untouched by any lazy update -> exact
         assert np.array_equal(got_codes[:, :128], ref_ints[:, :128])
 
