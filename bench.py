@@ -93,7 +93,7 @@ def _pmc_traffic(key):
     they come from separate `rocprofv3 --pmc` passes over THIS command (scripts/gpu_pmc_bench.sh: FETCH_SIZE doubled as
     the MI355X guide prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE), whose per-launch means are
     committed under profiles/ (newest round first); null when no PMC pass has been recorded for this kernel."""
-    for rnd in ("r4_pmc", "r3_pmc", "r2_pmc", "r1_pmc"):
+    for rnd in ("r5_pmc", "r4_pmc", "r3_pmc", "r2_pmc", "r1_pmc"):
         path = os.path.join(ROOT, "profiles", rnd, "bench_traffic.json")
         try:
             with open(path) as f:

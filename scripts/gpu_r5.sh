@@ -36,9 +36,9 @@ while [[ $# -gt 0 ]]; do
       grep -E "median|FAIL" gpurun_out/kbench_r5_decode.log | tail -40 ;;
     timeline)
       # one-step timelines (kernel trace + copies) of the bench step, late solve off / on
-      for late in 0 1; do
+      for late in 1; do
         rm -rf "$R/gpurun_out/tl_late$late"
-        ( cd /tmp && INC_MI355X_TRACE_RANGES=1 INC_MI355X_GPTQ_LATE_SOLVE=$late timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv \
+        ( cd /tmp && INC_MI355X_TRACE_RANGES=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv \
             -d "$R/gpurun_out/tl_late$late" -o tl -- python "$R/bench.py" --steps 2 --warmup 2 $BENCH_MIN > "$R/gpurun_out/tl_late$late.log" 2> "$R/gpurun_out/tl_late$late.err" )
         echo "timeline late=$late exit $?"; grep -o '"ms_per_step": [0-9.]*' gpurun_out/tl_late$late.log
         python3 scripts/step_timeline.py gpurun_out/tl_late$late gpurun_out/step_timeline_late$late.md > /dev/null 2> gpurun_out/step_timeline_late$late.err || tail -3 gpurun_out/step_timeline_late$late.err
@@ -95,7 +95,7 @@ PY
       find gpurun_out/prof_chol -name "*.csv" -size +20M -delete ;;
     prof)
       rm -rf "$R/gpurun_out/prof"
-      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r4 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs --no-per-layer > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r5 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs --no-per-layer > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
       echo "prof exit $?"; find gpurun_out/prof -name "*kernel_stats*" | head -3
       find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete ;;
     bench2)

@@ -147,6 +147,15 @@ def main():
             names[short] += k["e"] - k["s"]
             cnt[short] += 1
         rec["top_kernels"] = [dict(name=n, sum_ms=v / 1e6, launches=cnt[n]) for n, v in names.most_common(18)]
+        # the model's own elementwise / copy kernels by what they are (their names differ only inside the template arguments)
+        tn, tc = collections.Counter(), collections.Counter()
+        for k in step:
+            if classify(k["name"]).startswith("elementwise"):
+                full = k["name"].replace("at::native::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+                key = full[:150]
+                tn[key] += k["e"] - k["s"]
+                tc[key] += 1
+        rec["torch_kernels"] = [dict(name=n, sum_ms=v / 1e6, launches=tc[n]) for n, v in tn.most_common(16)]
         summary.append(rec)
     js = json.dumps(summary, indent=1)
     for rec in summary:
@@ -173,6 +182,11 @@ def main():
                      + ", ".join(f"{c} {v:.2f}" for c, v in sorted(rec["column_loop_beside_ms"].items(), key=lambda kv: -kv[1]) if v > 0.01))
         lines.append("")
         lines.append("top kernels: " + "; ".join(f"{t['name']} {t['sum_ms']:.1f} ms x{t['launches']}" for t in rec["top_kernels"][:12]))
+        lines.append("")
+        lines.append("| torch elementwise / norm / copy kernel | ms | launches |")
+        lines.append("|---|---|---|")
+        for t in rec.get("torch_kernels", []):
+            lines.append(f"| `{t['name']}` | {t['sum_ms']:.2f} | {t['launches']} |")
         lines.append("")
     text = "\n".join(lines)
     print(text)

@@ -142,3 +142,70 @@ def test_rtn_config_at_3_and_6_bits_end_to_end(hip):
         x = torch.randn(7, 160, device=hip)
         y = q(x)
         assert y.shape == (7, 40) and torch.isfinite(y).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# model level: the unmodified reference's quantised tiny Llama at 3 / 6 bits (tests/golden/make_golden_bits_models.py)
+# ---------------------------------------------------------------------------------------------------
+def _field_match(a, b, bits):
+    """Fraction of identical `bits`-wide fields of two packed int32 arrays (n_pack = 32 // bits fields per word)."""
+    a, b = a.astype(np.uint32).reshape(-1), b.astype(np.uint32).reshape(-1)
+    npk, mask = 32 // bits, np.uint32(2**bits - 1)
+    same = sum(int((((a >> np.uint32(bits * e)) & mask) == ((b >> np.uint32(bits * e)) & mask)).sum()) for e in range(npk))
+    return same / (npk * a.size)
+
+
+def _woq(model):
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    return {n: m for n, m in model.named_modules() if isinstance(m, MI355XWeightOnlyLinear)}
+
+
+@pytest.mark.parametrize("bits", [3, 6])
+def test_rtn_tiny_llama_odd_widths_bit_exact(hip, bits):
+    import os
+
+    from neural_compressor_amd.torch.quantization import RTNConfig, quantize
+    from tests.model_zoo import calib_ids, tiny_llama
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"rtn_tiny_llama_b{bits}_asym_g32.npz"))
+    q = quantize(tiny_llama(), RTNConfig(bits=bits, group_size=32, use_sym=False, use_layer_wise=False))
+    mods = _woq(q)
+    assert len(mods) == int(g["n_modules"]) == 14
+    for name, m in mods.items():
+        assert m.bits == bits
+        assert np.array_equal(m.qweight.cpu().numpy(), g[f"{name}.qweight"]), name
+        assert np.array_equal(m.qzeros.cpu().numpy(), g[f"{name}.qzeros"]), name
+        assert np.array_equal(m.scales.cpu().numpy().view(np.uint16), g[f"{name}.scales"].view(np.uint16)), name
+    with torch.no_grad():
+        y = q(calib_ids()[0].to("cuda")).logits.float().cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert float((y - ref).norm() / ref.norm()) <= 1e-2  # fp16 fused forward vs the reference's fp32 F.linear
+
+
+def test_gptq_tiny_llama_3bit_vs_reference(hip):
+    """GPTQConfig(bits=3) end to end: Hessians, factor, column loop at maxq = 7, 10-field words.  Block 0 sees the reference's inputs:
+    its codes must agree except at rounding ties; block 1 inherits what block 0 flipped."""
+    import os
+
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+    from tests.model_zoo import calib_ids, tiny_llama
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gptq_tiny_llama_b3_sym_g32.npz"))
+    model = prepare(tiny_llama(), GPTQConfig(bits=3, group_size=32, use_sym=True, block_size=128))
+    for x in calib_ids():
+        model(x)
+    q = convert(model)
+    mods = _woq(q)
+    assert len(mods) == int(g["n_modules"]) == 14
+    per_block = {0: [], 1: []}
+    for name, m in mods.items():
+        assert m.bits == 3 and m.qweight.shape == g[f"{name}.qweight"].shape
+        per_block[0 if ".layers.0." in name else 1].append(_field_match(m.qweight.cpu().numpy(), g[f"{name}.qweight"], 3))
+        assert np.array_equal(m.qzeros.cpu().numpy(), g[f"{name}.qzeros"]), name  # sym: the constant zero point, 10 fields per word
+    print(f"\n[gptq tiny_llama 3-bit] codes identical: block 0 {min(per_block[0]):.5f}, block 1 {min(per_block[1]):.5f}")
+    assert min(per_block[0]) >= 0.999 and min(per_block[1]) >= 0.99, per_block
+    with torch.no_grad():
+        y = q(calib_ids()[0].to("cuda")).logits.float().cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert float((y - ref).norm() / ref.norm()) <= 3e-2
