@@ -105,7 +105,8 @@ __device__ unsigned long long* g_d2r_timeline = nullptr;
 #define INC_D2R_STAMP(SLOT)
 #endif
 
-// ABL (harness build only, timing-only, WRONG results): bit 2 no x LDS-DMA, 3 no W loads, 6 no per-step barrier, 7 no epilogue stores
+// ABL (harness build only, timing-only, WRONG results): bit 2 no x LDS-DMA, 3 no W loads, 6 no per-step barrier, 7 no epilogue stores,
+// 9 no scalar pointer arithmetic (every step re-reads the first tiles)
 template <bool IS_BF16, int NS, int ABL>
 __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
   }
   const uint16_t* const xbase = xptr;
   auto advance_x = [&]() {  // scalar arithmetic only (no branch): the tile index saturates at the last tile
+    if constexpr ((ABL & 512) != 0) return;  // (harness, timing-only: the step without its scalar pointer arithmetic)
     asm volatile("" : "+s"(xt), "+s"(dma_off));  // inputs pinned too: the arithmetic starts HERE, behind the slot's MFMA
     xt = min(xt + 1, nk - 1);
     xptr = xbase + (uint32_t)(xt * TK);
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(D2R_THREADS) void woq_gemm_w4_d2r_kernel(
   uint32_t gi_ = 0;
   const uint32_t wstride32 = (uint32_t)wstride, n32 = (uint32_t)N, nw32 = (uint32_t)NW;  // every offset below is < 2^31 elements (inc_woq_gemm checks)
   auto advance_w = [&](int part) {  // scalar arithmetic only (no branch), in three small pieces for three gaps of the step
+    if constexpr ((ABL & 512) != 0) return;
     if (part == 0) {
       asm volatile("" : "+s"(wt));
       wt = min(wt + 1, nk - 1);
@@ -627,6 +630,8 @@ int inc_launch_woq_gemm_d2r(const uint16_t* x, const uint32_t* qw, const uint16_
   else if (abl == 268) INC_D2R(true, 4, 268)
   else if (abl == 332) INC_D2R(true, 4, 332)
   else if (abl == 320) INC_D2R(true, 4, 320) /* no barrier only */
+  else if (abl == 768) INC_D2R(true, 4, 768) /* no scalar pointer arithmetic */
+  else if (abl == 844) INC_D2R(true, 4, 844) /* no global traffic, no barrier, no pointer arithmetic */
 #endif
   else INC_D2R(true, 4, 0)
 #undef INC_D2R

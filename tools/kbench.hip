@@ -1165,6 +1165,8 @@ int main(int argc, char** argv) {
     run_d2r_timeline(4096, 4096, 4096, 268, "- all global traffic");
     run_d2r_timeline(4096, 4096, 4096, 320, "- barrier");
     run_d2r_timeline(4096, 4096, 4096, 332, "- global traffic - barrier");
+    run_d2r_timeline(4096, 4096, 4096, 768, "- scalar pointer arithmetic");
+    run_d2r_timeline(4096, 4096, 4096, 844, "- traffic - barrier - pointer arithmetic");
     run_d2r_timeline(4096, 4096, 4096, 256, "full kernel again");
   }
   if (what == "gemm" || what == "all") {
