@@ -156,6 +156,13 @@ int inc_codebook_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_ou
                        int64_t K, int group_size, const float* values, const int32_t* codes, int n_entries,
                        float quantile, inc_stream_t stream);
 
+/* The same with the caller's scales: quantize_4bit(tensor, scale=...) (utility.py:127-128: `scale = kwargs["scale"]`, the
+ * tensor is divided by it instead of by its own max).  scale_in [N,G] fp32 (device; must not alias scale_out); NULL = compute
+ * the scales (== inc_codebook_quant).  `quantile` is ignored when scale_in is given, like in the reference.               */
+int inc_codebook_quant_with_scale(const void* w, int wdtype, void* qdq_out, int32_t* int_out, float* scale_out, int64_t N,
+                                  int64_t K, int group_size, const float* values, const int32_t* codes, int n_entries,
+                                  float quantile, const float* scale_in, inc_stream_t stream);
+
 /* *out += sum((a-b)^2) over n elements, in fp64 with a FIXED summation order (same input -> same bits on every
  * launch; zero *out first).  == the loss of search_clip (utility.py:468) and AWQ's output-MSE (awq.py:336-344,
  * 450-458), which the reference accumulates in Python doubles and takes an argmin over.  `workspace`: at least

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinc_mi355x.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 INC_OK = 0
 INC_F32, INC_F16, INC_BF16 = 0, 1, 2
@@ -38,6 +38,7 @@ SIGNATURES = {
         [_P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, _P],
     ),
     "inc_codebook_quant": (c_int, [_P, c_int, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_float, _P]),
+    "inc_codebook_quant_with_scale": (c_int, [_P, c_int, _P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_int, c_float, _P, _P]),
     "inc_mse_accumulate_workspace_bytes": (c_int64, []),
     "inc_mse_accumulate": (c_int, [_P, _P, c_int, c_int64, _P, _P, _P]),
     "inc_gptq_hessian_accum": (c_int, [_P, c_int, c_int64, c_int64, c_int64, _P, c_float, c_float, _P]),

@@ -133,6 +133,47 @@ __device__ __forceinline__ void lds_dma_4x1k(const void* base, uint32_t lds_dst,
       : "memory", "scc");
 }
 
+// Eight LDS-DMA instructions of one wave from ONE base: LDS[lds_dst + i*PITCH + lane*16] <- base[v_i], i = 0..7 (the caller folds the
+// row stride into the per-lane offsets once per tile).  Same hazards as above; 4 + 3 per piece instructions instead of a 64-bit
+// scalar address computation, an M0 save / restore and six wait states per piece.
+template <int PITCH>
+__device__ __forceinline__ void lds_dma_8x1k(const void* base, uint32_t lds_dst, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3,
+                                             uint32_t v4, uint32_t v5, uint32_t v6, uint32_t v7) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_nop 4\n\t"
+      "s_mov_b32 m0, %10\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %9\n\t"
+      "s_add_u32 m0, %10, %11\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %9\n\t"
+      "s_add_u32 m0, %10, %12\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, %9\n\t"
+      "s_add_u32 m0, %10, %13\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %4, %9\n\t"
+      "s_add_u32 m0, %10, %14\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %5, %9\n\t"
+      "s_add_u32 m0, %10, %15\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %6, %9\n\t"
+      "s_add_u32 m0, %10, %16\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %7, %9\n\t"
+      "s_add_u32 m0, %10, %17\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %8, %9\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "s"(base), "s"(lds_dst), "n"(PITCH), "n"(2 * PITCH),
+        "n"(3 * PITCH), "n"(4 * PITCH), "n"(5 * PITCH), "n"(6 * PITCH), "n"(7 * PITCH)
+      : "memory", "scc");
+}
+
 // one 1 KiB LDS-DMA of this wave: LDS[lds_dst + lane*16] <- base[voff] (per-lane byte offset); M0 saved / restored
 __device__ __forceinline__ void lds_dma_1k(const void* base, uint32_t lds_dst, uint32_t voff) {
   uint32_t keep;

@@ -230,10 +230,11 @@ constexpr int TR_PITCH = 1056;
 constexpr int TR_TOK = 64;
 constexpr int TR_NST = 2;
 constexpr int TR_STAGE = TR_TOK * TR_PITCH;  // 67 584 B
-// Product form of the tile (round 5, tools/kbench hessian, profiles/r5/kbench_hessian.log): bit 5 = the step's 16 MFMA rows run as ONE
-// rolling fragment pipeline, bit 4 = static priority for waves 4-7.  Same MFMAs in the same order as the round-4 form (ABL 0,
-// harness flag 59): bit-identical H, 2-8 % less time per launch.
-constexpr int TR_ABL = 48;
+// Product form of the tile (round 5, tools/kbench hessian / hpf, profiles/r5/kbench_hessian*.log): bit 5 = the step's 16 MFMA rows run as
+// ONE rolling fragment pipeline, bit 4 = static priority for waves 4-7, bit 7 = a step's eight LDS-DMA pieces issued from one asm
+// block (per-lane row offsets computed once per tile; ~45 instead of ~200 instructions per wave and step: 9.79 -> 9.22 ms per
+// batched launch).  Same requests and MFMAs in the same order as the round-4 form (ABL 0, harness flag 59): bit-identical H.
+constexpr int TR_ABL = 176;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -276,7 +277,22 @@ __device__ __forceinline__ void hessian_syrk_tr_tile(const uint16_t* __restrict_
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + r * TR_PITCH);
     if constexpr ((ABL & 1) == 0) lds_dma_1k(x + t * ldx, dst, voff);
   };
+  // ABL bit 7: a step whose TOK token rows all exist (every step but a ragged last one) issues its pieces from ONE asm block -- the
+  // row stride sits in per-lane offsets computed once per tile, so a piece is an M0 update and the request instead of ~25 instructions
+  // (a clamped 64-bit row address, M0 save / restore, wait states).  Same requests in the same order: bit-identical H.
+  constexpr bool FAST_ISSUE = (ABL & 128) != 0 && RPW == 8;  // (written for eight rows per wave: the 64-token stages)
+  uint32_t voffr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) voffr[i] = voff + (uint32_t)((int64_t)i * ldx * 2);
   auto issue = [&](int kt) {
+    if constexpr (FAST_ISSUE && (ABL & 1) == 0) {
+      if ((int64_t)(kt + 1) * TOK <= T) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (kt & (NST - 1)) * STAGE + wave * RPW * TR_PITCH);
+        lds_dma_8x1k<TR_PITCH>(x + ((int64_t)kt * TOK + wave * RPW) * ldx, dst, voffr[0], voffr[1], voffr[2], voffr[3], voffr[4], voffr[5],
+                               voffr[6], voffr[7]);
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) issue_one(kt, i);
   };
@@ -1347,6 +1363,10 @@ int inc_gptq_hessian_accum(const void* x, int xdtype, int64_t T, int64_t K, int6
           INC_HABL(0)
           INC_LAUNCH_RETURN();
         }
+        if (habl == 14 && xdtype == INC_BF16) {  // 60: the product tile with its pieces issued from one asm block per step
+          INC_HABL(176)
+          INC_LAUNCH_RETURN();
+        }
         if (habl >= 10 && habl <= 12 && xdtype == INC_BF16) {  // 56: rolling fragments + priority; 57: one rolling pipeline per step; 58: that + priority
           if (habl == 10) INC_HABL(24) else if (habl == 11) INC_HABL(32) else INC_HABL(48)
           INC_LAUNCH_RETURN();
@@ -1464,11 +1484,11 @@ int inc_gptq_hessian_accum_multi(int n, const void* const* xs, int xdtype, int64
 #ifdef INC_KBENCH
     {  // harness flags 53 / 54 / 56 / 57 / 58 / 59: the tile variants of the single-problem launch, in the batched launch
       const int f = inc_small_tiles_flag(-1);
-      const int mabl = f == 53 ? 8 : f == 54 ? 16 : f == 56 ? 24 : f == 57 ? 32 : f == 58 ? 48 : f == 59 ? 64 : 0;  // (64 = ABL 0)
+      const int mabl = f == 53 ? 8 : f == 54 ? 16 : f == 56 ? 24 : f == 57 ? 32 : f == 58 ? 48 : f == 59 ? 64 : f == 60 ? 176 : 0;  // (64 = ABL 0)
       if (mabl && xdtype == INC_BF16) {
 #define INC_HMV(A) { (void)hipFuncSetAttribute((const void*)hessian_syrk_tr_256_multi_kernel<true, TR_TOK, TR_NST, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); \
                      a.block0 = 0; hessian_syrk_tr_256_multi_kernel<true, TR_TOK, TR_NST, A><<<grid, 512, smem3, s>>>(a, T); }
-        if (mabl == 8) INC_HMV(8) else if (mabl == 16) INC_HMV(16) else if (mabl == 24) INC_HMV(24) else if (mabl == 32) INC_HMV(32) else if (mabl == 64) INC_HMV(0) else INC_HMV(48)
+        if (mabl == 8) INC_HMV(8) else if (mabl == 16) INC_HMV(16) else if (mabl == 24) INC_HMV(24) else if (mabl == 32) INC_HMV(32) else if (mabl == 64) INC_HMV(0) else if (mabl == 176) INC_HMV(176) else INC_HMV(48)
 #undef INC_HMV
         if (a.nseg > 1) hessian_tail_finalize_kernel<<<4 * (first - a.full), 512, 0, s>>>(a);
         INC_LAUNCH_RETURN();

@@ -387,7 +387,8 @@ extern "C" {
 // 2: + find_params_mse, awq_repack, sq_*, w8a8_* (SmoothQuant), chol_diag_block
 // 3: inc_mse_accumulate sums in fp64 in a fixed order (workspace argument); inc_debug_set_small_tiles left the library
 // 4: inc_gptq_quantize_layer (the column loop as one call)
-int inc_abi_version(void) { return 7; }
+// 8: + inc_codebook_quant_with_scale (quantize_4bit with the caller's scale)
+int inc_abi_version(void) { return 8; }
 const char* inc_target_arch(void) { return "gfx950"; }
 const char* inc_error_string(int code) {
   switch (code) {

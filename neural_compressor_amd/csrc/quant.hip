@@ -203,7 +203,7 @@ struct CodeBook {
 template <int DT>
 __global__ __launch_bounds__(256) void codebook_quant_kernel(
     const void* __restrict__ w, void* qdq, int32_t* __restrict__ iout, float* __restrict__ scale_out, int64_t N, int64_t K,
-    int64_t G, int gs, int L, CodeBook cb, float quantile, int vec_ok) {
+    int64_t G, int gs, int L, CodeBook cb, float quantile, int vec_ok, const float* __restrict__ scale_in) {
   const int lane = threadIdx.x & 63;
   const int tl = lane & (L - 1);
   const int team = lane / L;
@@ -218,17 +218,24 @@ __global__ __launch_bounds__(256) void codebook_quant_kernel(
   const int64_t base = n * K + kbeg;
   const bool vec = vec_ok != 0;
 
-  float amax = 0.f;
-  for (int c = tl; c * 8 < klen; c += L) {
-    float v[8];
-    const int nv = klen - c * 8;
-    load8<DT>(w, base + c * 8, nv, vec, v);
+  float scale;
+  if (scale_in) {
+    // the caller's scale (quantize_4bit(..., scale=...), utility.py:127-128): used as it is -- torch divides / multiplies in the
+    // promoted type and rounds the result to the tensor's
+    scale = scale_in[pair];
+  } else {
+    float amax = 0.f;
+    for (int c = tl; c * 8 < klen; c += L) {
+      float v[8];
+      const int nv = klen - c * 8;
+      load8<DT>(w, base + c * 8, nv, vec, v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < nv) amax = fmaxf(amax, fabsf(v[i]));
+      for (int i = 0; i < 8; ++i)
+        if (i < nv) amax = fmaxf(amax, fabsf(v[i]));
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    scale = round_to<DT>(round_to<DT>(amax * quantile) / cb.vmax);
   }
-  for (int o = L >> 1; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-  const float scale = round_to<DT>(round_to<DT>(amax * quantile) / cb.vmax);
   if (active && tl == 0 && scale_out) scale_out[pair] = scale;
 
   for (int c = tl; c * 8 < klen; c += L) {
@@ -440,7 +447,15 @@ int inc_gptq_find_params_mse(const float* w, int64_t N, int64_t K, int64_t col0,
 int inc_codebook_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_out, float* scale_out, int64_t N, int64_t K,
                        int group_size, const float* values, const int32_t* codes, int n_entries, float quantile,
                        inc_stream_t stream) {
+  return inc_codebook_quant_with_scale(w, wdtype, qdq_out, int_out, scale_out, N, K, group_size, values, codes, n_entries, quantile,
+                                       nullptr, stream);
+}
+
+int inc_codebook_quant_with_scale(const void* w, int wdtype, void* qdq_out, int32_t* int_out, float* scale_out, int64_t N, int64_t K,
+                                  int group_size, const float* values, const int32_t* codes, int n_entries, float quantile,
+                                  const float* scale_in, inc_stream_t stream) {
   INC_CHECK_ARG(w && values && codes && N > 0 && K > 0 && n_entries >= 2 && n_entries <= 16);
+  INC_CHECK_ARG(!scale_in || scale_in != scale_out);
   int gs = group_size;
   if (gs <= 0 || gs > K) gs = (int)K;
   const int64_t G = ceil_div64(K, gs);
@@ -460,7 +475,7 @@ int inc_codebook_quant(const void* w, int wdtype, void* qdq_out, int32_t* int_ou
                      (!qdq_out || (reinterpret_cast<uintptr_t>(qdq_out) & 15) == 0) && (!int_out || (reinterpret_cast<uintptr_t>(int_out) & 15) == 0) && elt > 0;
   INC_DISPATCH_DTYPE(wdtype, DT, {
     codebook_quant_kernel<DT><<<(unsigned)ceil_div64(waves, 4), 256, 0, inc_s(stream)>>>(w, qdq_out, int_out, scale_out, N, K, G, gs, L, cb,
-                                                                                          quantile, vec_ok);
+                                                                                          quantile, vec_ok, scale_in);
   })
   INC_LAUNCH_RETURN();
 }

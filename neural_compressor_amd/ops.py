@@ -355,12 +355,13 @@ def groupwise_quant(w, bits, group_size, scheme, quantile=1.0, full_range=False,
     return qdq
 
 
-def codebook_quant(w, values, codes, group_size, quantile=1.0, return_int=False, inplace=True):
+def codebook_quant(w, values, codes, group_size, quantile=1.0, return_int=False, inplace=True, scale=None):
     """== quantize_4bit through quant_tensor (utility.py:112-149, 246-265): NF4 / FP4 code-book quantisation per row group.
 
     values / codes: the ascending code book and the integers stored for its entries (FLOAT_MAPPING / INT_MAPPING).
     return_int=False: fake-quantises `w` (in place when `inplace`) and returns it; return_int=True: (int32 codes [N,K],
-    scale [N,G] fp32, None) -- there is no zero point in these formats."""
+    scale [N,G] fp32, None) -- there is no zero point in these formats.  `scale` [N,G] (or broadcastable to it): the caller's
+    scales, used instead of the rows' own max (quantize_4bit(..., scale=...), utility.py:127-128)."""
     import ctypes
 
     dev = _dev(w)
@@ -371,6 +372,9 @@ def codebook_quant(w, values, codes, group_size, quantile=1.0, return_int=False,
     n = len(values)
     vals = (ctypes.c_float * n)(*[float(v) for v in values])
     cds = (ctypes.c_int32 * n)(*[int(c) for c in codes])
+    scale_in = None
+    if scale is not None:
+        scale_in = torch.broadcast_to(scale.to(device=dev, dtype=torch.float32).reshape(scale.shape[0], -1), (N, G)).contiguous()
     scale = torch.empty((N, G), dtype=torch.float32, device=dev)
     if return_int:
         iout = torch.empty((N, K), dtype=torch.int32, device=dev)
@@ -379,8 +383,8 @@ def codebook_quant(w, values, codes, group_size, quantile=1.0, return_int=False,
         iout = None
         qdq = w if inplace else torch.empty_like(w)
     with torch.cuda.device(dev):
-        check(lib.inc_codebook_quant(_ptr(w), dtype_code(w.dtype), _ptr(qdq), _ptr(iout), _ptr(scale), N, K, gs, vals, cds, n,
-                                     float(quantile), _stream()), "inc_codebook_quant")
+        check(lib.inc_codebook_quant_with_scale(_ptr(w), dtype_code(w.dtype), _ptr(qdq), _ptr(iout), _ptr(scale), N, K, gs, vals, cds, n,
+                                                float(quantile), _ptr(scale_in), _stream()), "inc_codebook_quant_with_scale")
     if return_int:
         return iout, scale, None
     return qdq

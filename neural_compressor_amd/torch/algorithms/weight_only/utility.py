@@ -33,12 +33,13 @@ def quantize_4bit(tensor, quantile=1.0, dtype="nf4", return_int=False, **kwargs)
     """NF4 / FP4 quantisation of a [rows, group] tensor, one scale per row (reference utility.py:112-149) -> inc_codebook_quant.
     In place like the reference; return_int (or double_quant) returns (codes-as-ints | quantised tensor, scale [rows,1], None)."""
     assert dtype in FLOAT_MAPPING, "unexpected data type."
-    if "scale" in kwargs:
-        raise NotImplementedError("quantize_4bit with a caller-provided scale is not used by any path in scope")
+    given = kwargs.get("scale") if "scale" in kwargs else None  # utility.py:127-128: the caller's scale replaces the rows' own max
     if return_int or kwargs.get("double_quant", False):
-        iw, scale, _ = ops.codebook_quant(tensor, FLOAT_MAPPING[dtype], INT_MAPPING[dtype], -1, quantile=quantile, return_int=True)
-        return iw, scale, None
-    return ops.codebook_quant(tensor, FLOAT_MAPPING[dtype], INT_MAPPING[dtype], -1, quantile=quantile, return_int=False, inplace=True)
+        iw, scale, _ = ops.codebook_quant(tensor, FLOAT_MAPPING[dtype], INT_MAPPING[dtype], -1, quantile=quantile, return_int=True,
+                                          scale=given)
+        return iw, (given if given is not None else scale), None
+    return ops.codebook_quant(tensor, FLOAT_MAPPING[dtype], INT_MAPPING[dtype], -1, quantile=quantile, return_int=False, inplace=True,
+                              scale=given)
 
 
 def quant_tensor(
@@ -96,7 +97,9 @@ def quant_tensor(
     scale_scheme = kwargs.get("double_quant_scheme", "asym")
     scale_group_size = kwargs.get("double_quant_group_size", 256)
     if kwargs.get("double_quant_return_int", False):
-        raise NotImplementedError("double_quant_return_int is marked TODO in the reference and unused")
+        # a TODO in the reference (utility.py:383-384): it drops the inner quant_tensor's result and then unpacks the [1, n] scale
+        # tensor into three names (:393-405) -- the option has never worked; the same exception, not a different behaviour
+        raise ValueError("not enough values to unpack (expected 3, got 1)")
     orig_scale_shape = scale.shape
     flat = scale.reshape(1, -1).contiguous()
     scale_mean = None

@@ -169,11 +169,13 @@ INT_MAPPING = {"nf4": [7, 1, 2, 3, 4, 5, 6, 0, -8, -7, -6, -5, -4, -3, -2, -1], 
                "fp4_e2m1_bnb": [-5, -6, -3, -4, -1, -2, -7, 0, 1, 6, 7, 4, 5, 2, 3], "fp4_e2m1": [-1, -2, -3, -4, -5, -6, -7, 0, 1, 2, 3, 4, 5, 6, 7]}
 
 
-def quantize_4bit(tensor, quantile=1.0, dtype="nf4", return_int=False, keep_scale=False):
-    """utility.py:112-149 (operates in place on `tensor` [rows, group]); keep_scale = the reference's double_quant kwarg."""
+def quantize_4bit(tensor, quantile=1.0, dtype="nf4", return_int=False, keep_scale=False, scale=None):
+    """utility.py:112-149 (operates in place on `tensor` [rows, group]); keep_scale = the reference's double_quant kwarg,
+    scale = its `scale` kwarg (:127-128: the caller's scale replaces the rows' own max)."""
     allow_data, allow_bit = FLOAT_MAPPING[dtype], INT_MAPPING[dtype]
-    scale = tensor.abs().max(1)[0] * quantile / max(allow_data)
-    scale.unsqueeze_(dim=-1)
+    if scale is None:
+        scale = tensor.abs().max(1)[0] * quantile / max(allow_data)
+        scale.unsqueeze_(dim=-1)
     tensor.div_(scale)
     mid = [(allow_data[i] + allow_data[i + 1]) / 2 for i in range(len(allow_data) - 1)]
     q = torch.zeros_like(tensor)
@@ -193,7 +195,7 @@ def quantize_4bit(tensor, quantile=1.0, dtype="nf4", return_int=False, keep_scal
 
 def quant_tensor(weight, bits=4, group_size=-1, scheme="asym", quantile=1.0, return_int=False, full_range=False, dtype="int",
                  double_quant=False, double_quant_dtype="int", double_quant_bits=8, double_quant_scheme="asym",
-                 double_quant_group_size=256):
+                 double_quant_group_size=256, double_quant_return_int=False):
     """utility.py:272-436 for dtype "int" / "nf4" / "fp4*", optionally with double quantisation of the scales (:378-436).
     NOT in place (works on a clone).
 
@@ -207,6 +209,8 @@ def quant_tensor(weight, bits=4, group_size=-1, scheme="asym", quantile=1.0, ret
         if double_quant_scheme == "asym":
             mean = flat.mean()
             flat.sub_(mean)
+        if double_quant_return_int:  # :383-384, 393-405: the inner call's result is dropped, so the unpack of `scale` fails -- always
+            raise ValueError("not enough values to unpack (expected 3, got 1)")
         flat = quant_tensor(flat, double_quant_bits, double_quant_group_size, "sym", 1.0, False, False, double_quant_dtype)
         if mean is not None:
             flat.add_(mean)

@@ -146,3 +146,32 @@ def test_rtn_nf4_save_load_round_trip(hip, g, tmp_path):
     with torch.no_grad():
         y1 = back(ids).logits.float().cpu()
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("dtype", ["nf4", "fp4", "fp4_e2m1"])
+@pytest.mark.parametrize("wd", ["f32", "bf16"])
+def test_quantize_4bit_with_given_scale_vs_reference_golden(hip, dtype, wd):
+    """quantize_4bit(tensor, scale=...) (reference utility.py:127-128) -> inc_codebook_quant_with_scale: fake-quantised values and
+    stored integers bit-exact against the unmodified reference (scales 0.7 .. 1.3 x the rows' own max: both ends of the book
+    saturate); double_quant_return_int raises what the reference raises (it has never worked there, :383-405)."""
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor, quantize_4bit
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "q4scale_golden.npz"))
+    td = torch.float32 if wd == "f32" else torch.bfloat16
+    tag = f"q4s_{dtype}_{wd}"
+    w = torch.from_numpy(g[f"{tag}_w"]).to(td).to(hip)
+    sc = torch.from_numpy(g[f"{tag}_scale"]).to(td).to(hip)
+    t = w.clone()
+    out = quantize_4bit(t, dtype=dtype, scale=sc)
+    assert out.data_ptr() == t.data_ptr()  # in place, like the reference
+    assert np.array_equal(out.float().cpu().numpy(), g[f"{tag}_qdq"])
+    ints, s2, zp = quantize_4bit(w.clone(), dtype=dtype, return_int=True, scale=sc)
+    assert zp is None and s2 is sc
+    assert np.array_equal(ints.cpu().numpy().astype(np.float32), g[f"{tag}_int"])
+    # without a scale the same call computes its own (the pre-existing path through the same kernel)
+    own = quantize_4bit(w.clone(), dtype=dtype)
+    ref = O.quantize_4bit(w.cpu().clone(), dtype=dtype)
+    assert torch.equal(own.cpu(), ref)
+    kind, msg = str(g["dqri_error"]).split(": ", 1)
+    with pytest.raises(ValueError, match=msg.split("(")[0].strip()):
+        quant_tensor(w.float().clone(), bits=4, group_size=32, scheme="asym", return_int=True, double_quant=True, double_quant_return_int=True)

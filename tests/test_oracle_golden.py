@@ -311,3 +311,22 @@ def test_smoothquant_non_default_cells_vs_reference():
     assert np.array_equal(O.sq_quant_w_asym(w).numpy(), g["qdq_w_asym"])
     x = torch.from_numpy(g["x"])
     assert np.array_equal(O.sq_quant_dequant_x(x, None, None).numpy(), g["qdq_x_dynamic"])
+
+
+@pytest.mark.parametrize("dtype", ["nf4", "fp4", "fp4_e2m1"])
+@pytest.mark.parametrize("wd", ["f32", "bf16"])
+def test_oracle_quantize_4bit_with_given_scale_vs_reference_golden(dtype, wd):
+    """quantize_4bit(tensor, scale=...) (utility.py:127-128) and the failure of double_quant_return_int (:383-405), restated in
+    oracle/ against the unmodified reference (tests/golden/make_golden_q4scale.py): bit-exact / the same exception."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "q4scale_golden.npz"))
+    td = torch.float32 if wd == "f32" else torch.bfloat16
+    tag = f"q4s_{dtype}_{wd}"
+    w = torch.from_numpy(g[f"{tag}_w"]).to(td)
+    sc = torch.from_numpy(g[f"{tag}_scale"]).to(td)
+    assert np.array_equal(O.quantize_4bit(w.clone(), dtype=dtype, scale=sc.clone()).float().numpy(), g[f"{tag}_qdq"])
+    ints, s2, zp = O.quantize_4bit(w.clone(), dtype=dtype, return_int=True, scale=sc.clone())
+    assert zp is None and torch.equal(s2, sc) and np.array_equal(ints.float().numpy(), g[f"{tag}_int"])
+    kind, msg = str(g["dqri_error"]).split(": ", 1)
+    assert kind == "ValueError"
+    with pytest.raises(ValueError, match=msg.split("(")[0].strip()):
+        O.quant_tensor(w.float(), bits=4, group_size=32, scheme="asym", return_int=True, double_quant=True, double_quant_return_int=True)

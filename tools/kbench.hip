@@ -827,6 +827,89 @@ static int run_hessian_multi_case(int64_t T) {
   return bad;
 }
 
+// ---- round 5: A/B of tile variants in the batched Hessian launch, timed there and back (kbench hpf) ----
+__global__ void fill_bf16_kernel(uint16_t* x, size_t n, uint32_t seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ (uint32_t)(i >> 32) * 40503u ^ seed;
+    float acc = 0.f;
+    for (int r = 0; r < 4; ++r) {  // sum of four uniforms: bell-shaped, every mantissa bit busy
+      h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+      acc += (float)(h & 0xffffff) * (1.f / 16777216.f) - 0.5f;
+    }
+    const uint32_t u = __float_as_uint(acc * 1.7f);
+    x[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+}
+__global__ void count_diff_kernel(const float* a, const float* b, size_t n, unsigned long long* out) {
+  unsigned long long c = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    c += __float_as_uint(a[i]) != __float_as_uint(b[i]);
+  if (c) atomicAdd(out, c);
+}
+static int run_hessian_pf_case(int64_t T, int passes) {
+  const int64_t Ks[4] = {4096, 4096, 4096, 11008};
+  std::vector<DevBuf<uint16_t>*> xs;
+  std::vector<DevBuf<float>*> Hs, Hr;
+  const void* xp[4];
+  float *hp[4], *hr[4];
+  int64_t ld[4];
+  float betas[4], alphas[4], b0[4] = {0.f, 0.f, 0.f, 0.f};
+  double flops = 0;
+  for (int i = 0; i < 4; ++i) {
+    xs.push_back(new DevBuf<uint16_t>((size_t)T * Ks[i]));
+    Hs.push_back(new DevBuf<float>((size_t)Ks[i] * Ks[i]));
+    Hr.push_back(new DevBuf<float>((size_t)Ks[i] * Ks[i]));
+    fill_bf16_kernel<<<2048, 256>>>(xs[i]->p, xs[i]->n, 0x9e3779b9u * (i + 1));
+    Hs[i]->zero(); Hr[i]->zero();
+    xp[i] = xs[i]->p; hp[i] = Hs[i]->p; hr[i] = Hr[i]->p; ld[i] = Ks[i]; betas[i] = 0.5f; alphas[i] = 0.5f;
+    flops += 2.0 * T * Ks[i] * Ks[i];
+  }
+  HIPCHECK(hipDeviceSynchronize());
+  printf("HESSIAN tile variants (harness flags), multi T=%ld K=4096+4096+4096+11008 (one launch)\n", (long)T);
+  DevBuf<char> hws((size_t)inc_gptq_hessian_accum_multi_workspace_bytes());
+  DevBuf<unsigned long long> dcount(1);
+  constexpr int NM = 4;
+  const int modes[NM] = {0, 58, 59, 58};  // product (one-block issue), the same without it, the round-4 form
+  int bad = 0;
+  inc_debug_set_small_tiles(0);
+  INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hr, b0, alphas, hws.p, (int64_t)hws.n, nullptr));
+  for (int mi = 1; mi < NM; ++mi) {
+    inc_debug_set_small_tiles(modes[mi]);
+    INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, b0, alphas, hws.p, (int64_t)hws.n, nullptr));
+    dcount.zero();
+    for (int i = 0; i < 4; ++i) count_diff_kernel<<<1024, 256>>>(hp[i], hr[i], Hs[i]->n, dcount.p);
+    HIPCHECK(hipDeviceSynchronize());
+    const unsigned long long nd = dcount.download()[0];
+    printf("  flag %d: %llu elements differ from the product launch  %s\n", modes[mi], nd, nd ? "FAIL" : "OK");
+    bad += nd ? 1 : 0;
+  }
+  Timer t;
+  std::vector<std::vector<float>> ms(NM);
+  for (int pass = 0; pass < passes; ++pass)
+    for (int k = 0; k < NM; ++k) {
+      const int mi = (pass & 1) ? NM - 1 - k : k;  // there and back: position in the sequence must not decide
+      inc_debug_set_small_tiles(modes[mi]);
+      INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, hws.p, (int64_t)hws.n, nullptr));
+      const int iters = 4;
+      t.start();
+      for (int i = 0; i < iters; ++i) INCCHECK(inc_gptq_hessian_accum_multi(4, xp, INC_BF16, T, Ks, ld, hp, betas, alphas, hws.p, (int64_t)hws.n, nullptr));
+      ms[mi].push_back(t.stop_ms() / iters);
+    }
+  inc_debug_set_small_tiles(0);
+  for (int mi = 0; mi < NM; ++mi) {
+    std::vector<float> v = ms[mi];
+    std::sort(v.begin(), v.end());
+    printf("  flag %3d  median %8.4f ms  min %8.4f  max %8.4f  %8.1f TFLOP/s (2*T*K^2, median) |", modes[mi], v[v.size() / 2], v.front(), v.back(),
+           flops / v[v.size() / 2] / 1e9);
+    for (float m : ms[mi]) printf(" %.3f", m);
+    printf("\n");
+  }
+  for (auto* b : xs) delete b;
+  for (auto* b : Hs) delete b;
+  for (auto* b : Hr) delete b;
+  return bad;
+}
+
 // ---- GPTQ column loop: quad-per-row quant block + lazy update generations (3rd = default, 2nd = flag 86, 1st = flag 1) --------
 static void colloop_inputs(int64_t N, int64_t K, int gs, std::vector<float>& hw, std::vector<float>& hh, std::vector<float>& hs, std::vector<float>& hz) {
   hw.resize((size_t)N * K); hh.assign((size_t)K * K, 0.f);
@@ -1228,6 +1311,10 @@ int main(int argc, char** argv) {
     fails += run_hessian_case(16384, 11008, true);
     fails += run_hessian_case(1000, 520, false);      // 40-token tail, feature chunks clamped at K
     fails += run_hessian_multi_case(16384);
+  }
+  if (what == "hpf") {
+    fails += run_hessian_pf_case(16384, 6);
+    fails += run_hessian_pf_case(65536, 6);
   }
   if (what == "qlayer" || what == "all") {
     fails += run_qlayer_case(300, 640, 64);
