@@ -376,6 +376,14 @@ class HessianAccumulator:
             perm = torch.argsort(torch.diagonal(H), descending=True)
             H = H[perm][:, perm].contiguous()
         Hinv, self._info = inverse_cholesky_upper(H, check=False)
+        # the status word goes to pinned host memory behind the factorisation, on the stream that produced it: `check` then waits for
+        # THIS event only.  (`info.item()` is a copy on the caller's stream plus a synchronisation of it -- in the block loop that
+        # stream already holds the whole second forward, and the chip ran dry after every block: ~1.5 ms per step.)
+        self._info_host, self._info_event = None, None
+        if self._info.is_cuda:
+            self._info_host = torch.empty(1, dtype=self._info.dtype, pin_memory=True)
+            self._info_host.copy_(self._info, non_blocking=True)
+            self._info_event = torch.cuda.current_stream(self._info.device).record_event()
         self.H = None
         self.finalized = (key, Hinv, dead, perm)
         return Hinv, dead, perm
@@ -402,6 +410,9 @@ class HessianAccumulator:
         """Raise if the (deferred) factorisation met a non-positive pivot; one host synchronisation."""
         if self._info is not None:
             info, self._info = self._info, None
+            if getattr(self, "_info_event", None) is not None:  # (a factor received from another rank has no event: read it back)
+                self._info_event.synchronize()
+                info, self._info_host, self._info_event = self._info_host, None, None
             try:
                 raise_if_not_spd(info)
             except torch.linalg.LinAlgError as e:
