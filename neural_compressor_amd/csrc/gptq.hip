@@ -893,6 +893,9 @@ __global__ __launch_bounds__(64 * WPW) void gptq_quant_block_q4_kernel(
     float* __restrict__ err, int64_t N, int64_t K, int64_t G, int64_t i1, int64_t g0, float maxq, int sym_flag) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* hs = reinterpret_cast<float*>(smem_raw);  // [QB][QB] Hinv1 tile, later reused as the waves' output stages
+  // The chain is the serial path of the column loop and, at 121 registers, shares its SIMDs with the trailing update's MFMA waves
+  // (248 registers): it goes first whenever it has an instruction ready, the update fills the rest of the issue slots.
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, r = lane >> 2, q = lane & 3;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t n0 = ((int64_t)blockIdx.x * WPW + wave) * Q4R;
@@ -991,6 +994,10 @@ __global__ __launch_bounds__(64 * WPW) void gptq_quant_block_q4_kernel(
     wr[ci] = own ? qv : wr[ci];
     ev[ci] = own ? e : ev[ci];
     cw[ci >> 2] = own ? (cw[ci >> 2] | ((uint32_t)t << (8 * (ci & 3)))) : cw[ci >> 2];
+    // Pinned HERE: left alone, the compiler sinks these three selects to the end of the chain -- nothing reads them before the output
+    // stage -- and keeps t, e and qv of all 128 steps alive: 306 registers (50 of them AGPRs used as spill space) instead of 121,
+    // i.e. one wave per SIMD, and no lazy-update workgroup (248 registers) beside a chain workgroup on the same CU.
+    asm volatile("" : "+v"(wr[ci]), "+v"(ev[ci]), "+v"(cw[ci >> 2]));
   };
   fetch_row(std::integral_constant<int, 0>{}, ha);
   static_for<0, QB / 2>([&](auto pc) {
@@ -1121,6 +1128,9 @@ __global__ __launch_bounds__(256, 2) void gptq_lazy_update_v3_kernel(float* __re
   // REUSES the first 64 KiB: wave w's share of it (k rows 32w .. 32w + 31) lands exactly on wave w's own Err1 slice, which that
   // wave has finished reading by then -- no workgroup barrier in between.
   constexpr uint32_t HS_OFF = CW == 128 ? 0u : 65536u;
+  // (the quarter tiles serve the "next 128 columns" update, which the next chain waits for: ahead of the rest of the trailing update,
+  // behind the chain itself)
+  if constexpr (CW != 128) __builtin_amdgcn_s_setprio(2);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
   const int tid = threadIdx.x, lane = tid & 63;

@@ -57,6 +57,18 @@ for line in open("gpurun_out/bench_ab.log"):
         print(sys.argv[1], "=", sys.argv[2], "ms/step", d["ms_per_step"], {k.replace("quantize_layer_", "ql_").replace("hessian_multi_", "h_"): v["avg_ms"] for k, v in d["kernel_breakdown"].items()}, d.get("allocator"))
 PY
       done ;;
+    final)
+      # the round's evidence set: the bench line the driver will see, rocprofv3 kernel stats of the reduced bench, the PMC traffic pass,
+      # the tile A/B of the harness and the lab candidates
+      timeout 900 python bench.py > gpurun_out/c_bench.log 2> gpurun_out/c_bench.err; echo "bench exit $?"
+      rm -rf "$R/gpurun_out/prof"
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r5 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extra-configs --no-per-layer > "$R/gpurun_out/prof_bench.log" 2> "$R/gpurun_out/prof_bench.err" )
+      echo "prof exit $?"; f=$(find gpurun_out/prof -name "*kernel_stats*" | head -1); cp "$f" gpurun_out/d_bench_kernel_stats.csv; head -5 gpurun_out/d_bench_kernel_stats.csv | cut -c1-200
+      find gpurun_out/prof -name "*.csv" -size +20M -delete
+      bash scripts/gpu_pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1; tail -12 gpurun_out/pmc_bench.log
+      find gpurun_out/pmc_bench -name "*.csv" -size +20M -delete
+      timeout 300 tools/kbench hpf > gpurun_out/kbench_hpf_final.log 2>&1; tail -14 gpurun_out/kbench_hpf_final.log
+      ( tools/hess_lab 16384 11008 0; tools/hess_lab 16384 4096 0 ) > gpurun_out/hess_lab_32x32.log 2>&1; cat gpurun_out/hess_lab_32x32.log ;;
     chol)
       timeout 300 python scripts/chol_time.py > gpurun_out/chol_time.log 2>&1; tail -12 gpurun_out/chol_time.log ;;
     choltrace)
