@@ -276,41 +276,54 @@ __global__ __launch_bounds__(256) void woq_dequant_kernel(
       int64_t gprev = -1;
       float s = 0.f;
       int32_t z = 0;
-      OT vals[NP];
       // without g_idx a packed word lies inside ONE group whenever group_size % NP == 0: one division per word instead of a 64-bit
       // division per element (eight per word: they were most of this kernel's time); other group sizes keep the per-element form
       const bool word_in_group = (group_size % NP) == 0;
       const int64_t gword = (kw * NP) / group_size;
-#pragma unroll
-      for (int e = 0; e < NP; ++e) {
-        const int64_t k = kw * NP + e;
-        vals[e] = enc<DT>(0.f);
-        if (k < K) {
-          const int64_t g = g_idx ? (int64_t)g_idx[k] : (word_in_group ? gword : k / group_size);
-          if (g != gprev) {
-            s = f16_bits_to_f32(scales[g * N + n]);
-            uint32_t zz = ((qzeros[g * NW + n / NP] >> zsh) & MASK) + 1u;
-            z = (zz > MASK) ? 0 : (int32_t)zz;
-            gprev = g;
-          }
-          const int32_t q = (int32_t)((word >> (BITS * e)) & MASK);
-          const float v = (float)(int8_t)(q - z) * s;  // exact in fp32, one rounding below
-          vals[e] = enc<DT>(v);
-        }
-      }
-      // the word's NP elements leave as 16-byte LDS writes (2-byte writes made this phase LDS-instruction-bound); rows are 16-byte
-      // aligned: LD * sizeof(OT) is a multiple of 16 and kwl * NP * sizeof(OT) too
+      // The word's NP elements are decoded CH at a time (CH = 8 for 1 / 2 / 4 / 8-bit words, the whole word for the odd widths) and leave
+      // as 16-byte LDS writes (2-byte writes made this phase LDS-instruction-bound); rows are 16-byte aligned: LD * sizeof(OT) is a
+      // multiple of 16 and kwl * NP * sizeof(OT) too.  (A 1-bit word decoded as ONE unrolled run of 32 elements with fp32 output needed
+      // 500 registers and 1.8 KiB of scratch: the chunks of a 32-element word are a loop, not an unroll.)
+      constexpr int CH = (NP > 8 && NP % 8 == 0) ? 8 : NP;
       constexpr int PER16 = 16 / (int)sizeof(OT);
-      if constexpr (NP % PER16 == 0) {
+      auto chunk = [&](int e0) {
+        OT vals[CH];
 #pragma unroll
-        for (int q4 = 0; q4 < NP / PER16; ++q4) {
-          uint4 pk;
-          __builtin_memcpy(&pk, &vals[q4 * PER16], 16);
-          *reinterpret_cast<uint4*>(&tile[lane * LD + kwl * NP + q4 * PER16]) = pk;
+        for (int ee = 0; ee < CH; ++ee) {
+          const int e = e0 + ee;
+          const int64_t k = kw * NP + e;
+          vals[ee] = enc<DT>(0.f);
+          if (k < K) {
+            const int64_t g = g_idx ? (int64_t)g_idx[k] : (word_in_group ? gword : k / group_size);
+            if (g != gprev) {
+              s = f16_bits_to_f32(scales[g * N + n]);
+              uint32_t zz = ((qzeros[g * NW + n / NP] >> zsh) & MASK) + 1u;
+              z = (zz > MASK) ? 0 : (int32_t)zz;
+              gprev = g;
+            }
+            const int32_t q = (int32_t)((word >> (BITS * e)) & MASK);
+            const float v = (float)(int8_t)(q - z) * s;  // exact in fp32, one rounding below
+            vals[ee] = enc<DT>(v);
+          }
         }
+        if constexpr (CH % PER16 == 0) {
+#pragma unroll
+          for (int q4 = 0; q4 < CH / PER16; ++q4) {
+            uint4 pk;
+            __builtin_memcpy(&pk, &vals[q4 * PER16], 16);
+            *reinterpret_cast<uint4*>(&tile[lane * LD + kwl * NP + e0 + q4 * PER16]) = pk;
+          }
+        } else {
+#pragma unroll
+          for (int ee = 0; ee < CH; ++ee) tile[lane * LD + kwl * NP + e0 + ee] = vals[ee];
+        }
+      };
+      if constexpr (NP / CH > 2) {
+#pragma unroll 1
+        for (int e0 = 0; e0 < NP; e0 += CH) chunk(e0);
       } else {
 #pragma unroll
-        for (int e = 0; e < NP; ++e) tile[lane * LD + kwl * NP + e] = vals[e];
+        for (int e0 = 0; e0 < NP; e0 += CH) chunk(e0);
       }
     }
   }
