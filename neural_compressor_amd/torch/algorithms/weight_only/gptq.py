@@ -205,6 +205,18 @@ def raise_if_not_spd(info):
             f"inverse_cholesky_upper: the matrix is not positive definite (pivot <= 0 in diagonal block {bad})")
 
 
+def hybrid_order_perm(diag_H, groupsize):
+    """The reference's hybrid order (Quantizer.compute_local_perms / compute_global_perm / compose_final_perm, gptq.py:1389-1461) as
+    three tensor ops on the device: inside every group the columns in descending order of diag(H), the groups in descending order
+    of their largest diag(H).  A column never leaves its group, so the packed module needs no g_idx."""
+    K = diag_H.numel()
+    G = K // groupsize
+    d = diag_H[: G * groupsize].reshape(G, groupsize)
+    local = torch.argsort(d, dim=1, descending=True)
+    glob = torch.argsort(d.max(dim=1).values, descending=True)
+    return (local[glob] + (glob * groupsize).unsqueeze(1)).reshape(-1)
+
+
 # ---------------------------------------------------------------------------------------------------
 # per-layer solver
 # ---------------------------------------------------------------------------------------------------
@@ -348,10 +360,11 @@ class HessianAccumulator:
         for acc, _ in todo:
             acc._committed()
 
-    def inverse_factor(self, percdamp, act_order):
+    def inverse_factor(self, percdamp, act_order, hybrid_groupsize=0):
         """Upper Cholesky factor of (H + damp I)^-1 (gptq.py:1186-1231); consumes H.  Cached so that layers
-        sharing the accumulator factorise once."""
-        key = (float(percdamp), bool(act_order))
+        sharing the accumulator factorise once.  `hybrid_groupsize` > 0: H is first rearranged by the reference's hybrid order
+        (gptq.py:1203-1209) and the third return value is that permutation."""
+        key = (float(percdamp), bool(act_order), int(hybrid_groupsize))
         if self.finalized is not None and self.finalized[0] == key:
             if self._handles:  # the factor is arriving from its owner rank: order this stream behind the transfers
                 for h in self._handles:
@@ -370,10 +383,18 @@ class HessianAccumulator:
             H = torch.zeros((self.columns, self.columns), dtype=torch.float32, device=self.device)
         elif H.is_cuda:
             H.record_stream(torch.cuda.current_stream(H.device))  # accumulated on the main stream, consumed (and dropped) on this one
+        hybrid_diag = None
+        if hybrid_groupsize:
+            # diag(H) as the reference sees it at gptq.py:1205 -- after the dead-column fix (H[dead, dead] = 1), before the damping
+            hybrid_diag = torch.diagonal(H).clone()
+            hybrid_diag[hybrid_diag == 0] = 1
         dead = ops.gptq_hessian_finalize(H, percdamp)
         perm = None
         if act_order:
             perm = torch.argsort(torch.diagonal(H), descending=True)
+            H = H[perm][:, perm].contiguous()
+        elif hybrid_groupsize:
+            perm = hybrid_order_perm(hybrid_diag, int(hybrid_groupsize))
             H = H[perm][:, perm].contiguous()
         Hinv, self._info = inverse_cholesky_upper(H, check=False)
         # the status word goes to pinned host memory behind the factorisation, on the stream that produced it: `check` then waits for
@@ -388,7 +409,7 @@ class HessianAccumulator:
         self.finalized = (key, Hinv, dead, perm)
         return Hinv, dead, perm
 
-    def prefactor(self, stream, percdamp, act_order):
+    def prefactor(self, stream, percdamp, act_order, hybrid_groupsize=0):
         """Run the factorisation on `stream` (a side stream): the independent Hessians of a block are factorised
         concurrently -- each is a chain of one-workgroup diagonal-block kernels and fp32 GEMMs that leaves most of the chip
         idle on its own -- instead of one after another.  The consumer (`inverse_factor` on the solve's stream) waits on
@@ -400,7 +421,7 @@ class HessianAccumulator:
         with torch.cuda.stream(stream):
             if H is not None:
                 H.record_stream(stream)  # allocated on `main`, read (and dropped) under `stream`
-            out = self.inverse_factor(percdamp, act_order)
+            out = self.inverse_factor(percdamp, act_order, hybrid_groupsize)
             for t in out:
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)  # allocated under `stream`, consumed by the column loop on `main`
@@ -435,19 +456,19 @@ class HessianAccumulator:
             self.H = None
         self._n = int(n_total)
 
-    def exchange_factor(self, ctx, owner, percdamp, act_order):
+    def exchange_factor(self, ctx, owner, percdamp, act_order, hybrid_groupsize=0):
         """The owner factorises; every other rank receives (Hinv, dead, perm) by broadcast (asynchronously under RCCL:
         `inverse_factor` waits on the handles when a solve first needs the factor)."""
         if ctx.rank == owner:
-            Hinv, dead, perm = self.inverse_factor(percdamp, act_order)
+            Hinv, dead, perm = self.inverse_factor(percdamp, act_order, hybrid_groupsize)
         else:
             self.flush()
             self._stage, self.H = None, None
             K = self.columns
             Hinv = torch.empty((K, K), dtype=torch.float32, device=self.device)
             dead = torch.empty(K, dtype=torch.uint8, device=self.device)
-            perm = torch.empty(K, dtype=torch.int64, device=self.device) if act_order else None
-            self.finalized = ((float(percdamp), bool(act_order)), Hinv, dead, perm)
+            perm = torch.empty(K, dtype=torch.int64, device=self.device) if (act_order or hybrid_groupsize) else None
+            self.finalized = ((float(percdamp), bool(act_order), int(hybrid_groupsize)), Hinv, dead, perm)
             self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
         # the "not positive definite" status word travels with the factor: every rank raises together in check() instead of the
         # owner alone (the others would walk into the next collective and hang)
@@ -513,8 +534,13 @@ class GPTQ:
                     fp8_aware=False, static_groups=False):
         """Returns (scale [N,G] fp32, scale_bf16_to_fp8, zero [N,G] fp32, Q [weight shape, weight dtype]);
         the integer codes (uint8 [N,K], original column order) are left in `self.codes`."""
-        if hybrid_order or fp8_aware:
-            raise NotImplementedError("hybrid_order / fp8_aware are Gaudi W4A8 options outside the MI355X scope")
+        if fp8_aware:
+            raise NotImplementedError("fp8_aware (INT4 weights pre-scaled for Gaudi's fp8 matrix units) is a Gaudi W4A8 option outside the MI355X scope")
+        if hybrid_order:
+            assert not act_order, "Error: hybrid_act_order is not allowed with act_order"  # (gptq.py:1204)
+            if static_groups:
+                raise NotImplementedError("hybrid_order with static_groups: the reference looks the groups' parameters up by PERMUTED "
+                                          "position there (gptq.py:1273-1277 take idx from act_order's perm only)")
         bits = int(self.cfg.get("bits", 4))
         sym = bool(self.cfg.get("sym", False))
         mse = bool(self.cfg.get("mse", False))  # GPTQConfig(use_mse_search=True): shrink-grid search in find_params
@@ -536,8 +562,11 @@ class GPTQ:
             W = W[r0:r1].contiguous()
         N = W.shape[0]
 
-        Hinv, dead, perm = self.acc.inverse_factor(percdamp, act_order)
         gs = K if (groupsize == -1 or groupsize >= K) else int(groupsize)
+        if hybrid_order and (groupsize == -1 or K % gs != 0):
+            raise ValueError("hybrid_order needs a group size that divides the number of columns (the reference's permutation covers "
+                             "columns // groupsize whole groups, gptq.py:1403-1461)")
+        Hinv, dead, perm = self.acc.inverse_factor(percdamp, act_order, gs if hybrid_order else 0)
         G = math.ceil(K / gs)
         scale = torch.empty((N, G), dtype=torch.float32, device=W.device)
         zero = torch.empty((N, G), dtype=torch.float32, device=W.device)
@@ -563,6 +592,8 @@ class GPTQ:
                 col_group = torch.div(perm, gs, rounding_mode="floor")
                 loop_scale = scale[:, col_group].contiguous()
                 loop_zero = zero[:, col_group].contiguous()
+        elif hybrid_order and N > 0:
+            w32 = w32[:, perm].contiguous()  # whole groups, rearranged inside: the loop's dynamic groups are the reference's
 
         codes = torch.empty((N, K), dtype=torch.uint8, device=W.device)
         Q = torch.empty((N, K), dtype=weight_dtype, device=W.device)
@@ -584,6 +615,14 @@ class GPTQ:
             invperm = torch.argsort(perm)
             Q = Q[:, invperm].contiguous()
             codes = codes[:, invperm].contiguous()
+        elif hybrid_order:
+            # gptq.py:1320-1328: the columns back in place, the groups' parameters back in the groups' original order
+            invperm = torch.argsort(perm)
+            Q = Q[:, invperm].contiguous()
+            codes = codes[:, invperm].contiguous()
+            inv_global = torch.argsort(torch.div(perm.reshape(G, gs)[:, 0], gs, rounding_mode="floor"))
+            scale = scale[:, inv_global].contiguous()
+            zero = zero[:, inv_global].contiguous()
         self.codes = codes
         # with static groups the parameters belong to contiguous ORIGINAL-order groups: the packed module needs no g_idx.
         # (The reference returns only the last group's scale in this mode (:1341-1345) and its export then indexes past
@@ -964,15 +1003,15 @@ class RAWGPTQuantizer(object):
         before broadcasting it and has already posted the receives of the cheaper ones ahead of it."""
         ctx = self.dist_ctx
         if self.hessian_allreduce:
-            for acc, _, _ in distinct:
+            for acc, _, _, _ in distinct:
                 acc.flush()
-            counts = torch.tensor([float(acc._n) for acc, _, _ in distinct], dtype=torch.float64,
+            counts = torch.tensor([float(acc._n) for acc, _, _, _ in distinct], dtype=torch.float64,
                                   device="cpu" if ctx.backend == "gloo" else self.device)
             counts = ctx.all_reduce(counts).tolist()  # a handful of scalars
-            for i, (acc, _, _) in enumerate(distinct):
+            for i, (acc, _, _, _) in enumerate(distinct):
                 acc.reduce_to_owner(ctx, ctx.owner(i), int(round(counts[i])))
-        for i, (acc, percdamp, act_order) in enumerate(distinct):
-            acc.exchange_factor(ctx, ctx.owner(i), percdamp, act_order)
+        for i, (acc, percdamp, act_order, hyb) in enumerate(distinct):
+            acc.exchange_factor(ctx, ctx.owner(i), percdamp, act_order, hyb)
 
     # -- the main loop (reference :568-887) ----------------------------------------------------------------
     @torch.no_grad()
@@ -1434,11 +1473,18 @@ class RAWGPTQuantizer(object):
                 acc.defer = False
             for h in handles:
                 h.remove()
+            def hybrid_gs(sv):  # group size of a hybrid-order solve (it shapes the factor: gptq.py:1203-1209), else 0
+                if not sv.cfg.get("hybrid_order", False):
+                    return 0
+                gs_ = sv.cfg.get("group_size", -1)
+                return sv.columns if (gs_ == -1 or gs_ >= sv.columns) else int(gs_)
+
             for name, owner in alias.items():
                 if (
                     solvers[name].columns == solvers[owner].columns
                     and solvers[name].cfg["percdamp"] == solvers[owner].cfg["percdamp"]
                     and solvers[name].cfg["act_order"] == solvers[owner].cfg["act_order"]
+                    and hybrid_gs(solvers[name]) == hybrid_gs(solvers[owner])
                 ):
                     solvers[name].acc = solvers[owner].acc
                 else:  # pragma: no cover - different damping per layer: cannot share the factorisation
@@ -1448,14 +1494,14 @@ class RAWGPTQuantizer(object):
                 acc = solvers[name].acc
                 if id(acc) not in seen:
                     seen.add(id(acc))
-                    distinct.append((acc, solvers[name].cfg["percdamp"], solvers[name].cfg["act_order"]))
+                    distinct.append((acc, solvers[name].cfg["percdamp"], solvers[name].cfg["act_order"], hybrid_gs(solvers[name])))
             if self.dist_ctx is not None:
                 self._exchange_factors(distinct)
                 for sv in solvers.values():
                     sv.row_ctx = self.dist_ctx
             elif self.hessian_allreduce:
                 group = None if self.hessian_allreduce is True else self.hessian_allreduce
-                for acc, _, _ in distinct:  # one all-reduce per DISTINCT accumulator
+                for acc, _, _, _ in distinct:  # one all-reduce per DISTINCT accumulator
                     acc.allreduce(group)
             if self.dist_ctx is None and len(distinct) > 1 and self.factor_streams > 1:
                 # the independent factorisations of the block run concurrently, the largest first (it is the critical path)
@@ -1464,8 +1510,8 @@ class RAWGPTQuantizer(object):
                     self._fstreams = [torch.cuda.Stream(device=self.device) for _ in range(self.factor_streams)]
                 order = sorted(range(len(distinct)), key=lambda i: -distinct[i][0].columns)
                 for slot, i in enumerate(order):
-                    acc, percdamp, act_order = distinct[i]
-                    acc.prefactor(self._fstreams[slot % len(self._fstreams)], percdamp, act_order)
+                    acc, percdamp, act_order, hyb = distinct[i]
+                    acc.prefactor(self._fstreams[slot % len(self._fstreams)], percdamp, act_order, hyb)
             # Step 2.4: solve (reference :690-747).  The column loop treats every weight ROW independently, so Linears
             # that share one Hessian (q/k/v, gate/up) and one GPTQ setting are stacked along N and solved in ONE pass:
             # a third of the serial 128-column steps and three times the rows in flight per step, same results.
@@ -1545,7 +1591,7 @@ class RAWGPTQuantizer(object):
                         solve(names)
 
             def finish_solves():
-                for acc, _, _ in distinct:
+                for acc, _, _, _ in distinct:
                     acc.check()  # deferred "not positive definite" checks of this group's factorisations (one sync each)
                 for n in list(solvers):
                     solvers[n].free()

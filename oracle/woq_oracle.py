@@ -368,8 +368,27 @@ def gptq_hinv(H, percdamp=0.01):
     return H, dead
 
 
+def gptq_hybrid_perms(diag_H, groupsize):
+    """Quantizer.compute_local_perms / compute_global_perm / compose_final_perm (gptq.py:1389-1461): inside every group the columns
+    in descending order of diag(H), the groups in descending order of their largest diag(H).  Returns (final_perm [K], global_perm [G])."""
+    n = diag_H.numel()
+    num_groups = n // groupsize
+    local_perms, metric = [], []
+    for g in range(num_groups):
+        sub = diag_H[g * groupsize : (g + 1) * groupsize]
+        local_perms.append(torch.argsort(sub, descending=True))
+        metric.append(sub.max().item())
+    global_perm = torch.argsort(torch.tensor(metric), descending=True)
+    final = []
+    for new_group in range(num_groups):
+        orig = global_perm[new_group].item()
+        for idx in local_perms[orig]:
+            final.append(idx.item() + orig * groupsize)
+    return torch.tensor(final, dtype=torch.long), global_perm
+
+
 def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, groupsize=-1, act_order=False,
-                     static_groups=False, Hinv=None, mse=False, trace=False):
+                     static_groups=False, Hinv=None, mse=False, trace=False, hybrid_order=False):
     """GPTQ.fasterquant (gptq.py:1143-1351) for int dtype.  Returns dict(scale [N,G], zero [N,G], Q fp32 [N,K], perm).
 
     `Hinv` (optional) injects a precomputed factor so the column loop can be tested in isolation.
@@ -395,6 +414,12 @@ def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, grou
             q.find_params(W[:, i : i + groupsize])
             groups.append(q)
     perm = None
+    final_perm = global_perm = None
+    if hybrid_order:  # gptq.py:1203-1209: columns rearranged by diag(H) WITHOUT mixing groups
+        assert not act_order, "Error: hybrid_act_order is not allowed with act_order"
+        final_perm, global_perm = gptq_hybrid_perms(torch.diag(H), groupsize)
+        W = W[:, final_perm]
+        H = H[final_perm][:, final_perm]
     if act_order:
         perm = torch.argsort(torch.diag(H), descending=True)
         W = W[:, perm]
@@ -439,6 +464,14 @@ def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, grou
             Err1[:, i] = err1
         Q[:, i1:i2] = Q1
         W[:, i2:] -= Err1.matmul(Hinv[i1:i2, i2:])
+    if hybrid_order:  # gptq.py:1320-1328: columns back in place, the groups' parameters back in the groups' original order
+        inv_final = torch.empty_like(final_perm)
+        inv_final[final_perm] = torch.arange(final_perm.numel())
+        Q = Q[:, inv_final]
+        inv_global = torch.empty_like(global_perm)
+        inv_global[global_perm] = torch.arange(global_perm.numel())
+        scale = [scale[i] for i in inv_global.tolist()]
+        zero = [zero[i] for i in inv_global.tolist()]
     if act_order:
         Q = Q[:, torch.argsort(perm)]
     # NB with static_groups the reference never appends to `scale` (gptq.py:1273-1277), so it returns only the
@@ -446,7 +479,7 @@ def gptq_fasterquant(W, H, bits=4, sym=False, blocksize=128, percdamp=0.01, grou
     if scale == []:
         scale.append(quantizer.scale)
         zero.append(quantizer.zero)
-    out = dict(scale=torch.cat(scale, dim=1), zero=torch.cat(zero, dim=1), Q=Q, perm=perm)
+    out = dict(scale=torch.cat(scale, dim=1), zero=torch.cat(zero, dim=1), Q=Q, perm=perm, final_perm=final_perm)
     if trace:
         out["Win"] = Win
     return out

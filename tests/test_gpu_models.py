@@ -1139,3 +1139,34 @@ def test_gptq_layer_per_gpu_three_rounds_with_exchange_lookahead(lookahead, monk
             continue
         for a, b, c in zip(res[0][n], res[1][n], single[n]):
             assert _same(a, c) and _same(b, c), n
+
+
+def test_gptq_hybrid_order_tiny_llama_vs_reference():
+    """GPTQConfig(hybrid_order=True) through prepare / convert (the block driver: shared Hessians of q/k/v and gate/up factorised once
+    WITH the hybrid permutation, prefactor streams, stacked solves) against the unmodified reference's CPU outputs
+    (tests/golden/make_golden_hybrid.py): 14 packed modules without g_idx, block 0's words near-identical, logits close."""
+    from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gptq_tiny_llama_hybrid.npz"))
+    ids = calib_ids()
+    model = prepare(tiny_llama(), GPTQConfig(bits=4, group_size=32, use_sym=True, block_size=128, hybrid_order=True))
+    for x in ids:
+        model(x)
+    q = convert(model)
+    mods = _woq_modules(q)
+    assert len(mods) == int(g["n_modules"]) == 14
+    assert all(m.g_idx is None for m in mods.values())
+    first = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items() if ".layers.0." in n)
+    worst = min(_nibble_match(m.qweight.cpu().numpy(), g[f"{n}.qweight"]) for n, m in mods.items())
+    rep = _parity_report("gptq_tiny_llama_hybrid", mods, g)
+    assert first >= 0.97 and worst >= 0.88, (first, worst, rep)
+    with torch.no_grad():
+        y = q(ids[0].to("cuda")).logits.float().cpu()
+    ref = torch.from_numpy(g["logits"])
+    rel = float((y - ref).norm() / ref.norm())
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "parity_report.txt"), "a") as f:
+            f.write(f"gptq_tiny_llama_hybrid: logits rel-Frobenius vs the reference's CPU model {rel:.3e}\n")
+    except OSError:
+        pass
+    assert rel <= 6e-2, rel

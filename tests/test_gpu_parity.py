@@ -9,6 +9,8 @@ Bars (BASELINE.json north_star / SURVEY.md 8(c)):
   * fused GEMM vs F.linear on the same bf16-rounded weights in fp32: rel-Frobenius <= 1e-3 (tolerance from north_star)
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -940,3 +942,53 @@ def test_prepared_forward_call_follows_the_module(hip):
     y_g = m(xh)
     ref = torch.nn.functional.linear(xh, m.recover(dtype=torch.float16))
     assert (y_g.float() - ref.float()).norm() <= 2e-3 * ref.float().norm()
+
+
+HYB_CASES = {
+    "hyb_sym_g32": dict(bits=4, sym=True, blocksize=128, groupsize=32),
+    "hyb_asym_g32": dict(bits=4, sym=False, blocksize=128, groupsize=32),
+    "hyb_sym_g64_2blk": dict(bits=4, sym=True, blocksize=128, groupsize=64),
+    "hyb_sym_g32_mse": dict(bits=4, sym=True, blocksize=128, groupsize=32, mse=True),
+}
+
+
+@pytest.mark.parametrize("tag", list(HYB_CASES))
+def test_gptq_layer_hybrid_order(hip, tag):
+    """GPTQ.fasterquant(hybrid_order=True) (reference gptq.py:1203-1209, 1320-1328, 1389-1461) on the MI355X against fixtures written by
+    the unmodified reference: the permutation itself (from diag(H) before damping, like the reference), codes, scales in the groups'
+    ORIGINAL order, and a packed module WITHOUT g_idx that dequantises to the reference's Q."""
+    from neural_compressor_amd.torch.algorithms.weight_only.gptq import GPTQ, hybrid_order_perm
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gptq_hybrid_golden.npz"))
+    kw = HYB_CASES[tag]
+    W = torch.from_numpy(g[f"{tag}_W"])
+    X = torch.from_numpy(g[f"{tag}_X"])
+    N, K = W.shape
+    # the permutation: three tensor ops on the device == the reference's Python loops (restated in the oracle)
+    Href = torch.from_numpy(g[f"{tag}_H"])
+    want_perm, _ = O.gptq_hybrid_perms(torch.diag(Href), kw["groupsize"])
+    assert torch.equal(hybrid_order_perm(torch.diag(Href).to(hip), kw["groupsize"]).cpu(), want_perm)
+    layer = torch.nn.Linear(K, N, bias=False).to(hip)
+    layer.weight.data.copy_(W)
+    gq = GPTQ(layer, device=hip)
+    gq.configure(dict(bits=kw["bits"], sym=kw["sym"], dtype="int", mse=kw.get("mse", False)))
+    for j in range(X.shape[0]):
+        gq.add_batch(X[j : j + 1].to(hip))
+    scale, _, zero, Q = gq.fasterquant(layer.weight.data, blocksize=kw["blocksize"], percdamp=0.01, groupsize=kw["groupsize"], hybrid_order=True)
+    assert gq.export_perm is None  # a column never leaves its group: no g_idx
+    ref_ints = g[f"{tag}_ints"].astype(np.int32) + (2 ** (kw["bits"] - 1) if kw["sym"] else 0)
+    match = float((gq.codes.cpu().numpy().astype(np.int32) == ref_ints).mean())
+    assert match >= (0.97 if kw.get("mse") else 0.99), f"only {match:.4f} of the codes match the reference"
+    assert rel_fro(scale.cpu(), torch.from_numpy(g[f"{tag}_scale"])) <= (1e-2 if kw.get("mse") else 1e-3)
+    if not kw["sym"]:
+        assert float((zero.cpu() != torch.from_numpy(g[f"{tag}_zero"])).float().mean()) <= 0.01
+    assert rel_fro(Q.cpu(), torch.from_numpy(g[f"{tag}_Q"])) <= 3e-2
+    m = MI355XWeightOnlyLinear(K, N, bits=kw["bits"], group_size=kw["groupsize"], zp=not kw["sym"], g_idx=False, device=hip)
+    m.pack_codes(gq.codes, scale, None if kw["sym"] else zero, None, g_idx=None)
+    assert rel_fro(m.recover().float().cpu(), Q.float().cpu()) <= 2e-3  # (the module stores fp16 scales)
+    with pytest.raises(AssertionError, match="hybrid_act_order"):
+        gq2 = GPTQ(layer, device=hip)
+        gq2.configure(dict(bits=4, sym=True, dtype="int", mse=False))
+        gq2.add_batch(X[:1].to(hip))
+        gq2.fasterquant(layer.weight.data, groupsize=kw["groupsize"], act_order=True, hybrid_order=True)

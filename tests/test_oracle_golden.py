@@ -330,3 +330,33 @@ def test_oracle_quantize_4bit_with_given_scale_vs_reference_golden(dtype, wd):
     assert kind == "ValueError"
     with pytest.raises(ValueError, match=msg.split("(")[0].strip()):
         O.quant_tensor(w.float(), bits=4, group_size=32, scheme="asym", return_int=True, double_quant=True, double_quant_return_int=True)
+
+
+HYB_CASES = {
+    "hyb_sym_g32": dict(bits=4, sym=True, blocksize=128, groupsize=32),
+    "hyb_asym_g32": dict(bits=4, sym=False, blocksize=128, groupsize=32),
+    "hyb_sym_g64_2blk": dict(bits=4, sym=True, blocksize=128, groupsize=64),
+    "hyb_sym_g32_mse": dict(bits=4, sym=True, blocksize=128, groupsize=32, mse=True),
+}
+
+
+@pytest.mark.parametrize("tag", list(HYB_CASES))
+def test_gptq_layer_hybrid_order(tag):
+    """GPTQ.fasterquant(hybrid_order=True) (gptq.py:1203-1209, 1320-1328: columns rearranged by diag(H) inside their groups, groups by
+    their largest diag(H); parameters returned in the groups' ORIGINAL order, so the export needs no g_idx) restated in oracle/ against
+    the unmodified reference (tests/golden/make_golden_hybrid.py): bit-exact."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gptq_hybrid_golden.npz"))
+    kw = HYB_CASES[tag]
+    W = torch.from_numpy(g[f"{tag}_W"])
+    X = torch.from_numpy(g[f"{tag}_X"])
+    H, n = torch.zeros(W.shape[1], W.shape[1]), 0
+    for j in range(X.shape[0]):
+        H, n = O.gptq_add_batch(H, n, X[j : j + 1])
+    assert np.array_equal(H.numpy(), g[f"{tag}_H"])
+    r = O.gptq_fasterquant(W, H, hybrid_order=True, **kw)
+    assert not torch.equal(r["final_perm"], torch.arange(W.shape[1]))  # (the fixture's permutation is not the identity)
+    assert np.array_equal(r["scale"].numpy(), g[f"{tag}_scale"])
+    assert np.array_equal(r["zero"].numpy(), g[f"{tag}_zero"])
+    assert np.array_equal(r["Q"].numpy(), g[f"{tag}_Q"])
+    ints = O.gptq_export_ints(r["Q"], r["scale"], r["zero"], kw["sym"], kw["groupsize"], None)
+    assert np.array_equal(ints.numpy(), g[f"{tag}_ints"].astype(np.int32))
