@@ -364,7 +364,7 @@ class HessianAccumulator:
         """Upper Cholesky factor of (H + damp I)^-1 (gptq.py:1186-1231); consumes H.  Cached so that layers
         sharing the accumulator factorise once.  `hybrid_groupsize` > 0: H is first rearranged by the reference's hybrid order
         (gptq.py:1203-1209) and the third return value is that permutation."""
-        key = (float(percdamp), bool(act_order), int(hybrid_groupsize))
+        key = (float(percdamp), bool(act_order)) + ((int(hybrid_groupsize),) if hybrid_groupsize else ())
         if self.finalized is not None and self.finalized[0] == key:
             if self._handles:  # the factor is arriving from its owner rank: order this stream behind the transfers
                 for h in self._handles:
@@ -468,7 +468,7 @@ class HessianAccumulator:
             Hinv = torch.empty((K, K), dtype=torch.float32, device=self.device)
             dead = torch.empty(K, dtype=torch.uint8, device=self.device)
             perm = torch.empty(K, dtype=torch.int64, device=self.device) if (act_order or hybrid_groupsize) else None
-            self.finalized = ((float(percdamp), bool(act_order), int(hybrid_groupsize)), Hinv, dead, perm)
+            self.finalized = ((float(percdamp), bool(act_order)) + ((int(hybrid_groupsize),) if hybrid_groupsize else ()), Hinv, dead, perm)
             self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
         # the "not positive definite" status word travels with the factor: every rank raises together in check() instead of the
         # owner alone (the others would walk into the next collective and hang)
