@@ -3,7 +3,7 @@
 neural_compressor_amd/csrc/gptq.hip into a stand-alone program with three forms of the step's output selects --
   orig  the three selects left to the compiler (it sinks them to the end of the chain: 306 registers)
   pinv  pinned with an `asm volatile` (the product form: 121 registers)
-  pinn  pinned with a plain `asm`
+  pinn  pinned + the rank-1 updates as packed fp32 operations on register pairs
 -- times 32 launches of each at N rows x 4096 columns (alone on the chip; 64 KiB and 82 KiB of LDS: two / one workgroup per CU)
 and compares the emitted codes.  usage: tools/chain_lab.py [build-dir]   ->  <build-dir>/chain_time ; run it with N as argument.
 Numbers: profiles/r5/chain_pin_timing.log."""
@@ -18,7 +18,45 @@ body = "\n".join(src[start:end])
 pin = '    asm volatile("" : "+v"(wr[ci]), "+v"(ev[ci]), "+v"(cw[ci >> 2]));'
 assert pin in body, "the product's pin statement moved: update this script"
 body = body.replace("  __builtin_amdgcn_s_setprio(3);\n", "")
-variants = {"orig": body.replace(pin, ""), "pinv": body, "pinn": body.replace(pin, pin.replace("asm volatile", "asm"))}
+def packed(b):
+    """the rank-1 updates as v_pk_mul_f32 / v_pk_add_f32 on register pairs (same roundings: un-fused multiply then subtract)"""
+    b = b.replace("  float wr[32], ev[32];", "  typedef float f32x2 __attribute__((ext_vector_type(2)));\n  f32x2 wr2[16];\n  float ev[32];")
+    b = b.replace("    wr[c] = w[rowc * K + i1 + 4 * c + q];", "    wr2[c >> 1][c & 1] = w[rowc * K + i1 + 4 * c + q];")
+    b = b.replace("vmax = fmaxf(vmax, wr[c]);", "vmax = fmaxf(vmax, wr2[c >> 1][c & 1]);").replace("vmin = fminf(vmin, wr[c]);", "vmin = fminf(vmin, wr2[c >> 1][c & 1]);")
+    b = b.replace("  float ha[33], hb2[33];", "  f32x2 ha[17], hb2[17];")
+    b = b.replace("auto fetch_row = [&](auto ic, float (&h)[33]) {", "auto fetch_row = [&](auto ic, f32x2 (&h)[17]) {")
+    b = b.replace("      for (int c = i >> 2; c < 32; ++c) h[c] = hs[i * QB + 4 * c + q];\n      h[32] = hs[i * QB + i];",
+                  "      for (int c = i >> 2; c < 32; ++c) h[c >> 1][c & 1] = hs[i * QB + 4 * c + q];\n      h[16][0] = hs[i * QB + i];")
+    b = b.replace("auto step = [&](auto ic, float (&h)[33]) {", "auto step = [&](auto ic, f32x2 (&h)[17]) {")
+    b = b.replace("const float x = quad_bcast(wr[ci], qo);", "const float x = quad_bcast(wr2[ci >> 1][ci & 1], qo);")
+    b = b.replace("const float e = (x - qv) / h[32];", "const float e = (x - qv) / h[16][0];")
+    old_loop = """#pragma unroll
+    for (int c = ci; c < 32; ++c) {
+      const float pr = e * h[c];  // exact zero below the diagonal (Hinv is upper triangular)
+      wr[c] = wr[c] - pr;
+    }"""
+    new_loop = """    if constexpr ((ci & 1) != 0) {
+      const float pr = e * h[ci >> 1][1];
+      wr2[ci >> 1][1] = wr2[ci >> 1][1] - pr;
+    }
+    {
+      const f32x2 e2 = {e, e};
+#pragma unroll
+      for (int c2 = (ci + 1) >> 1; c2 < 16; ++c2) {
+        const f32x2 pr = e2 * h[c2];  // exact zero below the diagonal (Hinv is upper triangular)
+        wr2[c2] = wr2[c2] - pr;
+      }
+    }"""
+    assert old_loop in b
+    b = b.replace(old_loop, new_loop)
+    b = b.replace("    wr[ci] = own ? qv : wr[ci];", "    wr2[ci >> 1][ci & 1] = own ? qv : wr2[ci >> 1][ci & 1];")
+    b = b.replace('"+v"(wr[ci]), "+v"(ev[ci])', '"+v"(wr2[ci >> 1]), "+v"(ev[ci])')
+    b = b.replace("st[r * QB + 4 * c + q] = wr[c];", "st[r * QB + 4 * c + q] = wr2[c >> 1][c & 1];")
+    assert "wr[" not in b.replace("wr2[", ""), [l for l in b.split("\n") if "wr[" in l.replace("wr2[", "")][:5]
+    return b
+
+
+variants = {"orig": body.replace(pin, ""), "pinv": body, "pinn": packed(body)}
 code = """#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -84,13 +122,13 @@ int main(int argc, char** argv) {
     run(0, 65536, codes[0], "original (selects sunk, 306 registers)");
     run(1, 65536, codes[1], "pinned, asm volatile");
     run(1, 83968, codes[1], "pinned, asm volatile, one per CU");
-    run(2, 65536, codes[2], "pinned, plain asm");
-    run(2, 83968, codes[2], "pinned, plain asm, one per CU");
+    run(2, 65536, codes[2], "pinned + packed rank-1 updates");
+    run(2, 83968, codes[2], "pinned + packed updates, one per CU");
   }
   std::vector<uint8_t> h0((size_t)N * K), h1((size_t)N * K), h2((size_t)N * K);
   HIPCHECK(hipMemcpy(h0.data(), codes[0], N * K, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(h1.data(), codes[1], N * K, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(h2.data(), codes[2], N * K, hipMemcpyDeviceToHost));
   size_t d1 = 0, d2 = 0; for (size_t i = 0; i < h0.size(); ++i) { d1 += h0[i] != h1[i]; d2 += h0[i] != h2[i]; }
-  printf("  codes differing from the original: %zu (volatile), %zu (plain)\n", d1, d2);
+  printf("  codes differing from the original: %zu (pinned), %zu (pinned + packed)\n", d1, d2);
   return 0;
 }
 """
