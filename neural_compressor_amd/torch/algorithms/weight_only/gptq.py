@@ -256,6 +256,7 @@ class HessianAccumulator:
         self.defer = False    # True: a full stage waits for flush_many (one launch for all Hessians of a forward)
         self.finalized = None  # (Hinv, dead, perm) cache keyed by (percdamp, act_order)
         self._info = None      # status word of a factorisation whose check was deferred (see check())
+        self._info_host, self._info_event = None, None  # its pinned copy and the event behind that copy (inverse_factor)
         self._handles = None   # pending broadcasts of a factor received from its owner rank (mode "sample+rows")
         self._ready = None     # event of a factorisation that ran on a side stream (prefactor)
 
@@ -431,7 +432,7 @@ class HessianAccumulator:
         """Raise if the (deferred) factorisation met a non-positive pivot; one host synchronisation."""
         if self._info is not None:
             info, self._info = self._info, None
-            if getattr(self, "_info_event", None) is not None:  # (a factor received from another rank has no event: read it back)
+            if self._info_event is not None:  # (a factor received from another rank has no event: read it back)
                 self._info_event.synchronize()
                 info, self._info_host, self._info_event = self._info_host, None, None
             try:
