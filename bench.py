@@ -93,7 +93,7 @@ def _pmc_traffic(key):
     they come from separate `rocprofv3 --pmc` passes over THIS command (scripts/gpu_pmc_bench.sh: FETCH_SIZE doubled as
     the MI355X guide prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE), whose per-launch means are
     committed under profiles/ (newest round first); null when no PMC pass has been recorded for this kernel."""
-    for rnd in ("r5_pmc", "r4_pmc", "r3_pmc", "r2_pmc", "r1_pmc"):
+    for rnd in ("r6_pmc", "r5_pmc", "r4_pmc", "r3_pmc", "r2_pmc", "r1_pmc"):
         path = os.path.join(ROOT, "profiles", rnd, "bench_traffic.json")
         try:
             with open(path) as f:
@@ -160,29 +160,35 @@ def bench_dequant_gemm(device, shapes, iters=20):
             torch.cuda.synchronize()
             batches.append(e0.elapsed_time(e1) / iters)
         ms = sorted(batches)[1]
-        dense_ms = None
-        if M >= 1024:
+        dense_ms, unfused_ms = None, None
+        if M >= 128:
             # the library's DENSE bf16 GEMM (hipBLASLt through torch) on the same shape, in the same process and thermal state, timed in
-            # alternation with the fused kernel: the yardstick VERDICT r3 asks for (a reference point, not a product path)
+            # alternation with the fused kernel (a reference point, not a product path).  M >= 1024 also times the UN-FUSED route the
+            # fusion competes with: inc_woq_dequant (recover()) into a dense bf16 weight, then the library GEMM on it, per call.
+            from neural_compressor_amd import ops as _ops
+
             wd = torch.randn(N, K, device=device, dtype=torch.bfloat16) * 0.02
             for _ in range(20):
                 torch.nn.functional.linear(x, wd)
-            fused, dense = [], []
+
+            def unfused():
+                w_ = _ops.woq_dequant(m.qweight, m.scales, m.qzeros, None, N, K, 128, 4, torch.bfloat16)
+                return torch.nn.functional.linear(x, w_)
+
+            legs = [("fused", lambda: m(x)), ("dense", lambda: torch.nn.functional.linear(x, wd))] + ([("unfused", unfused)] if M >= 1024 else [])
+            got = {k: [] for k, _ in legs}
             for _ in range(3):
-                e0.record()
-                for _ in range(iters):
-                    m(x)
-                e1.record()
-                torch.cuda.synchronize()
-                fused.append(e0.elapsed_time(e1) / iters)
-                e0.record()
-                for _ in range(iters):
-                    torch.nn.functional.linear(x, wd)
-                e1.record()
-                torch.cuda.synchronize()
-                dense.append(e0.elapsed_time(e1) / iters)
-            ms = min(ms, sorted(fused)[1])
-            dense_ms = sorted(dense)[1]
+                for k, fn in legs:
+                    e0.record()
+                    for _ in range(iters):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    got[k].append(e0.elapsed_time(e1) / iters)
+            ms = min(ms, sorted(got["fused"])[1])
+            dense_ms = sorted(got["dense"])[1]
+            if "unfused" in got:
+                unfused_ms = sorted(got["unfused"])[1]
             del wd
         graph_ms = None
         if M <= 512:
@@ -258,17 +264,17 @@ def bench_dequant_gemm(device, shapes, iters=20):
         if dense_ms is not None:
             row.update(hipblaslt_dense_bf16_ms=round(dense_ms, 4), hipblaslt_dense_bf16_tflops=round(flops / dense_ms / 1e9, 2),
                        vs_hipblaslt_dense=round(dense_ms / ms, 4))
+        if unfused_ms is not None:
+            # recover() + library GEMM per call against the fused kernel (> 1: the fusion wins time, not only memory)
+            row.update(unfused_dequant_plus_hipblaslt_ms=round(unfused_ms, 4), fused_vs_unfused=round(unfused_ms / ms, 4))
         if graph_ms is not None:
             row.update(graph_ms=round(graph_ms, 4), graph_tflops=round(flops / graph_ms / 1e9, 2), graph_gbs=round(bytes_ / graph_ms / 1e6, 1),
                        graph_frac=round((flops / graph_ms / 1e9) / BF16_MFMA_PEAK_TFLOPS if bound == "mfma" else (bytes_ / graph_ms / 1e6) / HBM_PEAK_GBS, 4))
         if cold_ms is not None:
-            # the HBM fraction of an HBM-bound row is the COLD one (distinct weights per call); the eager `frac` above includes the
-            # host side of a single call and the graph figure is cache-resident
+            # the HBM fraction to quote for an HBM-bound row is the COLD one (`cold_graph_frac`: distinct weights per call); `frac` keeps
+            # its meaning of rounds 1-4 (eager single call, host side included) and `graph_frac` is the cache-resident replay
             row.update(cold_graph_ms=round(cold_ms, 4), cold_graph_gbs=round(bytes_ / cold_ms / 1e6, 1),
                        cold_graph_frac=round((bytes_ / cold_ms / 1e6) / HBM_PEAK_GBS, 4), cold_ring_modules=ring_n, cold_ring_mib=round(ring_mib, 1))
-            if bound == "hbm":
-                row["frac"] = row["cold_graph_frac"]
-                row["frac_basis"] = "cold_graph (hipGraph replay over a ring of modules with distinct packed weights: the bytes come from HBM)"
         res.append(row)
     return res
 
@@ -366,14 +372,32 @@ def _cpu_baseline_worker(threads):
     # the reference's forward on this host (modules.py:594-610): recover() once, then F.linear on the CACHED fp32 weight -- the CPU figure
     # SURVEY 8(d) asks for beside the fused dequant-GEMM.  One 2048-token calibration sample per shape (bounded: < 1 s each).
     wrec = torch.from_numpy(np.asarray(rec)).float()
-    for (Nl, Kl, wl) in ((4096, 4096, wrec), (11008, 4096, torch.randn(11008, 4096, generator=g) * 0.02), (4096, 11008, torch.randn(4096, 11008, generator=g) * 0.02)):
-        xl = torch.randn(2048, Kl, generator=g)
-        torch.nn.functional.linear(xl, wl)  # warm-up
-        reps = 3
-        t0 = time.time()
-        for _ in range(reps):
-            torch.nn.functional.linear(xl, wl)
-        out[f"t_linear_2048x{Nl}x{Kl}"] = (time.time() - t0) / reps
+    # M in {1, 16, 512, 4096} at 4096 x 4096, and the prefill row (M = 4096) of the two 11008 shapes -- each beside the GPU row
+    for (Nl, Kl, wl, Ms) in ((4096, 4096, wrec, (1, 16, 512, 4096)), (11008, 4096, torch.randn(11008, 4096, generator=g) * 0.02, (4096,)),
+                             (4096, 11008, torch.randn(4096, 11008, generator=g) * 0.02, (4096,))):
+        for Ml in Ms:
+            xl = torch.randn(Ml, Kl, generator=g)
+            torch.nn.functional.linear(xl, wl)  # warm-up
+            reps = 3 if Ml >= 512 else 20
+            t0 = time.time()
+            for _ in range(reps):
+                torch.nn.functional.linear(xl, wl)
+            out[f"t_linear_{Ml}x{Nl}x{Kl}"] = (time.time() - t0) / reps
+    # BASELINE config #1 on these cores: RTN INT8 per-channel over every Linear of an OPT-125M-shaped stack (72 modules; rtn.py:68 ->
+    # quant_tensor + pack), the oracle's restatement of the reference's CPU adaptor
+    from tests.model_zoo import opt125m_like
+
+    model = opt125m_like()
+    t0 = time.time()
+    nmod = 0
+    for name, mod in model.named_modules():
+        if isinstance(mod, torch.nn.Linear) and name != "lm_head":
+            iw_, sc_, _ = O.quant_tensor(mod.weight.data.clone(), bits=8, group_size=-1, scheme="sym", return_int=True)
+            O.woq_pack_optimum(iw_.numpy().astype(np.int32), sc_.numpy(), None, 8)
+            nmod += 1
+    out["t_rtn_config1"] = time.time() - t0
+    out["rtn_config1_modules"] = nmod
+    del model
     # pack / unpack / recover at 11008 x 4096 (the per_layer rows that had no CPU figure)
     w2 = torch.randn(11008, 4096, generator=g) * 0.02
     iw2, sc2, _ = O.quant_tensor(w2, bits=4, group_size=128, scheme="sym", return_int=True)
@@ -465,20 +489,24 @@ def bench_per_layer(device, cpu):
         acc.add_batch(x.view(TOK // 2048, 2048, K))
         Hs[K] = acc
         del x, H
+    # the three solves of a block, set up side by side and timed INTERLEAVED and repeated (profiles/NOTES.md: a single cold-started
+    # timing of a latency chain reads the chip's clock state, not the kernel): min and median of REPS rounds over the shapes
+    REPS = 5
+    setups = []
     for N, K in ((4096, 4096), (11008, 4096), (4096, 11008)):
         layer = torch.nn.Linear(K, N, bias=False, device=device, dtype=torch.bfloat16)
         layer.weight.data.normal_(0, 0.02)
         W0 = layer.weight.data.clone()
+        Hs[K].flush()
+
         # (a) the whole solve: damp + inverse-Cholesky factor + column loop (GPTQ.fasterquant), a fresh accumulator copy each time
-        def solve():
+        def solve(layer=layer, W0=W0, K=K):
             a = G.HessianAccumulator(K, device)
             a.H, a._n = Hs[K].H.clone(), Hs[K]._n
             gq = G.GPTQ(layer, device=device, accumulator=a)
             gq.configure(dict(bits=4, sym=True, dtype="int"))
             gq.fasterquant(W0, blocksize=128, percdamp=0.01, groupsize=128)
-            return gq
-        Hs[K].flush()
-        t_solve = timed(solve, reps=2, warm=1)
+
         # (b) the column loop alone, with the factor in hand (inc_gptq_quantize_layer)
         a = G.HessianAccumulator(K, device)
         a.H, a._n = Hs[K].H.clone(), Hs[K]._n
@@ -489,18 +517,37 @@ def bench_per_layer(device, cpu):
         Q = torch.empty(N, K, dtype=torch.bfloat16, device=device)
         err = torch.empty(2, N, 128, device=device)
         side = G._lookahead_stream(device)
+        w32s = [ops.gptq_prepare_weight(W0, dead) for _ in range(REPS + 1)]  # the loop consumes its working copy: one per timed call
 
-        def loop():
-            w32 = ops.gptq_prepare_weight(W0, dead)
-            ops.gptq_quantize_layer(w32, Hinv, scale, zero, None, None, codes, Q, err, 128, 128, 128, 4, True, ops.GPTQ_DYNAMIC_GROUPS, aux_stream=side)
-        t_loop = timed(loop, reps=3, warm=1)
-        t_prep = timed(lambda: ops.gptq_prepare_weight(W0, dead), reps=3, warm=1)
-        t_loop -= t_prep
-        out[f"fasterquant_{N}x{K}"] = dict(gpu_s=round(t_solve, 5), cpu_s=c(f"t_fq_{N}x{K}"), column_loop_s=round(t_loop, 5),
-                                           column_loop_us_per_column=round(t_loop * 1e6 / K, 3),
-                                           column_loop_gbs=round(2.0 * N * K * 4 / t_loop / 1e9, 1),
-                                           column_loop_hbm_frac=round(2.0 * N * K * 4 / t_loop / 1e9 / HBM_PEAK_GBS, 4))
-        del layer, W0, Hinv, a, scale, zero, codes, Q, err
+        def loop(i, Hinv=Hinv, scale=scale, zero=zero, codes=codes, Q=Q, err=err, side=side, w32s=w32s):
+            ops.gptq_quantize_layer(w32s[i], Hinv, scale, zero, None, None, codes, Q, err, 128, 128, 128, 4, True, ops.GPTQ_DYNAMIC_GROUPS, aux_stream=side)
+
+        setups.append((N, K, solve, loop))
+    t_solve = {i: [] for i in range(len(setups))}
+    t_loop = {i: [] for i in range(len(setups))}
+    for rep in range(REPS + 1):  # round 0 is the warm-up
+        for i, (N, K, solve, loop) in enumerate(setups):
+            torch.cuda.synchronize()
+            e0.record()
+            loop(rep)
+            e1.record()
+            torch.cuda.synchronize()
+            if rep:
+                t_loop[i].append(e0.elapsed_time(e1) * 1e-3)
+            if rep < 3:
+                e0.record()
+                solve()
+                e1.record()
+                torch.cuda.synchronize()
+                if rep:
+                    t_solve[i].append(e0.elapsed_time(e1) * 1e-3)
+    for i, (N, K, _, _) in enumerate(setups):
+        lo, med = min(t_loop[i]), sorted(t_loop[i])[len(t_loop[i]) // 2]
+        out[f"fasterquant_{N}x{K}"] = dict(gpu_s=round(min(t_solve[i]), 5), cpu_s=c(f"t_fq_{N}x{K}"), column_loop_s_min=round(lo, 5), column_loop_s_median=round(med, 5),
+                                           column_loop_us_per_column_min=round(lo * 1e6 / K, 3), column_loop_us_per_column_median=round(med * 1e6 / K, 3),
+                                           column_loop_hbm_frac=round(2.0 * N * K * 4 / med / 1e9 / HBM_PEAK_GBS, 4), reps=REPS)
+    del setups
+    torch.cuda.empty_cache()
     # pack / unpack / recover / quant_tensor of one 4096 x 4096 g128 layer (bytes: SURVEY 8(d))
     N = K = 4096
     w = torch.randn(N, K, device=device) * 0.02
@@ -660,8 +707,9 @@ def cpu_baseline(timeout_s=420):
                 f"forward of one 2048-token sample = {m['t_fwd']:.2f} s; x (128 samples x 7 Hessians + 7 solves + 2 x 128 forwards) x 32 blocks"),
         per_block_s=dict(hessians=round(hess, 2), solves=round(solve, 2), forwards=round(fwd, 2)),
         # the reference's packed-module forward on these cores: fp32 F.linear on the cached recovered weight (modules.py:594-610)
-        f_linear=[dict(M=2048, N=n_, K=k_, ms=round(m[f"t_linear_2048x{n_}x{k_}"] * 1e3, 2), tflops=round(2.0 * 2048 * n_ * k_ / m[f"t_linear_2048x{n_}x{k_}"] / 1e12, 3))
-                  for (n_, k_) in ((4096, 4096), (11008, 4096), (4096, 11008)) if f"t_linear_2048x{n_}x{k_}" in m],
+        f_linear=[dict(M=m_, N=n_, K=k_, ms=round(m[f"t_linear_{m_}x{n_}x{k_}"] * 1e3, 3), tflops=round(2.0 * m_ * n_ * k_ / m[f"t_linear_{m_}x{n_}x{k_}"] / 1e12, 4))
+                  for (m_, n_, k_) in ((1, 4096, 4096), (16, 4096, 4096), (512, 4096, 4096), (4096, 4096, 4096), (4096, 11008, 4096), (4096, 4096, 11008))
+                  if f"t_linear_{m_}x{n_}x{k_}" in m],
         **{k: round(v, 4) for k, v in m.items()},
     )
 
@@ -708,7 +756,7 @@ def bench_e2e(device, args, rank, world, note):
 
 
 def bench_awq_sq_blocks(device, note):
-    """BASELINE configs #3 (AWQ INT4 g128, auto-scale + auto-clip; one Llama-2-7B-shaped block, 128 x 512 tokens) and #4
+    """BASELINE configs #3 (AWQ INT4 g128, auto-scale + auto-clip; one Llama-2-7B-shaped block, 128 x 2048 tokens: the headline's set) and #4
     (SmoothQuant W8A8 calibrate + convert; one Llama-2-13B-shaped block, 32 x 2048 tokens): wall-clock per block."""
     from transformers import LlamaConfig, LlamaForCausalLM
 
@@ -727,7 +775,7 @@ def bench_awq_sq_blocks(device, note):
     out = {}
     g = torch.Generator().manual_seed(1)
     for tag, dims, n, seq, cfg in (
-        ("awq_block", (4096, 11008, 32), 128, 512, AWQConfig(bits=4, group_size=128, use_sym=False, use_auto_scale=True, use_auto_clip=True)),
+        ("awq_block", (4096, 11008, 32), 128, 2048, AWQConfig(bits=4, group_size=128, use_sym=False, use_auto_scale=True, use_auto_clip=True)),
         ("smoothquant_block", (5120, 13824, 40), 32, 2048, SmoothQuantConfig(alpha=0.5, folding=False, scale_sharing=True)),
     ):
         ids = [torch.randint(0, 32000, (1, seq), generator=g) for _ in range(n)]
@@ -751,10 +799,118 @@ def bench_awq_sq_blocks(device, note):
         out[tag] = dict(seconds_per_block=round(dt, 3), first_pass_s=round(times[0], 3), samples=n, seq_len=seq, hidden=dims[0],
                         ffn=dims[1], model_estimate_s=round(dt * (32 if tag == "awq_block" else 40), 1))
         if tag == "awq_block":
-            out[tag]["floor"] = ("the block's time is 1.36e15 flop of GEMMs the reference's algorithm prescribes (20 whole-block forwards per multi-Linear "
-                                 "tuple + 20 / 10 Linear forwards per module, awq.py:341,454); going below needs the losses in Hessian form, which is "
-                                 "not the reference's bf16-rounded output MSE: a parity decision, not a kernel limit")
+            out[tag]["floor"] = "GEMM flops the reference's grid searches prescribe (awq.py:341,454); DESIGN.md section 6"
         note(f"{tag}: {dt:.2f}s (first pass {times[0]:.2f}s)")
+    return out
+
+
+def bench_rtn_config1(device, note):
+    """BASELINE config #1 (OPT-125M RTN INT8 weight-only, rtn.py:68) on the GPU: quantize(model, RTNConfig(bits=8, group_size=-1)) over
+    the OPT-125M-shaped stack the parity test uses (72 Linears, weights resident in HBM), wall-clock incl. packing; the CPU port of the
+    same job is timed in cpu_baseline (t_rtn_config1)."""
+    from neural_compressor_amd.torch.quantization import RTNConfig, quantize
+    from tests.model_zoo import opt125m_like
+
+    times = []
+    for _ in range(3):
+        model = opt125m_like().to(device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        q = quantize(model, RTNConfig(bits=8, group_size=-1, use_layer_wise=False))
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        del model, q
+    note(f"config #1 (RTN INT8, OPT-125M-shaped): {min(times) * 1e3:.1f} ms")
+    return dict(seconds=round(min(times), 4), first_pass_s=round(times[0], 4), modules=72, params_m=85.0,
+                what="quantize(model, RTNConfig(bits=8, group_size=-1)) on an OPT-125M-shaped stack, weights in HBM, packing included")
+
+
+def _run_child(mode, timeout_s=600):
+    """Some measurements want a FRESH process (no streams created yet, chip not just out of a full-power phase: profiles/NOTES.md):
+    re-run this script with --child MODE and read the JSON line it prints."""
+    import subprocess
+
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", mode], capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # report, never fake
+        print(f"[bench] child '{mode}' failed: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+
+
+def compact_line(full):
+    """The ONE stdout line: the contract's keys, `roofline` and `cpu_baseline` as flat scalars (the driver's record keeps the scalars of
+    these two objects and drops nested lists), everything else in short form.  The full record goes to --detail-file."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "dist_backend", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data", "config", "value_is", "rounds_only_s", "layer_round_ms", "sanity") if k in full}
+    roof = dict(full.get("roofline") or {})
+    cpu = full.get("cpu_baseline") or {}
+    rows = full.get("dequant_gemm") or []
+    loop = (full.get("ceilings") or {}).get("bf16_mfma_loop_tflops")
+    fl = {(f["M"], f["N"], f["K"]): f["tflops"] for f in (cpu.get("f_linear") or [])}
+    gem = []
+    for r in rows:
+        tag = f"{r['M']}x{r['N']}x{r['K']}"
+        if r["bound"] == "mfma":
+            # second half of BASELINE's metric: fused INT4->bf16 dequant-GEMM per shape -- TFLOP/s, of the spec peak, against hipBLASLt's
+            # dense bf16 GEMM timed in alternation, and (M >= 1024) against the un-fused route recover() + hipBLASLt
+            roof[f"gemm_{tag}_tflops"] = r["tflops"]
+            roof[f"gemm_{tag}_frac"] = r["frac"]
+            if r.get("vs_hipblaslt_dense") is not None:
+                roof[f"gemm_{tag}_vs_hipblaslt"] = r["vs_hipblaslt_dense"]
+            if r.get("fused_vs_unfused") is not None:
+                roof[f"gemm_{tag}_vs_unfused"] = r["fused_vs_unfused"]
+            if loop and r["M"] >= 1024:
+                roof[f"gemm_{tag}_of_mfma_loop"] = round(r["tflops"] / loop, 4)
+        elif r.get("cold_graph_frac") is not None:
+            # HBM-bound rows: the COLD figure (ring of distinct modules), the only one that is HBM bandwidth
+            roof[f"gemv_{tag}_hbm_frac_cold"] = r["cold_graph_frac"]
+            roof[f"gemv_{tag}_us_cold"] = round(r["cold_graph_ms"] * 1e3, 2)
+        if (r["M"], r["N"], r["K"]) in fl:
+            roof[f"cpu_f_linear_{tag}_tflops"] = fl[(r["M"], r["N"], r["K"])]
+        gem.append([r["M"], r["N"], r["K"], r["tflops"], r["frac"]])
+    big = [r["frac"] for r in rows if r["M"] >= 4096]
+    if big:
+        roof["gemm_frac_min_M_ge_4096"], roof["gemm_frac_max_M_ge_4096"] = min(big), max(big)
+    for r in full.get("dequant_gemv_groups") or []:
+        roof[f"gemv_group_{r['group']}_hbm_frac_cold"] = r["cold_graph_frac"]
+        roof[f"gemv_group_{r['group']}_us_cold"] = round(r["cold_graph_ms"] * 1e3, 2)
+    per = full.get("per_layer") or {}
+    for k, v in per.items():
+        if k.startswith("fasterquant_"):
+            roof[f"column_loop_{k[12:]}_us_per_column_median"] = v.get("column_loop_us_per_column_median")
+            roof[f"column_loop_{k[12:]}_us_per_column_min"] = v.get("column_loop_us_per_column_min")
+        elif k.startswith(("unpack", "recover", "pack", "quant_tensor")):
+            roof[f"{k}_hbm_frac_cold"] = v.get("hbm_frac")
+    ceil_ = full.get("ceilings") or {}
+    for k in ("hbm_copy_gbs", "hbm_stream_triad_gbs", "bf16_mfma_loop_tflops"):
+        if ceil_.get(k) is not None:
+            roof[f"measured_{k}"] = ceil_[k]
+    out["roofline"] = roof
+    if cpu:
+        out["cpu_baseline"] = {k: v for k, v in cpu.items() if not isinstance(v, (list, dict))}
+        if len(str(out["cpu_baseline"].get("sample", ""))) > 118:
+            out["cpu_baseline"]["sample"] = "oracle on this host: one call per distinct shape of a block, x counts x 32 blocks (detail file has the terms)"
+    if full.get("e2e"):
+        out["e2e"] = {k: full["e2e"][k] for k in ("wall_s", "blocks", "packed_modules", "prepare_and_capture_s") if k in full["e2e"]}
+    out["kernel_breakdown"] = {k: v["avg_ms"] for k, v in (full.get("kernel_breakdown") or {}).items() if v.get("launches")}
+    if gem:
+        out["dequant_gemm"] = dict(columns=["M", "N", "K", "tflops", "frac_eager"], rows=gem)
+    if full.get("w8a8_gemm"):
+        out["w8a8_gemm"] = dict(columns=["M", "N", "K", "gemm_tops", "fwd_tops"], rows=[[r["M"], r["N"], r["K"], r["gemm_tops"], r["fwd_tops"]] for r in full["w8a8_gemm"]])
+    for k in ("awq_block", "smoothquant_block"):
+        if full.get(k):
+            out[k] = {kk: full[k][kk] for kk in ("seconds_per_block", "samples", "seq_len", "model_estimate_s") if kk in full[k]}
+    for k in ("awq_e2e", "smoothquant_e2e", "rtn_config1"):
+        if full.get(k):
+            out[k] = {kk: vv for kk, vv in full[k].items() if not isinstance(vv, str)}
+    if per:
+        out["per_layer"] = {k: ([v.get("gpu_s_per_sample"), v.get("frac")] if k.startswith("hessian") else
+                                [v.get("gpu_s"), v.get("hbm_frac") if "hbm_frac" in v else v.get("column_loop_s_median")]) for k, v in per.items()}
+    if full.get("dequant_gemm_replicas"):
+        out["dequant_gemm_replicas"] = full["dequant_gemm_replicas"]
+    out["allocator"] = {k: v for k, v in (full.get("allocator") or {}).items() if k in ("hipMalloc_calls", "hipFree_calls", "reserved_GiB")}
     return out
 
 
@@ -774,7 +930,17 @@ def main():
     ap.add_argument("--mgpu-mode", choices=("layer", "exact"), default="layer", help="N > 1: one block per GPU on float activations (north_star) | exact reference semantics")
     ap.add_argument("--layer-on-one-gpu", action="store_true", help="N = 1: time the layer-per-GPU mode's round (float forward + quantise, no exchange)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="llama2-7b", help="llama2-70b: BASELINE config #5's block shape (hidden 8192, ffn 28672, GQA 64:8)")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="the full per-row record (cold / graph / cache-resident variants of every row); the stdout line is its compact form")
+    ap.add_argument("--full-line", action="store_true", help="print the full record on stdout instead of the compact line")
+    ap.add_argument("--child", choices=("per_layer",), default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.child == "per_layer":
+        # a fresh process on an otherwise idle chip (the parent waits): the measured ceilings and the per-layer calls
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(device)
+        print(json.dumps(dict(ceilings=bench_ceilings(device), per_layer=bench_per_layer(device, None))), flush=True)
+        return
     global WORKLOAD
     WORKLOAD = args.workload
     if args.workload != "llama2-7b":
@@ -947,37 +1113,27 @@ def main():
         traffic, traffic_src = _pmc_traffic(dom)
         multi = dom.startswith("hessian_multi")
         roofline = dict(kernel=("hessian_syrk_tr_256_multi_kernel<bf16>" if multi else "hessian_syrk_tr_256_kernel<bf16>") +
-                               f" ({dom}; algorithmic flops 2*T*K^2 per Hessian and launch)", bound="mfma",
+                               f" K={dom.split('K')[-1]}; flops 2*T*K^2 per Hessian", bound="mfma",
                         achieved=round(achieved, 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                         avg_launch_ms=round(v["avg_ms"], 4), launches=v["launches"], tokens_per_launch=tokens,
                         executed_frac=round(achieved * executed / BF16_MFMA_PEAK_TFLOPS, 4),
                         all_launches_frac=round(all_work / (all_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
-                        note="algorithmic = the full X^T X products (SURVEY 8d); the syrk kernel executes the upper-triangular tiles "
-                             f"only ({executed:.3f} of it): executed_frac is the matrix-pipe view of the same time; all_launches_frac = "
-                             "algorithmic flops of EVERY Hessian launch of the timed region / their summed time")
+                        note=f"algorithmic = full X^T X (SURVEY 8d); the syrk executes the upper tiles only ({executed:.3f}): executed_frac")
 
     result = dict(
         metric=f"{WORKLOAD.replace('-', '_')}_gptq_int4_g128_quantize_wall_clock", value=round(value, 3), unit="s", n_gpus=world, rccl_ranks=rccl_ranks,
         dist_backend=dist_backend,
         steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 2), higher_is_better=False,
         scaling="strong", vs_baseline=None, dtype="bf16", data="synthetic",
-        config=dict(workload=f"{WORKLOAD} GPTQ INT4 group_size=128 sym, {args.samples} calib samples x {args.seq} tokens; step = one transformer block "
-                             f"(7 Linears: q/o [{hidden},{hidden}], k/v [{hidden * kv_heads // heads},{hidden}], gate/up [{ffn},{hidden}], down [{hidden},{ffn}]); "
-                             f"value = {model_blocks} blocks", baseline_config=baseline_cfg,
-                    samples=args.samples, seq_len=args.seq, block_size=128, percdamp=0.01,
-                    capture_pass=("first forward of a block ends at its last hooked Linear (that Linear's own product and the residual add "
-                                  "behind it only feed the output the reference computes and discards, gptq.py:690-702); "
-                                  "INC_MI355X_GPTQ_CAPTURE_EARLY_STOP=0 runs it in full; the quantised model is bit-identical either way"),
+        config=dict(workload=f"{WORKLOAD} GPTQ INT4 g128 sym, {args.samples}x{args.seq} calib tokens; step = one block (7 Linears), value = {model_blocks} blocks",
+                    baseline_config=baseline_cfg, samples=args.samples, seq_len=args.seq, block_size=128, percdamp=0.01,
+                    linears=f"q/o [{hidden},{hidden}], k/v [{hidden * kv_heads // heads},{hidden}], gate/up [{ffn},{hidden}], down [{hidden},{ffn}]",
+                    capture_pass="first forward ends at the last hooked Linear (gptq.CAPTURE_EARLY_STOP; bit-identical model; DESIGN.md 6)",
                     arithmetic="bf16 activations/weights (MFMA, fp32 accumulate), fp32 Hessian + Cholesky + column loop, int4 codes",
-                    parallelism=(("single GPU" if not layer_mode else "single GPU running the layer-per-GPU mode's round (float forward of the "
-                                  "block, then its quantisation on those inputs, no second forward): the terms of the N-GPU projection") if world == 1 else
-                                 (f"ONE model on {world} ranks, one transformer block per rank (step = one round of {world} blocks): samples sharded "
-                                  f"{world}-way for the float forwards, block inputs sent to the block's owner over RCCL ({os.environ.get('INC_MI355X_GPTQ_ACT_EXCHANGE', 'scatter')}), "
-                                  "each block calibrated on the FLOAT model's activations (north_star's layer-per-GPU mode; deviates from the reference's "
-                                  "sequential gptq.py:749-762, per-block results bit-identical to a single process of this mode)") if layer_mode else
-                                 f"ONE model on {world} ranks: samples sharded {world}-way, Hessians reduced to owner ranks + factor broadcast "
-                                 "(RCCL), row-sharded column loop + all-gather; exact reference semantics"),
+                    parallelism=(("single GPU" if not layer_mode else "single GPU running the layer-per-GPU mode's round (no exchange)") if world == 1 else
+                                 (f"ONE model on {world} ranks, one block per rank per round, inputs sent to the owner over RCCL (mode layer; DESIGN.md 7)" if layer_mode else
+                                  f"ONE model on {world} ranks: samples sharded, Hessians reduced to owners, row-sharded column loop (mode exact)")),
                     steps_per_model=steps_per_model),
         roofline=roofline, kernel_breakdown=breakdown, allocator=allocator, sanity=sanity,
     )
@@ -1018,32 +1174,42 @@ def main():
         note("dequant-GEMM shapes timed")
         result["w8a8_gemm"] = bench_w8a8_gemm(device, [(4096, 5120, 5120), (4096, 13824, 5120), (4096, 5120, 13824)])
         note("W8A8 shapes timed")
+    if rank == 0 and not args.no_per_layer:
+        # BEFORE the CPU baseline (which leaves the chip idle and down-clocked for half a minute) and in a fresh process: ceilings + per-layer
+        torch.cuda.empty_cache()
+        child = _run_child("per_layer") if WORKLOAD == "llama2-7b" else dict(ceilings=bench_ceilings(device), per_layer=None)
+        if child:
+            result["ceilings"] = child["ceilings"]
+            if child.get("per_layer"):
+                result["per_layer"] = child["per_layer"]
+        note("ceilings + per-layer figures done (fresh process)")
     if rank == 0 and world == 1 and not args.no_extra_configs:
         result.update(bench_awq_sq_blocks(device, note))
+        result["rtn_config1"] = bench_rtn_config1(device, note)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         note("cpu baseline done")
-    if rank == 0 and not args.no_per_layer:
-        result["ceilings"] = bench_ceilings(device)
-        if WORKLOAD == "llama2-7b":
-            result["per_layer"] = bench_per_layer(device, result.get("cpu_baseline"))
-        note("ceilings + per-layer figures done")
-    if rank == 0 and result.get("roofline") and result.get("dequant_gemm"):
-        # the second half of BASELINE's metric next to the first, inside an object the driver's record keeps: fused INT4->bf16
-        # dequant-GEMM per shape against the spec peak, against the bare MFMA loop measured in this run, and against the library's
-        # dense bf16 GEMM timed in alternation with it
-        loop = (result.get("ceilings") or {}).get("bf16_mfma_loop_tflops")
-        result["roofline"]["dequant_gemm"] = [
-            dict(shape=f"{r['M']}x{r['N']}x{r['K']}", tflops=r["tflops"], frac_of_spec=r["frac"],
-                 frac_of_measured_mfma_loop=(round(r["tflops"] / loop, 4) if loop else None),
-                 hipblaslt_dense_bf16_tflops=r.get("hipblaslt_dense_bf16_tflops"), vs_hipblaslt_dense=r.get("vs_hipblaslt_dense"),
-                 # the reference's forward on this host's cores for the same layer (fp32 F.linear on the cached recovered weight,
-                 # one 2048-token sample; cpu_baseline.f_linear): a reported baseline, not a target
-                 cpu_f_linear_tflops=next((f["tflops"] for f in ((result.get("cpu_baseline") or {}).get("f_linear") or [])
-                                           if f["N"] == r["N"] and f["K"] == r["K"]), None))
-            for r in result["dequant_gemm"] if r["M"] >= 1024]
+        cpu = result["cpu_baseline"]
+        cpu_key = {"hessian_K4096": "t_add_4096", "hessian_K11008": "t_add_11008", "quant_tensor_4096x4096": "t_quant_tensor_4096",
+                   "pack_4096x4096": "t_pack_4096", "unpack_4096x4096": "t_unpack_4096", "recover_4096x4096": "t_recover_4096",
+                   "pack_11008x4096": "t_pack_11008", "unpack_11008x4096": "t_unpack_11008", "recover_11008x4096": "t_recover_11008"}
+        for k, row in (result.get("per_layer") or {}).items():
+            ck = cpu_key.get(k) or (k.replace("fasterquant_", "t_fq_") if k.startswith("fasterquant_") else None)
+            if ck and cpu.get(ck) is not None:
+                row["cpu_s_per_sample" if k.startswith("hessian") else "cpu_s"] = cpu[ck]
+        if result.get("rtn_config1") and cpu.get("t_rtn_config1") is not None:
+            result["rtn_config1"]["cpu_port_s"] = cpu["t_rtn_config1"]
     if rank == 0:
-        print(json.dumps(result))
+        line = result if args.full_line else compact_line(result)
+        try:
+            os.makedirs(os.path.dirname(args.detail_file), exist_ok=True)
+            with open(args.detail_file, "w") as f:
+                json.dump(result, f, indent=1)
+            if not args.full_line:
+                line["detail_file"] = os.path.relpath(args.detail_file, ROOT)
+        except OSError as e:  # a read-only checkout: the compact line is still complete on its own
+            print(f"[bench] could not write {args.detail_file}: {e}", file=sys.stderr)
+        print(json.dumps(line))
     if live:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
