@@ -279,6 +279,68 @@ def bench_dequant_gemm(device, shapes, iters=20):
     return res
 
 
+def bench_gemv_groups(device):
+    """Decode (M = 1) of the module groups that share x -- q / k / v and gate / up of a Llama-2-7B block -- as ONE launch per group
+    (inc_woq_gemm_multi via woq_linear_group), measured COLD: a hipGraph over a ring of groups with distinct packed weights (>= 512 MiB),
+    next to the same ring issued as single calls.  Bytes = the packed bytes of all modules of the group (SURVEY 8(d) per module)."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear, woq_linear_group
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    res = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for tag, n, N, K in (("qkv_3x4096x4096", 3, 4096, 4096), ("gateup_2x11008x4096", 2, 11008, 4096)):
+        torch.manual_seed(0)
+        w = torch.randn(N, K, device=device) * 0.02
+        iw, sc, _ = quant_tensor(w, bits=4, group_size=128, scheme="sym", return_int=True)
+        m = MI355XWeightOnlyLinear(K, N, bits=4, group_size=128, device=device)
+        m.pack(iw, sc, None, None)
+        m.bias = None
+        del w, iw
+        G = K // 128
+        per = N * K / 2 + G * N * 2 + G * (N // 8) * 4
+        bytes_ = n * per + K * 2 + n * N * 2
+        ring_n = int(max(2, -(-(512 << 20) // int(n * per))))
+        ring = [[copy.deepcopy(m) for _ in range(n)] for _ in range(ring_n)]
+        x = torch.randn(1, K, device=device, dtype=torch.bfloat16)
+        row = dict(group=tag, modules=n, M=1, N=N, K=K, bytes=int(bytes_), cold_ring_groups=ring_n, cold_ring_mib=round(ring_n * n * per / 2**20, 1))
+        for key, fn in (("cold_graph_ms", lambda grp: woq_linear_group(x, grp)), ("single_calls_cold_graph_ms", lambda grp: [mm(x) for mm in grp])):
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        for grp in ring:
+                            fn(grp)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                keep = []
+                with torch.cuda.graph(graph):
+                    for grp in ring:
+                        keep.append(fn(grp))
+                graph.replay()
+                torch.cuda.synchronize()
+                reps = 5
+                e0.record()
+                for _ in range(reps):
+                    graph.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                row[key] = round(e0.elapsed_time(e1) / (reps * ring_n), 5)
+                del graph, keep
+            except Exception as e:  # pragma: no cover - report, never fake
+                row[key] = None
+                print(f"[bench] group decode timing of {tag} failed: {type(e).__name__}: {e}", file=sys.stderr)
+        if row.get("cold_graph_ms"):
+            row["cold_graph_gbs"] = round(bytes_ / row["cold_graph_ms"] / 1e6, 1)
+            row["cold_graph_frac"] = round(bytes_ / row["cold_graph_ms"] / 1e6 / HBM_PEAK_GBS, 4)
+        if row.get("single_calls_cold_graph_ms"):
+            row["single_calls_cold_graph_frac"] = round(bytes_ / row["single_calls_cold_graph_ms"] / 1e6 / HBM_PEAK_GBS, 4)
+        res.append(row)
+        del ring, m
+        torch.cuda.empty_cache()
+    return res
+
+
 def bench_w8a8_gemm(device, shapes, iters=20):
     """BASELINE config #4's kernel (SmoothQuant W8A8, Llama-2-13B shapes): the whole W8A8Linear forward = activation
     quantisation (HBM-bound) + INT8 MFMA GEMM; `gemm_ms` is the GEMM alone."""
@@ -432,6 +494,17 @@ def bench_ceilings(device):
     e1.record()
     torch.cuda.synchronize()
     triad = 5 * 12.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    # copy ceiling: 1 GiB read + 1 GiB written, every variant of the probe (loads in flight per lane x non-temporal x grid shape), best kept
+    copies = {}
+    for variant in range(16):
+        ops.probe_hbm_copy(a, b, variant)
+        e0.record()
+        for _ in range(3):
+            ops.probe_hbm_copy(a, b, variant)
+        e1.record()
+        torch.cuda.synchronize()
+        copies[variant] = round(3 * 8.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    best = max(copies, key=copies.get)
     del a, b, c
     src = torch.randn(64 * 1024, dtype=torch.bfloat16, device=device)
     sink = torch.zeros(4096 * 256, dtype=torch.float32, device=device)
@@ -444,9 +517,11 @@ def bench_ceilings(device):
     torch.cuda.synchronize()
     mfma = 3 * flops / (e0.elapsed_time(e1) * 1e-3) / 1e12
     torch.cuda.empty_cache()
-    return dict(hbm_stream_triad_gbs=round(triad, 1), hbm_spec_gbs=HBM_PEAK_GBS, bf16_mfma_loop_tflops=round(mfma, 1),
+    return dict(hbm_stream_triad_gbs=round(triad, 1), hbm_copy_gbs=copies[best], hbm_copy_variant=best, hbm_copy_all_variants=copies,
+                hbm_spec_gbs=HBM_PEAK_GBS, bf16_mfma_loop_tflops=round(mfma, 1),
                 bf16_mfma_spec_tflops=BF16_MFMA_PEAK_TFLOPS,
-                note="measured in this run: triad = inc_probe_hbm_triad over 3 x 1 GiB fp32 (12 n bytes per call); MFMA loop = "
+                note="measured in this run: triad = inc_probe_hbm_triad over 3 x 1 GiB fp32 (12 n bytes per call); copy = inc_probe_hbm_copy, 1 GiB "
+                     "read + 1 GiB written, best of its 16 variants (variant = 4 log2(loads in flight per lane) + 2 non-temporal + 1 flat grid); MFMA loop = "
                      "inc_probe_mfma_bf16, 16 waves per CU of back-to-back v_mfma_f32_32x32x16_bf16 on random operands (the chip "
                      "clocks to its power budget: zero operands would read higher); every `frac` in this line is against the spec figures")
 
@@ -874,8 +949,10 @@ def compact_line(full):
     if big:
         roof["gemm_frac_min_M_ge_4096"], roof["gemm_frac_max_M_ge_4096"] = min(big), max(big)
     for r in full.get("dequant_gemv_groups") or []:
-        roof[f"gemv_group_{r['group']}_hbm_frac_cold"] = r["cold_graph_frac"]
-        roof[f"gemv_group_{r['group']}_us_cold"] = round(r["cold_graph_ms"] * 1e3, 2)
+        if r.get("cold_graph_frac") is not None:  # ONE launch for the modules that share x (inc_woq_gemm_multi), cold
+            roof[f"gemv_group_{r['group']}_hbm_frac_cold"] = r["cold_graph_frac"]
+            roof[f"gemv_group_{r['group']}_us_cold"] = round(r["cold_graph_ms"] * 1e3, 2)
+            roof[f"gemv_group_{r['group']}_single_calls_hbm_frac_cold"] = r.get("single_calls_cold_graph_frac")
     per = full.get("per_layer") or {}
     for k, v in per.items():
         if k.startswith("fasterquant_"):
@@ -1171,6 +1248,8 @@ def main():
         if WORKLOAD == "llama2-70b":
             shapes = [(4096, 8192, 8192), (4096, 28672, 8192), (4096, 8192, 28672), (1, 8192, 8192), (1, 28672, 8192), (1, 8192, 28672)]
         result["dequant_gemm"] = bench_dequant_gemm(device, shapes)
+        if WORKLOAD == "llama2-7b":
+            result["dequant_gemv_groups"] = bench_gemv_groups(device)
         note("dequant-GEMM shapes timed")
         result["w8a8_gemm"] = bench_w8a8_gemm(device, [(4096, 5120, 5120), (4096, 13824, 5120), (4096, 5120, 13824)])
         note("W8A8 shapes timed")

@@ -83,10 +83,12 @@ int inc_woq_pack(const void* int_weight, int in_bytes, const float* scales, cons
 /* ---- K2 fused: unpack the optimum layout -------------------------------------------------- *
  * == INCWeightOnlyLinear.unpack (modules.py:377-411): int_weight [N,K] int16 (0..2^bits-1),
  *   zp [N,G] int16 = stored+1, values > 2^bits-1 wrap to 0 (modules.py:407-410).
- *   Either output pointer may be NULL to skip it.
+ *   Either output pointer may be NULL to skip it.  scales_ng (with int_weight; NULL = off): the module's scales [G,N] fp16
+ *   (scales_gn) written as [N,G] in the same launch -- unpack returns `scales.T.contiguous()` (modules.py:382).
  */
 int inc_woq_unpack(const int32_t* qweight, const int32_t* qzeros, int16_t* int_weight, int16_t* zp,
-                   int64_t N, int64_t K, int64_t G, int bits, inc_stream_t stream);
+                   int64_t N, int64_t K, int64_t G, int bits, const uint16_t* scales_gn, uint16_t* scales_ng,
+                   inc_stream_t stream);
 
 /* ---- K3: recover / dequantize ------------------------------------------------------------- *
  * == INCWeightOnlyLinear.recover (modules.py:413-443):
@@ -131,6 +133,22 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
                  const int32_t* qzeros, const int32_t* g_idx, const void* bias, void* y, int64_t M,
                  int64_t N, int64_t K, int64_t G, int group_size, int bits, void* workspace,
                  int64_t workspace_bytes, inc_stream_t stream);
+
+/* Several packed modules that multiply the SAME x, in ONE launch -- the decode path of q / k / v (and of gate / up): n calls of
+ * INCWeightOnlyLinear.forward (modules.py:594-610) on one activation, which the reference issues one F.linear after the other.
+ *   x [M,K] of `xdtype`, M <= 64; module i: qweight[i] [K/8,N[i]], scales[i] [G,N[i]] fp16, qzeros[i] [G,ceil(N[i]/8)], bias[i] [N[i]] of
+ *   `xdtype` or NULL (bias itself may be NULL), y[i] [M,N[i]] of `xdtype`; K, group_size and bits (4) are common, no g_idx.
+ *   The arrays of pointers / sizes live in HOST memory (like inc_gptq_hessian_accum_multi); the state dict is untouched.
+ *   Every 64-column strip is computed exactly as inc_woq_gemm's streaming kernel computes it, so the launch is bit-identical to
+ *   inc_woq_gemm on the N-concatenated module (deterministic: fixed-order split-K sum).  INC_ERR_UNSUPPORTED (nothing launched)
+ *   when the batch is not eligible (n < 2 or > 8, M > 64, bits != 4, a group size that is not a power of two >= 32 or one
+ *   group, N[i] < 64 or N[i] % 4 != 0, K % 32 != 0, unaligned x, or M > 32 on more than 24 Mi weights, where inc_woq_gemm's
+ *   strip kernel is the faster form): call inc_woq_gemm per module then.
+ *   `workspace`: inc_woq_gemm_multi_workspace_bytes bytes; its first 16 KiB are arrival counters with the rules of inc_woq_gemm's. */
+int64_t inc_woq_gemm_multi_workspace_bytes(int n, int64_t M, const int64_t* N, int64_t K);
+int inc_woq_gemm_multi(int n, const void* x, int xdtype, const int32_t* const* qweight, const uint16_t* const* scales,
+                       const int32_t* const* qzeros, const void* const* bias, void* const* y, int64_t M, const int64_t* N,
+                       int64_t K, int group_size, int bits, void* workspace, int64_t workspace_bytes, inc_stream_t stream);
 
 /* ---- K7: group-wise round-to-nearest quantisation ------------------------------------------ *
  * == quant_tensor / qdq_weight_sym / qdq_weight_asym (weight_only/utility.py:272-436, :199, :162).
@@ -387,6 +405,9 @@ int inc_w8a8_gemm(const int8_t* xq, const int8_t* wq, const float* alpha, const 
  * inc_probe_mfma_bf16: `blocks` workgroups x 4 waves x `iters` x 8 v_mfma_f32_32x32x16_bf16 on operands read from `src`
  *   (>= 64 KiB, any non-zero data); *flops_out (host pointer, may be NULL) receives the flops of the launch.            */
 int inc_probe_hbm_triad(float* a, const float* b, const float* c, float s, int64_t n, inc_stream_t stream);
+/* dst <- src: `bytes` read + `bytes` written, 16 bytes per lane; `variant` 0..15 picks loads in flight per lane / non-temporal hints /
+ * grid shape (probe.hip).  The copy ceiling of the chip (guide: 6.29 TB/s) is what the streaming kernels K1-K3 are priced against. */
+int inc_probe_hbm_copy(void* dst, const void* src, int64_t bytes, int variant, inc_stream_t stream);
 int inc_probe_mfma_bf16(const void* src, float* sink, int blocks, int iters, double* flops_out, inc_stream_t stream);
 /* inc_trace_marker: an EMPTY launch of `id` (1..4096) workgroups of 64 threads on `stream`: a phase boundary that a
  *   `rocprofv3 --kernel-trace` timeline shows as inc_trace_marker_kernel with Grid_Size_X = 64 * id (scripts/step_timeline.py). */

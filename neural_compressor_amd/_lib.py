@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinc_mi355x.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 INC_OK = 0
 INC_F32, INC_F16, INC_BF16 = 0, 1, 2
@@ -25,7 +25,7 @@ SIGNATURES = {
     "inc_pack_rows": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, _P]),
     "inc_unpack_rows": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, c_int, _P]),
     "inc_woq_pack": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P]),
-    "inc_woq_unpack": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_int, _P]),
+    "inc_woq_unpack": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_int, _P, _P, _P]),
     "inc_woq_dequant": (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_int64, c_int64, c_int, c_int, _P]),
     "inc_dequant_ints": (c_int, [_P, _P, c_int, _P, _P, _P, c_int, c_int64, c_int64, c_int64, c_int, _P]),
     "inc_woq_gemm_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
@@ -33,6 +33,8 @@ SIGNATURES = {
         c_int,
         [_P, c_int, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, _P],
     ),
+    "inc_woq_gemm_multi_workspace_bytes": (c_int64, [c_int, c_int64, _P, c_int64]),
+    "inc_woq_gemm_multi": (c_int, [c_int, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int, _P, c_int64, _P]),
     "inc_groupwise_quant": (
         c_int,
         [_P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, _P],
@@ -70,6 +72,7 @@ SIGNATURES = {
     "inc_gptq_lazy_update": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, _P]),
     "inc_gptq_lazy_update_cols": (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int64, c_int64, _P]),
     "inc_probe_hbm_triad": (c_int, [_P, _P, _P, c_float, c_int64, _P]),
+    "inc_probe_hbm_copy": (c_int, [_P, _P, c_int64, c_int, _P]),
     "inc_probe_mfma_bf16": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "inc_trace_marker": (c_int, [c_int, _P]),
     "inc_gptq_quantize_layer": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int, _P, c_int64, c_int64, c_int, c_int, c_int,

@@ -1094,19 +1094,19 @@ constexpr int VS = 8;   // largest VSTEPS (sizes the workspace)
 // MB = 16-row blocks of x per workgroup (M <= 16 * MB): batched decode (16 < M <= 64) streams the packed weights ONCE like the
 // M <= 16 case -- every dequantised B fragment feeds MB MFMAs -- instead of parking a 256-row tile that is mostly clamped rows.
 // NT (harness A/B, same results): the packed-weight requests carry the non-temporal hint -- every word is read once by one CU
+// The body of one (64-column strip, K-slice) workgroup: `counter` is the strip's arrival counter, `partial` the module's slabs.
 template <bool IS_BF16, bool G128, int VSTEPS, int MB, bool NT = false>
-__global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
+__device__ __forceinline__ void woq_gemv_w4_body(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
-    float* __restrict__ partial, unsigned* __restrict__ counters, int M, int64_t N, int64_t K, int64_t NW,
-    int64_t G, int g_shift, int splitk) {
+    float* __restrict__ partial, unsigned* __restrict__ counter, int M, int64_t N, int64_t K, int64_t NW,
+    int g_shift, int splitk, int strip, int slice) {
   constexpr int VS = VSTEPS;  // shadows the file-level maximum inside this kernel
   constexpr int ROWS = 16 * MB;
   constexpr int NOUT = ROWS * 64 / 256;  // outputs per thread of the strip
   __shared__ float red[4 * ROWS * 65];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float inv_u = fp8_unit_inverse();
-  const int strip = blockIdx.x, slice = blockIdx.y;
   const int jn = lane & 15, oct = lane >> 4;
   const int64_t n0 = (int64_t)strip * 64;
   int64_t ncol = n0 + 4 * jn;
@@ -1211,9 +1211,9 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      const unsigned ticket = __hip_atomic_fetch_add(&counters[strip], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)(splitk - 1);
-      if (last) __hip_atomic_store(&counters[strip], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
+      if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
       red[0] = last ? 1.f : 0.f;
     }
     __syncthreads();
@@ -1242,6 +1242,47 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
       const float v = sum[i] + (bias ? cvt16<IS_BF16>(braw[i]) : 0.f);
       y[out_off[i]] = IS_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
     }
+}
+
+template <bool IS_BF16, bool G128, int VSTEPS, int MB, bool NT = false>
+__global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
+    const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
+    const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
+    float* __restrict__ partial, unsigned* __restrict__ counters, int M, int64_t N, int64_t K, int64_t NW,
+    int64_t G, int g_shift, int splitk) {
+  woq_gemv_w4_body<IS_BF16, G128, VSTEPS, MB, NT>(x, qweight, scales, qzeros, bias, y, partial, counters + blockIdx.x, M, N, K, NW, g_shift, splitk,
+                                                 (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Several packed modules that multiply the SAME x (q / k / v of an attention block; gate / up of an MLP) in ONE launch
+// (inc_woq_gemm_multi): a decode call of one module is ~2 us of streaming behind ~5 us of launch boundary, first-byte latency and
+// split-K hand-off, and the modules of a group are independent given x.  The strips of the modules occupy consecutive ranges of
+// blockIdx.x; every strip runs exactly the body above on its own module's tensors -> bit-identical to the single launches.
+constexpr int GEMV_MAX_BATCH = 8;
+struct GemvBatch {
+  const uint32_t* qweight[GEMV_MAX_BATCH];
+  const uint16_t* scales[GEMV_MAX_BATCH];
+  const uint32_t* qzeros[GEMV_MAX_BATCH];
+  const uint16_t* bias[GEMV_MAX_BATCH];
+  uint16_t* y[GEMV_MAX_BATCH];
+  int64_t N[GEMV_MAX_BATCH];
+  int64_t part_off[GEMV_MAX_BATCH];  // first float of the module's split-K slabs in the workspace
+  int first[GEMV_MAX_BATCH + 1];     // first strip of every module, then the number of strips
+  int n;
+};
+
+template <bool IS_BF16, bool G128, int VSTEPS, int MB>
+__global__ __launch_bounds__(256) void woq_gemv_w4_multi_kernel(GemvBatch args, const uint16_t* __restrict__ x, float* __restrict__ partial,
+                                                                unsigned* __restrict__ counters, int M, int64_t K, int g_shift, int splitk) {
+  const int b = (int)blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < GEMV_MAX_BATCH; ++i)
+    if (i < args.n && b >= args.first[i]) p = i;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const int64_t N = args.N[p];
+  woq_gemv_w4_body<IS_BF16, G128, VSTEPS, MB>(x, args.qweight[p], args.scales[p], args.qzeros[p], args.bias[p], args.y[p], partial + args.part_off[p],
+                                              counters + b, M, N, K, (N + 7) / 8, g_shift, splitk, b - args.first[p], (int)blockIdx.y);
 }
 
 // =============================================================================================
@@ -2048,6 +2089,85 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     if (bf) splitk_reduce_kernel<true><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, slices);
     else splitk_reduce_kernel<false><<<(unsigned)rb, 256, 0, s>>>(part, bp, yp, M, N, slices);
   }
+  INC_LAUNCH_RETURN();
+}
+
+// ---- modules that share x, one launch (decode: q / k / v, gate / up) -----------------------------------------------------------
+// plan of the batched streaming launch: strips of 64 columns per module, VSTEPS by the rule inc_woq_gemm applies to ONE module with
+// the modules' columns together -> the launch is bit-identical to inc_woq_gemm on the N-concatenated module (strips are independent)
+static bool gemv_multi_plan(int n, int64_t M, const int64_t* N, int64_t K, int group_size, int bits, int* g_shift_out, int* vsteps_out,
+                            int* splitk_out, int64_t* strips_out) {
+  if (n < 2 || n > GEMV_MAX_BATCH || bits != 4 || M < 1 || M > GEMV_MAX_M || K <= 0 || (K % 32) != 0) return false;
+  int g_shift = -2;
+  if (group_size >= K) g_shift = -1;
+  else if (group_size >= 32 && (group_size & (group_size - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < group_size) ++g_shift; }
+  if (g_shift == -2) return false;
+  int64_t strips = 0;
+  for (int i = 0; i < n; ++i) {
+    if (N[i] < 64 || (N[i] % 4) != 0) return false;
+    strips += ceil_div64(N[i], 64);
+  }
+  if (strips * 4 > WS_COUNTER_BYTES) return false;
+  if (M > 16 && ceil_div64(K, 32 * 4 * 4) > 64) return false;  // (row-blocked form: the single call takes a tile kernel there)
+  int64_t ntot = 0;
+  for (int i = 0; i < n; ++i) ntot += N[i];
+  if (M > 32 && ntot * K > ((int64_t)24 << 20)) return false;  // inc_woq_gemm prefers the strip kernel there (21 vs 29 us at 64 x 11008 x 4096)
+  const bool vs4 = M > 16 || (strips * ceil_div64(K, 32 * 8 * 4) < 512 && ceil_div64(K, 32 * 4 * 4) <= 64);
+  *g_shift_out = g_shift;
+  *vsteps_out = vs4 ? 4 : 8;
+  *splitk_out = (int)ceil_div64(K, 32 * (vs4 ? 4 : 8) * 4);
+  *strips_out = strips;
+  return true;
+}
+
+int64_t inc_woq_gemm_multi_workspace_bytes(int n, int64_t M, const int64_t* N, int64_t K) {
+  if (n < 1 || !N) return 0;
+  int64_t ntot = 0;
+  for (int i = 0; i < n; ++i) ntot += N[i];
+  return WS_COUNTER_BYTES + ceil_div64(K, 32 * 4 * 4) * M * ntot * 4;  // 4 steps per wave: the most slices either form uses
+}
+
+int inc_woq_gemm_multi(int n, const void* x, int xdtype, const int32_t* const* qweight, const uint16_t* const* scales,
+                       const int32_t* const* qzeros, const void* const* bias, void* const* y, int64_t M, const int64_t* N, int64_t K,
+                       int group_size, int bits, void* workspace, int64_t workspace_bytes, inc_stream_t stream) {
+  INC_CHECK_ARG(x && qweight && scales && qzeros && y && N && n > 0 && M > 0 && K > 0 && group_size > 0);
+  if (!(xdtype == INC_BF16 || xdtype == INC_F16)) return INC_ERR_UNSUPPORTED;
+  int g_shift, vsteps, splitk;
+  int64_t strips;
+  if (!gemv_multi_plan(n, M, N, K, group_size, bits, &g_shift, &vsteps, &splitk, &strips) || (reinterpret_cast<uintptr_t>(x) & 15) != 0)
+    return INC_ERR_UNSUPPORTED;  // nothing launched: the caller issues inc_woq_gemm per module
+  GemvBatch args;
+  args.n = n;
+  int64_t off = 0;
+  int first = 0;
+  for (int i = 0; i < n; ++i) {
+    INC_CHECK_ARG(qweight[i] && scales[i] && qzeros[i] && y[i]);
+    args.qweight[i] = (const uint32_t*)qweight[i];
+    args.scales[i] = scales[i];
+    args.qzeros[i] = (const uint32_t*)qzeros[i];
+    args.bias[i] = bias ? (const uint16_t*)bias[i] : nullptr;
+    args.y[i] = (uint16_t*)y[i];
+    args.N[i] = N[i];
+    args.part_off[i] = off;
+    args.first[i] = first;
+    off += (int64_t)splitk * M * N[i];
+    first += (int)ceil_div64(N[i], 64);
+  }
+  for (int i = n; i <= GEMV_MAX_BATCH; ++i) args.first[i] = first;
+  for (int i = n; i < GEMV_MAX_BATCH; ++i) { args.qweight[i] = nullptr; args.scales[i] = nullptr; args.qzeros[i] = nullptr; args.bias[i] = nullptr; args.y[i] = nullptr; args.N[i] = 0; args.part_off[i] = 0; }
+  if (!workspace || workspace_bytes < WS_COUNTER_BYTES + off * 4) return INC_ERR_WORKSPACE;
+  hipStream_t s = inc_s(stream);
+  unsigned* counters = (unsigned*)workspace;
+  float* part = (float*)((char*)workspace + WS_COUNTER_BYTES);
+  const uint16_t* xp = (const uint16_t*)x;
+  dim3 grid((unsigned)strips, (unsigned)splitk);
+  const bool bf = xdtype == INC_BF16, g128 = g_shift == -1 || g_shift >= 7;
+#define INC_GEMVM(F, GG, V, B) woq_gemv_w4_multi_kernel<F, GG, V, B><<<grid, 256, 0, s>>>(args, xp, part, counters, (int)M, K, g_shift, splitk)
+#define INC_GEMVM2(F, GG) { if (M > 32) INC_GEMVM(F, GG, 4, 4); else if (M > 16) INC_GEMVM(F, GG, 4, 2); else if (vsteps == 4) INC_GEMVM(F, GG, 4, 1); else INC_GEMVM(F, GG, 8, 1); }
+  if (bf) { if (g128) INC_GEMVM2(true, true) else INC_GEMVM2(true, false) }
+  else { if (g128) INC_GEMVM2(false, true) else INC_GEMVM2(false, false) }
+#undef INC_GEMVM2
+#undef INC_GEMVM
   INC_LAUNCH_RETURN();
 }
 

@@ -153,7 +153,8 @@ template <int BITS, bool VEC>
 __global__ __launch_bounds__(256) void woq_unpack_qweight_kernel(const uint32_t* __restrict__ qweight,
                                                                  int16_t* __restrict__ out, int64_t N,
                                                                  int64_t K, int64_t KW, const uint32_t* __restrict__ qzeros,
-                                                                 int16_t* __restrict__ zp, int64_t G, int64_t NW) {
+                                                                 int16_t* __restrict__ zp, int64_t G, int64_t NW,
+                                                                 const uint16_t* __restrict__ scales_gn, uint16_t* __restrict__ scales_ng) {
   constexpr int NP = 32 / BITS;
   constexpr uint32_t MASK = (1u << BITS) - 1u;
   __shared__ uint32_t tile[TILE * TILE_LD];
@@ -215,6 +216,13 @@ __global__ __launch_bounds__(256) void woq_unpack_qweight_kernel(const uint32_t*
       }
     }
   }
+  if (scales_ng) {  // scales [G,N] -> [N,G] (modules.py:382: unpack hands the scales back row-major per output channel), same share
+    const int ng = (int)((G - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    for (int i = threadIdx.x; i < ng * TILE; i += 256) {
+      const int64_t g = blockIdx.x + (int64_t)(i / TILE) * gridDim.x, nn = n0 + (i % TILE);
+      if (nn < N) scales_ng[nn * G + g] = scales_gn[g * N + nn];
+    }
+  }
 }
 
 // qzeros [G,NW] -> zp [N,G] int16: stored+1, wrap values above maxq to 0 (modules.py:407-410)
@@ -231,6 +239,101 @@ __global__ void woq_unpack_qzeros_kernel(const uint32_t* __restrict__ qzeros, in
     if (z > mask) z = 0;
     zp[i] = static_cast<int16_t>(z);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// 4-bit words straight from registers (round 6): unpack AND recover without LDS, every access a full 128-byte line
+// ------------------------------------------------------------------------------------------
+// A packed word holds 8 consecutive k of ONE output row n, and the words of a packed row kw are contiguous along n.  A wave takes a
+// patch of 32 n x 8 packed rows (64 k): lane (quad = lane & 7, r = lane >> 3) loads the uint4 of rows n = n0 + 4 quad .. + 3 at packed
+// row kw0 + r -- per packed row the eight quads read 128 contiguous bytes -- and writes, for each of its four rows, the word's 8 outputs
+// as ONE 16-byte store at out[n][8 kw]: the eight r-lanes of a (quad, row) write 128 contiguous bytes.  No transpose through LDS, no
+// barrier, 16 bytes per lane in both directions; the patches of a wave are independent, so all of its loads are issued before the first
+// store.  The LDS-transposing kernels below (any width, g_idx, ragged shapes) measured 0.24-0.42 of the HBM peak on cold tensors; they
+// stay the general path.  MODE 0: int16 codes (unpack, modules.py:377-411; zero points like woq_unpack_qweight_kernel); MODE 1 / 2:
+// fp16 / bf16 weights (recover, modules.py:413-443: int8(q - z) * s exactly in fp32, rounded once -- the same arithmetic as
+// woq_dequant_kernel, bit for bit).
+typedef uint32_t w4d_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int W4D_PATCHES = 2;  // patches (64 k each) per wave: with group_size 128 a wave owns one group of its 32 rows
+template <int MODE>
+__global__ __launch_bounds__(256) void woq_w4_direct_kernel(const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
+                                                            const uint32_t* __restrict__ qzeros, uint16_t* __restrict__ out, int64_t N, int64_t K,
+                                                            int64_t KW, int64_t NW, int group_size, int16_t* __restrict__ zp, int64_t G,
+                                                            const uint16_t* __restrict__ scales_gn, uint16_t* __restrict__ scales_ng, int side_blocks) {
+  if constexpr (MODE == 0) {
+    // the zero points and the [G,N] -> [N,G] scales of a 32-row strip are the work of ONE extra workgroup of that strip (the last index
+    // of grid.x when side_blocks = 1): behind a weight patch they would add a dependent load -> store chain to every workgroup's life
+    if (side_blocks && blockIdx.x == gridDim.x - 1) {
+      const int64_t n0 = (int64_t)blockIdx.y * 32;
+      for (int64_t i = threadIdx.x; i < G * 32; i += 256) {
+        const int64_t g = i / 32, nn = n0 + (i % 32);
+        if (nn >= N) continue;
+        if (zp) {
+          const uint32_t word = qzeros[g * NW + nn / 8];
+          uint32_t z = ((word >> (4 * (uint32_t)(nn % 8))) & 15u) + 1u;
+          if (z > 15u) z = 0;
+          zp[nn * G + g] = static_cast<int16_t>(z);
+        }
+        if (scales_ng) scales_ng[nn * G + g] = scales_gn[g * N + nn];
+      }
+      return;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int quad = lane & 7, r = lane >> 3;
+  const int64_t n = (int64_t)blockIdx.y * 32 + 4 * quad;
+  const int64_t kwb = ((int64_t)blockIdx.x * 4 + wave) * (8 * W4D_PATCHES);
+  uint4 w[W4D_PATCHES];
+  uint2 sraw[W4D_PATCHES];
+  uint32_t zraw[W4D_PATCHES];
+  bool live[W4D_PATCHES];
+#pragma unroll
+  for (int p = 0; p < W4D_PATCHES; ++p) {
+    const int64_t kw = kwb + 8 * p + r;
+    live[p] = n < N && kw < KW;
+    const int64_t kwc = live[p] ? kw : 0, nc = live[p] ? n : 0;
+    const w4d_u32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const w4d_u32x4*>(qweight + kwc * N + nc));  // every word is read once
+    w[p] = make_uint4(wv.x, wv.y, wv.z, wv.w);
+    if constexpr (MODE != 0) {
+      const int64_t g = (kwc * 8) / group_size;
+      sraw[p] = *reinterpret_cast<const uint2*>(scales + g * N + nc);
+      zraw[p] = qzeros[g * NW + (nc >> 3)];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < W4D_PATCHES; ++p) {
+    if (!live[p]) continue;
+    const int64_t kw = kwb + 8 * p + r;
+    const uint32_t ww[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t o[4];
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) o[h] = ((ww[c] >> (8 * h)) & 15u) | (((ww[c] >> (8 * h + 4)) & 15u) << 16);
+      } else {
+        const uint32_t sw = c < 2 ? sraw[p].x : sraw[p].y;
+        const float sc = f16_bits_to_f32((uint16_t)(sw >> (16 * (c & 1))));
+        uint32_t zz = ((zraw[p] >> (4 * (uint32_t)((n + c) & 7))) & 15u) + 1u;
+        const int32_t z = zz > 15u ? 0 : (int32_t)zz;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float v0 = (float)(int8_t)((int32_t)((ww[c] >> (8 * h)) & 15u) - z) * sc;
+          const float v1 = (float)(int8_t)((int32_t)((ww[c] >> (8 * h + 4)) & 15u) - z) * sc;
+          o[h] = MODE == 1 ? ((uint32_t)f32_to_f16_bits(v0) | ((uint32_t)f32_to_f16_bits(v1) << 16))
+                           : ((uint32_t)f32_to_bf16_bits(v0) | ((uint32_t)f32_to_bf16_bits(v1) << 16));
+        }
+      }
+      const w4d_u32x4 ov = {o[0], o[1], o[2], o[3]};
+      __builtin_nontemporal_store(ov, reinterpret_cast<w4d_u32x4*>(out + (n + c) * K + kw * 8));  // written once, read by a later kernel
+    }
+  }
+}
+
+// the direct form needs whole words inside one group, 16-byte rows on both sides and four output rows per lane
+static bool w4_direct_ok(const void* qweight, const void* out, int64_t N, int64_t K, int group_size, int bits, const void* g_idx) {
+  return bits == 4 && !g_idx && (N % 4) == 0 && (K % 8) == 0 && (group_size % 8) == 0 && ((reinterpret_cast<uintptr_t>(qweight) & 15) == 0) &&
+         ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -401,7 +504,7 @@ extern "C" {
 // 3: inc_mse_accumulate sums in fp64 in a fixed order (workspace argument); inc_debug_set_small_tiles left the library
 // 4: inc_gptq_quantize_layer (the column loop as one call)
 // 8: + inc_codebook_quant_with_scale (quantize_4bit with the caller's scale)
-int inc_abi_version(void) { return 8; }
+int inc_abi_version(void) { return 9; }
 const char* inc_target_arch(void) { return "gfx950"; }
 const char* inc_error_string(int code) {
   switch (code) {
@@ -495,20 +598,26 @@ int inc_woq_pack(const void* int_weight, int in_bytes, const float* scales, cons
 }
 
 int inc_woq_unpack(const int32_t* qweight, const int32_t* qzeros, int16_t* int_weight, int16_t* zp,
-                   int64_t N, int64_t K, int64_t G, int bits, inc_stream_t stream) {
-  INC_CHECK_ARG(N > 0 && K > 0 && G > 0);
+                   int64_t N, int64_t K, int64_t G, int bits, const uint16_t* scales_gn, uint16_t* scales_ng, inc_stream_t stream) {
+  INC_CHECK_ARG(N > 0 && K > 0 && G > 0 && (!scales_ng || (scales_gn && int_weight)));
   if (bits < 1 || bits > 8) return INC_ERR_UNSUPPORTED;
   hipStream_t s = inc_s(stream);
   const int n_pack = 32 / bits;
   const int64_t KW = ceil_div64(K, n_pack), NW = ceil_div64(N, n_pack);
   const uint32_t* qzp = reinterpret_cast<const uint32_t*>(qzeros);
   if (zp) INC_CHECK_ARG(qzeros);
-  if (int_weight) {
+  if (int_weight && w4_direct_ok(qweight, int_weight, N, K, 8, bits, nullptr) && ceil_div64(N, 32) <= 65535) {
+    INC_CHECK_ARG(qweight);
+    const int side = (zp || scales_ng) ? 1 : 0;
+    dim3 grid((unsigned)ceil_div64(KW, 4 * 8 * W4D_PATCHES) + side, (unsigned)ceil_div64(N, 32));
+    woq_w4_direct_kernel<0><<<grid, 256, 0, s>>>(reinterpret_cast<const uint32_t*>(qweight), nullptr, qzp, reinterpret_cast<uint16_t*>(int_weight), N, K, KW, NW,
+                                                8, zp, G, scales_gn, scales_ng, side);
+  } else if (int_weight) {
     INC_CHECK_ARG(qweight);
     dim3 grid((unsigned)ceil_div64(KW, TILE), (unsigned)ceil_div64(N, TILE));
     const bool vec = (n_pack % 8 == 0 || n_pack == 4) && (K % n_pack == 0) && (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(int_weight) & 15) == 0);
     const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
-#define INC_UNPACK(B, V) woq_unpack_qweight_kernel<B, V><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW, qzp, zp, G, NW)
+#define INC_UNPACK(B, V) woq_unpack_qweight_kernel<B, V><<<grid, 256, 0, s>>>(qw, int_weight, N, K, KW, qzp, zp, G, NW, scales_gn, scales_ng)
     switch (bits) {
       case 4: if (vec) INC_UNPACK(4, true); else INC_UNPACK(4, false); break;
       case 8: if (vec) INC_UNPACK(8, true); else INC_UNPACK(8, false); break;
@@ -537,6 +646,13 @@ int inc_woq_dequant(const int32_t* qweight, const uint16_t* scales, const int32_
   dim3 grid((unsigned)ceil_div64(K, (DQ_KT / n_pack) * n_pack), (unsigned)ceil_div64(N, TILE));
   const uint32_t* qw = reinterpret_cast<const uint32_t*>(qweight);
   const uint32_t* qz = reinterpret_cast<const uint32_t*>(qzeros);
+  if ((out_dtype == INC_F16 || out_dtype == INC_BF16) && w4_direct_ok(qweight, out, N, K, group_size, bits, g_idx) && (N % 8) == 0 &&
+      ((reinterpret_cast<uintptr_t>(scales) & 7) == 0) && ceil_div64(N, 32) <= 65535) {
+    dim3 dgrid((unsigned)ceil_div64(KW, 4 * 8 * W4D_PATCHES), (unsigned)ceil_div64(N, 32));
+    if (out_dtype == INC_F16) woq_w4_direct_kernel<1><<<dgrid, 256, 0, s>>>(qw, scales, qz, (uint16_t*)out, N, K, KW, NW, group_size, nullptr, G, nullptr, nullptr, 0);
+    else woq_w4_direct_kernel<2><<<dgrid, 256, 0, s>>>(qw, scales, qz, (uint16_t*)out, N, K, KW, NW, group_size, nullptr, G, nullptr, nullptr, 0);
+    INC_LAUNCH_RETURN();
+  }
 #define INC_DQ_LAUNCH(B, D) \
   woq_dequant_kernel<B, D><<<grid, 256, 0, s>>>(qw, scales, qz, g_idx, (typename out_elem<D>::type*)out, N, K, KW, NW, group_size)
 #define INC_DQ_BITS(D)                                                                                                       \

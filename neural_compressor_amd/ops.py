@@ -118,17 +118,22 @@ def woq_pack(int_weight, scales, zp, bits, shift, qweight=None, qzeros=None, sca
     return qweight, qzeros, scales_out
 
 
-def woq_unpack(qweight, qzeros, N, K, G, bits, want_weight=True, want_zp=True):
-    """== INCWeightOnlyLinear.unpack (modules.py:377-411): (int_weight [N,K] int16, zp [N,G] int16)."""
-    dev = _dev(qweight, qzeros)
+def woq_unpack(qweight, qzeros, N, K, G, bits, want_weight=True, want_zp=True, scales=None):
+    """== INCWeightOnlyLinear.unpack (modules.py:377-411): (int_weight [N,K] int16, zp [N,G] int16).  `scales` [G,N] fp16 (optional,
+    with the weights): a third result, the scales as [N,G] (`scales.T.contiguous()`, modules.py:382), written by the same launch."""
+    dev = _dev(qweight, qzeros, scales)
     iw = torch.empty((N, K), dtype=torch.int16, device=dev) if want_weight else None
     zp = torch.empty((N, G), dtype=torch.int16, device=dev) if want_zp else None
+    sc_t = None
+    if scales is not None:
+        assert want_weight and scales.dtype == torch.float16 and scales.shape == (G, N) and scales.is_contiguous()
+        sc_t = torch.empty((N, G), dtype=torch.float16, device=dev)
     with torch.cuda.device(dev):
         check(
-            lib.inc_woq_unpack(_ptr(qweight), _ptr(qzeros), _ptr(iw), _ptr(zp), N, K, G, bits, _stream()),
+            lib.inc_woq_unpack(_ptr(qweight), _ptr(qzeros), _ptr(iw), _ptr(zp), N, K, G, bits, _ptr(scales), _ptr(sc_t), _stream()),
             "inc_woq_unpack",
         )
-    return iw, zp
+    return (iw, zp) if scales is None else (iw, zp, sc_t)
 
 
 def awq_repack(awq_qweight, awq_qzeros, bits=4):
@@ -320,6 +325,63 @@ class WoqGemmCall:
         return y
 
 
+class WoqGemmGroupCall:
+    """inc_woq_gemm_multi for modules that multiply the SAME activation (q / k / v; gate / up): ONE launch instead of one per module
+    (a decode call of one module is ~2 us of weight streaming behind ~5 us of launch boundary and hand-off).  The state dict is
+    untouched: the call holds the modules' packed buffers by reference and hands the library host arrays of their addresses.
+    `parts` = [(qweight, scales, qzeros, bias or None, N), ...]; K, group_size, bits common.  __call__(x2d) -> [y_i [M, N_i]], or None
+    when the library declines the batch (nothing launched: the owner then calls the modules one by one)."""
+
+    def __init__(self, parts, K, group_size, bits, dtype):
+        import ctypes
+
+        if dtype is not torch.bfloat16 and dtype is not torch.float16:
+            raise TypeError("woq_gemm computes in bf16 or fp16")
+        self.n = len(parts)
+        self.dev = _dev(*[t for p in parts for t in p[:4]])
+        self.dev_index = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        self.K, self.gs, self.bits, self.dtype = K, group_size, bits, dtype
+        self.dt = INC_BF16 if dtype is torch.bfloat16 else INC_F16
+        bias = [None if p[3] is None else (p[3] if p[3].dtype == dtype else p[3].to(dtype)) for p in parts]
+        self.keep = (parts, bias)
+        self.versions = tuple(None if t is None else t._version for p in parts for t in p[:4])
+        self.Ns = [int(p[4]) for p in parts]
+        n = self.n
+        self.qw = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in parts])
+        self.sc = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in parts])
+        self.qz = (ctypes.c_void_p * n)(*[p[2].data_ptr() for p in parts])
+        self.bi = (ctypes.c_void_p * n)(*[_ptr(b) for b in bias]) if any(b is not None for b in bias) else None
+        self.Narr = (ctypes.c_int64 * n)(*self.Ns)
+        self.yarr = (ctypes.c_void_p * n)()
+        self.need = {}
+
+    def current(self, parts):
+        mine = self.keep[0]
+        return (len(parts) == len(mine) and all(a is b for p, q in zip(parts, mine) for a, b in zip(p[:4], q[:4]))
+                and self.versions == tuple(None if t is None else t._version for p in parts for t in p[:4]))
+
+    def __call__(self, x2d):
+        M = x2d.shape[0]
+        need = self.need.get(M)
+        if need is None:
+            need = self.need[M] = lib.inc_woq_gemm_multi_workspace_bytes(self.n, M, self.Narr, self.K)
+        ys = [torch.empty((M, N), dtype=self.dtype, device=self.dev) for N in self.Ns]
+        for i, y in enumerate(ys):
+            self.yarr[i] = y.data_ptr()
+        idx = self.dev_index
+        stream = _raw_stream(idx)
+        buf = _ws_cache.get((idx, stream))
+        if buf is None or buf.numel() < need:
+            buf = _workspace(self.dev, need)
+        with torch.cuda.device(self.dev):
+            rc = lib.inc_woq_gemm_multi(self.n, x2d.data_ptr(), self.dt, self.qw, self.sc, self.qz, self.bi, self.yarr, M, self.Narr, self.K,
+                                        self.gs, self.bits, buf.data_ptr(), buf.numel(), stream)
+        if rc == -2:  # INC_ERR_UNSUPPORTED: nothing was launched
+            return None
+        check(rc, "inc_woq_gemm_multi")
+        return ys
+
+
 # ---------------------------------------------------------------------------------------------------
 # K7 group-wise RTN
 # ---------------------------------------------------------------------------------------------------
@@ -374,7 +436,17 @@ def codebook_quant(w, values, codes, group_size, quantile=1.0, return_int=False,
     cds = (ctypes.c_int32 * n)(*[int(c) for c in codes])
     scale_in = None
     if scale is not None:
-        scale_in = torch.broadcast_to(scale.to(device=dev, dtype=torch.float32).reshape(scale.shape[0], -1), (N, G)).contiguous()
+        # anything the reference's `tensor.div_(scale)` broadcasts against the grouped weight [N * G, group_size] (utility.py:127-128): a
+        # per-tensor scalar (0-dim or one element), one value per row [N] / [N,1], or the full [N,G] table.  The kernel divides in fp32
+        # (the reference divides in the promoted dtype of weight and scale; equal for fp32 scales, one rounding apart for 16-bit ones)
+        sc32 = scale.to(device=dev, dtype=torch.float32)
+        if sc32.numel() == 1:
+            sc32 = sc32.reshape(1, 1)
+        elif sc32.dim() < 2:
+            sc32 = sc32.reshape(-1, 1)
+        else:
+            sc32 = sc32.reshape(sc32.shape[0], -1)
+        scale_in = torch.broadcast_to(sc32, (N, G)).contiguous()
     scale = torch.empty((N, G), dtype=torch.float32, device=dev)
     if return_int:
         iout = torch.empty((N, K), dtype=torch.int32, device=dev)
@@ -575,6 +647,16 @@ def probe_hbm_triad(a, b, c, s):
     dev = _dev(a, b, c)
     with torch.cuda.device(dev):
         check(lib.inc_probe_hbm_triad(_ptr(a), _ptr(b), _ptr(c), float(s), a.numel(), _stream()), "inc_probe_hbm_triad")
+
+
+def probe_hbm_copy(dst, src, variant=0):
+    """dst <- src (same byte count, 16-byte aligned): the chip's copy ceiling for bench.py; `variant` see inc_probe_hbm_copy."""
+    dev = _dev(dst, src)
+    nbytes = src.numel() * src.element_size()
+    assert nbytes == dst.numel() * dst.element_size() and nbytes % 16 == 0
+    with torch.cuda.device(dev):
+        check(lib.inc_probe_hbm_copy(_ptr(dst), _ptr(src), nbytes, int(variant), _stream()), "inc_probe_hbm_copy")
+    return dst
 
 
 def probe_mfma_bf16(src, sink, blocks, iters):

@@ -315,7 +315,7 @@ class HessianAccumulator:
             x, version = self._direct
             if x._version != version:
                 raise RuntimeError("a Linear's input was modified in place before its Hessian update was launched; "
-                                   "set INC_MI355X_HESSIAN_ZERO_COPY=0 for this model")
+                                   "set HessianAccumulator.ZERO_COPY = False for this model")
         else:
             x = self._stage[: self._fill]
             if self._probe is not None:
@@ -512,6 +512,19 @@ class GPTQ:
     def add_batch(self, inp, out=None):
         self.acc.add_batch(inp)
 
+    @staticmethod
+    def check_hybrid_order(columns, groupsize, act_order, static_groups):
+        """What hybrid_order requires (gptq.py:1203-1209, 1403-1461), checked BEFORE any factorisation or factor exchange: the block
+        driver calls it when the solvers are configured, so every rank raises at the same point and no Hessian is factorised for a
+        solve that cannot run."""
+        assert not act_order, "Error: hybrid_act_order is not allowed with act_order"  # (gptq.py:1204)
+        if static_groups:
+            raise NotImplementedError("hybrid_order with static_groups: the reference looks the groups' parameters up by PERMUTED "
+                                      "position there (gptq.py:1273-1277 take idx from act_order's perm only)")
+        if groupsize == -1 or (groupsize < columns and columns % int(groupsize) != 0):
+            raise ValueError("hybrid_order needs a group size that divides the number of columns (the reference's permutation covers "
+                             "columns // groupsize whole groups, gptq.py:1403-1461)")
+
     lookahead = True  # the column loop's second stream (bit-identical either way; tests compare)
 
     def column_loop(self, w32, Hinv, scale, zero, loop_scale, loop_zero, codes, Q, gs, kernel_gs, blocksize, bits, sym, dynamic_groups, mse):
@@ -538,10 +551,7 @@ class GPTQ:
         if fp8_aware:
             raise NotImplementedError("fp8_aware (INT4 weights pre-scaled for Gaudi's fp8 matrix units) is a Gaudi W4A8 option outside the MI355X scope")
         if hybrid_order:
-            assert not act_order, "Error: hybrid_act_order is not allowed with act_order"  # (gptq.py:1204)
-            if static_groups:
-                raise NotImplementedError("hybrid_order with static_groups: the reference looks the groups' parameters up by PERMUTED "
-                                          "position there (gptq.py:1273-1277 take idx from act_order's perm only)")
+            self.check_hybrid_order(self.columns, groupsize, act_order, static_groups)
         bits = int(self.cfg.get("bits", 4))
         sym = bool(self.cfg.get("sym", False))
         mse = bool(self.cfg.get("mse", False))  # GPTQConfig(use_mse_search=True): shrink-grid search in find_params
@@ -564,9 +574,6 @@ class GPTQ:
         N = W.shape[0]
 
         gs = K if (groupsize == -1 or groupsize >= K) else int(groupsize)
-        if hybrid_order and (groupsize == -1 or K % gs != 0):
-            raise ValueError("hybrid_order needs a group size that divides the number of columns (the reference's permutation covers "
-                             "columns // groupsize whole groups, gptq.py:1403-1461)")
         Hinv, dead, perm = self.acc.inverse_factor(percdamp, act_order, gs if hybrid_order else 0)
         G = math.ceil(K / gs)
         scale = torch.empty((N, G), dtype=torch.float32, device=W.device)
@@ -1417,6 +1424,9 @@ class RAWGPTQuantizer(object):
                 solvers[name] = GPTQ(layer, device=self.device)
                 solvers[name].defer_check = True  # checked once per group of solves below
                 solvers[name].configure(self.get_layer_config(self.get_full_layer_name(name, block_idx)))
+                cfg_ = solvers[name].cfg
+                if cfg_.get("hybrid_order", False):  # before the capture pass, the factorisations and (multi-GPU) the factor exchange
+                    GPTQ.check_hybrid_order(solvers[name].columns, cfg_.get("group_size", -1), cfg_.get("act_order", False), cfg_.get("static_groups", False))
             # Step 2.3: hooks feeding the Hessians (reference :670-688).  Layers that receive the very same input
             # tensor in a forward (q/k/v, gate/up) share one accumulator instead of recomputing X^T X.
             live, alias = {}, {}

@@ -227,8 +227,11 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         N, K = self.out_features, self.in_features
         if self.use_optimum_format:
             G = self.scales.shape[0]
-            iw, zp = ops.woq_unpack(self.qweight, self.qzeros, N, K, G, self.bits)
-            scales = self.scales.T.contiguous()
+            if self.scales.dtype == torch.float16 and self.scales.is_contiguous():
+                iw, zp, scales = ops.woq_unpack(self.qweight, self.qzeros, N, K, G, self.bits, scales=self.scales)  # one launch
+            else:
+                iw, zp = ops.woq_unpack(self.qweight, self.qzeros, N, K, G, self.bits)
+                scales = self.scales.T.contiguous()
         else:
             has_zp = hasattr(self, "qzeros")
             qw = self.qweight if self.compression_dim == 1 else self.qweight.T.contiguous()
@@ -370,6 +373,39 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
 
 # the reference's class name for the non-Gaudi device class; code that imports it keeps working
 INCWeightOnlyLinear = MI355XWeightOnlyLinear
+
+_GROUP_CALLS = {}
+
+
+def woq_linear_group(x, modules):
+    """[m(x) for m in modules] for packed modules that multiply the SAME activation -- q / k / v of an attention block, gate / up of
+    an MLP -- as ONE launch (inc_woq_gemm_multi) when x is a decode-sized batch (<= 64 rows).  Each module keeps its own buffers and
+    state-dict keys (`MI355XWeightOnlyLinear` stays the single-module path); the result of every module is what `inc_woq_gemm`'s
+    streaming kernel computes for it.  Anything the batched launch does not cover (prefill-sized x, g_idx plans, other widths,
+    non-optimum layouts, a dtype other than bf16 / fp16) is the plain list of single calls: the reference's forward per module
+    (modules.py:594-610)."""
+    mods = list(modules)
+    m0 = mods[0]
+    ok = (len(mods) >= 2 and x.dtype in (torch.bfloat16, torch.float16) and x.is_cuda and x.numel() > 0
+          and all(isinstance(m, MI355XWeightOnlyLinear) and m.bits == 4 and m.in_features == m0.in_features and m.group_size == m0.group_size
+                  and m._forward_plan() == "fused" for m in mods))
+    if ok:
+        K = m0.in_features
+        x2d = x.reshape(-1, K)
+        if x2d.shape[0] <= 64:
+            if not x2d.is_contiguous():
+                x2d = x2d.contiguous()
+            parts = [(m.qweight, m.scales, m.qzeros, m.bias, m.out_features) for m in mods]
+            key = tuple(id(m) for m in mods) + (x.dtype,)
+            call = _GROUP_CALLS.get(key)
+            if call is None or not call.current(parts):
+                if len(_GROUP_CALLS) > 4096:
+                    _GROUP_CALLS.clear()
+                call = _GROUP_CALLS[key] = ops.WoqGemmGroupCall(parts, K, m0.group_size, m0.bits, x.dtype)
+            ys = call(x2d)
+            if ys is not None:
+                return [y.view(*x.shape[:-1], m.out_features) for y, m in zip(ys, mods)]
+    return [m(x) for m in mods]
 
 
 class MulLinear(torch.nn.Module):

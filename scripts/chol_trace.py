@@ -1,4 +1,4 @@
-"""inverse_cholesky_upper at one K, a few times (for `rocprofv3 --kernel-trace`; scripts/gpu_r3.sh choltrace summarises the last run).
+"""inverse_cholesky_upper at one K, a few times (for `rocprofv3 --kernel-trace`; scripts/gpu_r5.sh choltrace summarises the last run).
 usage: python scripts/chol_trace.py [K]"""
 import sys
 import time

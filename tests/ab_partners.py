@@ -96,7 +96,7 @@ def inverse_cholesky_upper_python(H, check=True, outer=1024, tri_depth=2, tri_mi
     outer = max(nb, (CHOL_OUTER // nb) * nb)
     tag = 0
     top = []
-    # Look-ahead over the outer blocks (INC_MI355X_CHOL_LOOKAHEAD=1): the next outer block needs only the FIRST column
+    # Look-ahead over the outer blocks (gptq.CHOL_LOOKAHEAD = True): the next outer block needs only the FIRST column
     # chunk of this block's trailing update (it holds that block's diagonal block and its whole panel).  The other chunks run on
     # a second stream underneath the next block's factorisation -- a chain of one-workgroup diagonal kernels and small GEMMs that
     # leaves the chip idle (kernel trace at K = 11008: 9.9 ms of chol_diag_block + 13.7 ms of GEMMs back to back) -- and are

@@ -1,0 +1,136 @@
+"""-m gpu: inc_woq_gemm_multi -- the decode forward of several packed modules that share x (q / k / v; gate / up) in ONE launch.
+
+Reference semantics: n independent INCWeightOnlyLinear.forward calls on the same activation (modules.py:594-610).  Checked here:
+  * against the oracle's forward per module (O.woq_linear, <= 1e-3 like every fused-GEMM test);
+  * bit-identical to inc_woq_gemm on the N-CONCATENATED module (what a fused qkv module would compute): every 64-column strip runs
+    the same streaming body with the same K-slices, so the batched launch is the single launch of the wide module, bit for bit;
+  * against the n single calls: equal up to fp32 summation order only (a single 4096 x 4096 call at M <= 4 takes the no-split
+    kernel, which sums K in another order) -- the distance is printed and gated at float noise;
+  * batches the library declines fall back to the single calls and return exactly their results.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import woq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GS = 128
+
+
+def _packed(hip, N, K, seed, bias=False, sym=True, dtype=torch.bfloat16):
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(hip)
+    iw, sc, zp = quant_tensor(w, bits=4, group_size=GS, scheme="sym" if sym else "asym", return_int=True)
+    m = MI355XWeightOnlyLinear(K, N, bits=4, group_size=GS, zp=not sym, bias=bias, device=hip)
+    b = (torch.randn(N, generator=g) * 0.1).to(hip) if bias else None
+    m.pack(iw, sc, zp if not sym else None, b)
+    if not bias:
+        m.bias = None
+    return m
+
+
+def _concat(hip, mods):
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+
+    K, N = mods[0].in_features, sum(m.out_features for m in mods)
+    c = MI355XWeightOnlyLinear(K, N, bits=4, group_size=GS, zp=True, bias=mods[0].bias is not None, device=hip)
+    c.qweight = torch.cat([m.qweight for m in mods], dim=1).contiguous()
+    c.scales = torch.cat([m.scales for m in mods], dim=1).contiguous()
+    c.qzeros = torch.cat([m.qzeros for m in mods], dim=1).contiguous()
+    c.bias = None if mods[0].bias is None else torch.cat([m.bias for m in mods]).contiguous()
+    return c
+
+
+@pytest.mark.parametrize("M", [1, 4, 16, 33, 64])
+@pytest.mark.parametrize("group", ["qkv 3 x 4096x4096", "gate+up 2 x 11008x4096", "down-like 2 x 4096x11008"])
+def test_gemm_multi_llama_groups_vs_oracle_concat_and_singles(hip, group, M):
+    from neural_compressor_amd import ops
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import woq_linear_group
+
+    n, N, K = {"qkv 3 x 4096x4096": (3, 4096, 4096), "gate+up 2 x 11008x4096": (2, 11008, 4096), "down-like 2 x 4096x11008": (2, 4096, 11008)}[group]
+    mods = [_packed(hip, N, K, 10 * i + K % 97) for i in range(n)]
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(hip)
+    ys = woq_linear_group(x, mods)
+    call = ops.WoqGemmGroupCall([(m.qweight, m.scales, m.qzeros, m.bias, m.out_features) for m in mods], K, GS, 4, torch.bfloat16)
+    ys2 = call(x)
+    if M > 32:
+        # more than 32 rows on these sizes: the library declines (inc_woq_gemm's strip kernel is the faster form) -> the single calls
+        assert ys2 is None
+        assert all(torch.equal(y, m(x)) for y, m in zip(ys, mods))
+        return
+    # the batched entry point really ran (rc 0), not the fallback
+    assert ys2 is not None, "the library declined an eligible batch"
+    assert all(torch.equal(a, b) for a, b in zip(ys, ys2))
+    # (1) bit-identical to the single launch of the N-concatenated module
+    yc = _concat(hip, mods)(x)
+    off = 0
+    for y in ys:
+        assert y.shape == (M, N) and y.dtype == torch.bfloat16
+        assert torch.equal(y, yc[:, off:off + N]), "batched launch != single launch of the concatenated module"
+        off += N
+    # (2) oracle per module, (3) distance to the single calls
+    worst_o = worst_s = 0.0
+    for m, y in zip(mods, ys):
+        qw, sc, qz = m.qweight.cpu().numpy(), m.scales.cpu().numpy(), m.qzeros.cpu().numpy()
+        rows = torch.arange(M)[: 8]
+        ref = O.woq_linear(x[rows].cpu(), qw, sc, qz, None, N, K, 4, GS, compute_dtype=torch.bfloat16)
+        e = float((y[rows].float().cpu() - ref.to(torch.bfloat16).float()).norm() / ref.norm())
+        worst_o = max(worst_o, e)
+        ys_single = m(x)
+        worst_s = max(worst_s, float((y.float() - ys_single.float()).norm() / ys_single.float().norm()))
+    print(f"\n[gemm multi {group} M={M}] vs oracle (bf16-rounded) {worst_o:.2e}; vs the single calls {worst_s:.2e}; == concatenated single launch")
+    assert worst_o <= 1e-3
+    assert worst_s <= 2e-3  # bf16 output: one ulp = 3.9e-3 relative on an element, a handful of elements move by one
+
+
+def test_gemm_multi_bias_asym_fp16_and_ragged_columns(hip):
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import woq_linear_group
+
+    K = 1024
+    mods = [_packed(hip, N, K, 3 + i, bias=True, sym=False) for i, N in enumerate((256, 1000, 64, 4100))]
+    from neural_compressor_amd import ops
+
+    for dtype, rows in ((torch.float16, 5), (torch.bfloat16, 5), (torch.bfloat16, 20), (torch.float16, 40)):  # 1 / 2 / 4 row blocks of 16
+        x = torch.randn(rows, K, generator=torch.Generator().manual_seed(2)).to(dtype).to(hip)
+        call = ops.WoqGemmGroupCall([(m.qweight, m.scales, m.qzeros, m.bias, m.out_features) for m in mods], K, GS, 4, dtype)
+        assert call(x) is not None, "this batch is eligible for the one-launch form"
+        ys = woq_linear_group(x, mods)
+        for m, y in zip(mods, ys):
+            qw, sc, qz = m.qweight.cpu().numpy(), m.scales.cpu().numpy(), m.qzeros.cpu().numpy()
+            ref = O.woq_linear(x.cpu(), qw, sc, qz, m.bias.float().cpu(), m.out_features, K, 4, GS, compute_dtype=dtype)
+            e = float((y.float().cpu() - ref.to(dtype).float()).norm() / ref.norm())
+            assert y.shape == (rows, m.out_features) and e <= 2e-3, (m.out_features, dtype, rows, e)
+    x = x[:5].contiguous()
+    # leading dimensions are kept
+    y3 = woq_linear_group(x.view(1, 5, K), mods)
+    assert all(a.shape == (1, 5, m.out_features) for a, m in zip(y3, mods))
+
+
+def test_gemm_multi_falls_back_to_single_calls_when_not_eligible(hip):
+    from neural_compressor_amd import ops
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import woq_linear_group
+
+    K = 512
+    mods = [_packed(hip, 256, K, 7), _packed(hip, 128, K, 8)]
+    x_big = torch.randn(65, K).to(torch.bfloat16).to(hip)      # prefill-sized: not the decode launch
+    ys = woq_linear_group(x_big, mods)
+    assert all(torch.equal(y, m(x_big)) for y, m in zip(ys, mods))
+    x32 = torch.randn(3, K).to(hip)                              # fp32 activations: the module's own cast-and-return path
+    ys = woq_linear_group(x32, mods)
+    assert all(y.dtype == torch.float32 and torch.equal(y, m(x32)) for y, m in zip(ys, mods))
+    # the library itself declines (nothing launched) what it cannot batch: one module, M > 64
+    call = ops.WoqGemmGroupCall([(m.qweight, m.scales, m.qzeros, None, m.out_features) for m in mods[:1]], K, GS, 4, torch.bfloat16)
+    assert call(x_big[:4].contiguous()) is None
+    call = ops.WoqGemmGroupCall([(m.qweight, m.scales, m.qzeros, None, m.out_features) for m in mods], K, GS, 4, torch.bfloat16)
+    assert call(x_big) is None
+    # deterministic: two launches, same bits
+    x = torch.randn(2, K).to(torch.bfloat16).to(hip)
+    a, b = call(x), call(x)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
