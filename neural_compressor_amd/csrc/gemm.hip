@@ -1548,7 +1548,9 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
   __syncthreads();                                   // every wave's ring is dead: the reduction buffer takes their place
 
   // ---- the waves' accumulators meet in LDS, 64 rows x 64 columns per pass ---------------------------------------------
-  // D of an MFMA: column = lane & 15 -> tile column 4*jn + c, row = 4*oct + r
+  // D of an MFMA: column = lane & 15 -> tile column 4*jn + c, row = 4*oct + r.  Every thread sums and stores FOUR adjacent columns at a
+  // time: 16-byte LDS reads, 16-byte write-through partial stores or one 8-byte store of four outputs (round 6: the single-float form of
+  // this epilogue was about a third of a mid-M launch, tools/midm_lab)
   const int64_t slab = (int64_t)M * N;
   constexpr int RP = 68;  // row pitch of the reduction buffer in floats
 #pragma unroll
@@ -1562,20 +1564,20 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
             make_float4(acc[b][4 * nb + 0][r], acc[b][4 * nb + 1][r], acc[b][4 * nb + 2][r], acc[b][4 * nb + 3][r]);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 64 * 64 / NT; ++i) {
-      const int idx = tid + NT * i, rr = idx >> 6, cc = idx & 63;
-      float v = red[rr * RP + cc];
+    for (int i = 0; i < (64 * 16 + NT - 1) / NT; ++i) {
+      const int idx = tid + NT * i, rr = idx >> 4, c4 = (idx & 15) * 4;
+      if (idx >= 64 * 16) continue;
+      float4 v = *reinterpret_cast<const float4*>(red + rr * RP + c4);
 #pragma unroll
-      for (int wv = 1; wv < WAVES; ++wv) v += red[(wv * 64 + rr) * RP + cc];  // fixed order
+      for (int wv = 1; wv < WAVES; ++wv) {  // fixed order
+        const float4 u = *reinterpret_cast<const float4*>(red + (wv * 64 + rr) * RP + c4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
       const int m = m0 + rr;
-      const int64_t n = n0 + 64 * nb + cc;
-      if (m < M && n < N) {
-        if (splitk > 1) {
-          __hip_atomic_store(&partial[(int64_t)slice * slab + (int64_t)m * N + n], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
-        } else {
-          const float o = v + (bias ? cvt16<IS_BF16>(bias[n]) : 0.f);
-          y[(int64_t)m * N + n] = IS_BF16 ? f32_to_bf16_bits(o) : f32_to_f16_bits(o);
-        }
+      const int64_t n = n0 + 64 * nb + c4;
+      if (m < M && n < N) {  // N % 4 == 0 on this path: the four columns exist together
+        if (splitk > 1) splitk_store16_sc1(partial + (int64_t)slice * slab + (int64_t)m * N + n, f32x4{v.x, v.y, v.z, v.w});
+        else store_out4<IS_BF16>(y + (int64_t)m * N + n, v, bias ? bias + n : nullptr);
       }
     }
   }
@@ -1592,36 +1594,39 @@ __global__ __launch_bounds__(64 * WAVES) void woq_gemm_w4_strip_kernel(
   }
   __syncthreads();
   if (red[0] == 0.f) return;
-  // last arriver: fixed-order sum over the slices (sc1 loads: L1-bypassing, the partials were written through); 8 outputs x up
-  // to 4 slices of a thread are in flight together
-  constexpr int OUTS = ROWS * COLS / NT;
-  for (int i0 = 0; i0 < OUTS; i0 += 8) {
-    float pv[4][8];
-    int64_t off[8];
-    bool ok[8];
+  // last arriver: fixed-order sum over the slices (sc1 16-byte loads: the partials were written through); 4 column quads x up to 4
+  // slices of a thread are in flight together
+  constexpr int QUADS = ROWS * COLS / 4 / NT;
+  static_assert(ROWS * COLS / 4 % NT == 0 && QUADS % 4 == 0, "whole batches of four quads per thread");
+  for (int i0 = 0; i0 < QUADS; i0 += 4) {
+    f32x4 pv[4][4];
+    int64_t off[4];
+    bool ok[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + NT * (i0 + i), rr = idx / COLS, cc = idx % COLS;
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + NT * (i0 + i), rr = idx / (COLS / 4), c4 = (idx % (COLS / 4)) * 4;
       const int m = m0 + rr;
-      const int64_t n = n0 + cc;
+      const int64_t n = n0 + c4;
       ok[i] = m < M && n < N;
       off[i] = ok[i] ? (int64_t)m * N + n : 0;
     }
+    const float* sb[4];
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-      const int64_t base = (int64_t)(sl < splitk ? sl : splitk - 1) * slab;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) pv[sl][i] = __hip_atomic_load(&partial[base + off[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int sl = 0; sl < 4; ++sl) {  // slab bases are wave-uniform (SGPR pairs); slices past splitk re-read the last one and are not added
+      const uint64_t a = (uint64_t)(uintptr_t)(partial + (int64_t)(sl < splitk ? sl : splitk - 1) * slab);
+      sb[sl] = reinterpret_cast<const float*>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                                                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a)));
     }
+    splitk_load16x16_sc1(pv, sb[0], sb[1], sb[2], sb[3], (uint32_t)(off[0] * 4), (uint32_t)(off[1] * 4), (uint32_t)(off[2] * 4), (uint32_t)(off[3] * 4));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float v = pv[0][i];
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = pv[0][i];
 #pragma unroll
-      for (int sl = 1; sl < 4; ++sl) v += sl < splitk ? pv[sl][i] : 0.f;
+      for (int sl = 1; sl < 4; ++sl)
+        if (sl < splitk) v += pv[sl][i];
       if (ok[i]) {
-        const int64_t n = n0 + (tid + NT * (i0 + i)) % COLS;
-        v += bias ? cvt16<IS_BF16>(bias[n]) : 0.f;
-        y[off[i]] = IS_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v);
+        const int64_t n = n0 + ((tid + NT * (i0 + i)) % (COLS / 4)) * 4;
+        store_out4<IS_BF16>(y + off[i], make_float4(v[0], v[1], v[2], v[3]), bias ? bias + n : nullptr);
       }
     }
   }
@@ -1854,8 +1859,15 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     INC_LAUNCH_RETURN();
   }
   const bool strip_ok = !g_idx && bits == 4 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && (M > GEMV_MAX_M || (M > 32 && N * K > ((int64_t)24 << 20)) || (dbg == 83 && M > 16)) && M <= STRIP_MAX_M &&
-                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (dbg == 0 || (dbg >= 83 && dbg <= 89) || (dbg >= 100 && dbg <= 102));
-  if (strip_ok) {
+                        ceil_div64(M, TM) * ceil_div64(N, TN) <= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
+                        (reinterpret_cast<uintptr_t>(bias) & 7) == 0 && (dbg == 0 || (dbg >= 83 && dbg <= 89) || (dbg >= 100 && dbg <= 102));
+  if (strip_ok && dbg == 0 && M > 128 && M * N < ((int64_t)1 << 30) && inc_woq_gemm_strip8_splitk(M, N, K) == 1) {
+    // enough 128 x 128 tiles to fill the chip without K-slices (>= 192): the four-wave kernel that dequantises every weight once per
+    // 128 rows (gemm_strip8.hip).  tools/midm_lab, 4096 x 4096: M = 1024 46 vs 57 us; 11008 x 4096, M = 256: 40 vs 48 us.  With K-slices
+    // its larger partial tiles lose to the 64-row strips below (M = 512: 34 vs 30 us), so those keep this kernel's predecessor.
+    return inc_launch_woq_gemm_strip8(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, nullptr, nullptr, 1, bf, s);
+  }
+  if (strip_ok && M * N < ((int64_t)1 << 30)) {
     int splitk = strip_splitk(M, N, K);
     const int64_t wgs = ceil_div64(M, 64) * ceil_div64(N, 128);
     if (splitk > 1 && (!workspace || workspace_bytes < WS_COUNTER_BYTES + (int64_t)splitk * M * N * 4 || wgs * 4 > WS_COUNTER_BYTES)) splitk = 1;

@@ -12,6 +12,12 @@ int inc_launch_woq_gemm_d2r8(const uint16_t* x, const uint32_t* qw, const uint16
                              uint16_t* y, int64_t M, int64_t N, int64_t K, int64_t NW, int g_shift, int y_vec_ok, float* part, int steps,
                              int splits, bool bf, hipStream_t s);
 
+// gemm_strip8.hip: the 128 x 128 mid-M kernel (four waves, K split inside the workgroup) and its split-K plan
+int inc_woq_gemm_strip8_splitk(int64_t M, int64_t N, int64_t K);
+int inc_launch_woq_gemm_strip8(const uint16_t* x, const uint32_t* qw, const uint16_t* scales, const uint32_t* qz, const uint16_t* bias,
+                               uint16_t* y, int64_t M, int64_t N, int64_t K, int64_t NW, int g_shift, float* part, unsigned* counters,
+                               int splitk, bool bf, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -118,6 +124,44 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c)
     __builtin_memcpy(&fb, &b, 16);
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, c, 0, 0, 0);
   }
+}
+
+// 16-byte write-through store / L2-coherent load of split-K partials (the hand-off of MI355X_MICROARCH.md "Valid forms": sc1 stores ->
+// vmcnt(0) -> barrier -> one relaxed agent-scope ticket -> sc1 loads by the last arriver); the caller waits for the loads (vmcnt) itself
+__device__ __forceinline__ void splitk_store16_sc1(float* p, f32x4 v) {
+  // (s_nop: a VMEM store of more than 64 bits reads its data registers AFTER issue -- the next instruction may not overwrite them for two
+  // wait states; the compiler's hazard recogniser inserts that for its own stores but cannot see into an asm statement.  Without it this
+  // hand-off returned wrong sums a few times per hundred launches.)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+// pv[sl][i] = 16 bytes at bases[sl] + off[i] (byte offsets < 4 GiB), sl, i in 0..3, sc1 (L2-coherent: the partials were written through by
+// other XCDs), and the wait for them -- ONE asm statement: a load whose result the compiler sees before an explicit s_waitcnt may be
+// copied or spilled by it before the data has landed (MI355X guide, inline-asm hazards)
+__device__ __forceinline__ void splitk_load16x16_sc1(f32x4 (&pv)[4][4], const float* b0, const float* b1, const float* b2, const float* b3,
+                                                     uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %16, %20 sc1\n\tglobal_load_dwordx4 %1, %17, %20 sc1\n\tglobal_load_dwordx4 %2, %18, %20 sc1\n\tglobal_load_dwordx4 %3, %19, %20 sc1\n\t"
+      "global_load_dwordx4 %4, %16, %21 sc1\n\tglobal_load_dwordx4 %5, %17, %21 sc1\n\tglobal_load_dwordx4 %6, %18, %21 sc1\n\tglobal_load_dwordx4 %7, %19, %21 sc1\n\t"
+      "global_load_dwordx4 %8, %16, %22 sc1\n\tglobal_load_dwordx4 %9, %17, %22 sc1\n\tglobal_load_dwordx4 %10, %18, %22 sc1\n\tglobal_load_dwordx4 %11, %19, %22 sc1\n\t"
+      "global_load_dwordx4 %12, %16, %23 sc1\n\tglobal_load_dwordx4 %13, %17, %23 sc1\n\tglobal_load_dwordx4 %14, %18, %23 sc1\n\tglobal_load_dwordx4 %15, %19, %23 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(pv[0][0]), "=&v"(pv[0][1]), "=&v"(pv[0][2]), "=&v"(pv[0][3]), "=&v"(pv[1][0]), "=&v"(pv[1][1]), "=&v"(pv[1][2]), "=&v"(pv[1][3]),
+        "=&v"(pv[2][0]), "=&v"(pv[2][1]), "=&v"(pv[2][2]), "=&v"(pv[2][3]), "=&v"(pv[3][0]), "=&v"(pv[3][1]), "=&v"(pv[3][2]), "=&v"(pv[3][3])
+      : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(b0), "s"(b1), "s"(b2), "s"(b3)
+      : "memory");
+}
+// four adjacent outputs of one row: + bias, one rounding to the 16-bit type, one 8-byte store (y + n with n % 4 == 0 and N % 4 == 0)
+template <bool IS_BF16>
+__device__ __forceinline__ void store_out4(uint16_t* dst, float4 v, const uint16_t* bias4) {
+  if (bias4) {
+    const uint2 b = *reinterpret_cast<const uint2*>(bias4);
+    v.x += cvt16<IS_BF16>((uint16_t)(b.x & 0xffffu)); v.y += cvt16<IS_BF16>((uint16_t)(b.x >> 16));
+    v.z += cvt16<IS_BF16>((uint16_t)(b.y & 0xffffu)); v.w += cvt16<IS_BF16>((uint16_t)(b.y >> 16));
+  }
+  uint2 o;
+  o.x = pack2<IS_BF16>(v.x, v.y);
+  o.y = pack2<IS_BF16>(v.z, v.w);
+  *reinterpret_cast<uint2*>(dst) = o;
 }
 
 constexpr int TM = 256, TN = 256, TK = 64;

@@ -320,6 +320,10 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
             y = y.float()
         return y.reshape(*lead, self.out_features)
 
+    # widths other than 4 / 8 bits: True = multiply through inc_woq_gemm's per-element tile form (no dense weight ever exists; 8-10 x
+    # slower), False = HIP recover() into a transient dense weight + the library GEMM (what the reference's forward does on its CPU)
+    ODD_WIDTH_FUSED = False
+
     def _forward_plan(self):
         """Pick the forward route once per packed state.  A per-element `g_idx` (GPTQ act_order, HF desc_act
         checkpoints; modules.py:341-344) that is a permutation of whole groups is handled by sorting the K axis by group:
@@ -327,13 +331,15 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         K-sorted copy of the packed words with only an activation gather per call."""
         # in-place re-packing / load_state_dict bump the tensors' version counters -> the plan is rebuilt
         key = (self.qweight.data_ptr(), self.qweight._version,
-               None if self.g_idx is None else (self.g_idx.data_ptr(), self.g_idx._version))
+               None if self.g_idx is None else (self.g_idx.data_ptr(), self.g_idx._version), self.ODD_WIDTH_FUSED)
         if getattr(self, "_plan_key", None) == key:
             return self._plan
         plan = "dense"
         # 4 / 8 bits: whole words per group (the fast kernels); every other width 1..7 runs inc_woq_gemm's per-element tile form,
         # which takes any group size (n_pack = 10 / 6 / 5 for 3 / 5 / 6 bits never divides one)
-        fusable = self.use_optimum_format and (self.group_size % self.n_pack == 0 if self.bits in (4, 8) else True)
+        # (the per-element form is the memory-saving route, not the fast one: measured 376-480 us against 40-100 us for HIP recover() +
+        # the library GEMM at 4096^2 for every M from 1 to 4096, profiles/r6/anyw_route_time.log -- so it is opt-in: ODD_WIDTH_FUSED)
+        fusable = self.use_optimum_format and (self.group_size % self.n_pack == 0 if self.bits in (4, 8) else self.ODD_WIDTH_FUSED)
         self._k_order = self._qweight_sorted = None
         if fusable:
             K, gs = self.in_features, self.group_size
