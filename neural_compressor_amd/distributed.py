@@ -211,6 +211,74 @@ class CalibrationGroup:
         return out[:n_rows].contiguous()
 
 
+def solve_cost(n_rows, n_cols):
+    """Relative time of one column loop over [n_rows, n_cols] (a latency chain per column with a per-row throughput term; fitted to
+    tools/kbench qlayer: 4096^2 2.2 ms, 12288 x 4096 3.8, 22016 x 4096 6.3, 4096 x 11008 8.8)."""
+    return n_cols * (0.4 + n_rows / 20480.0)
+
+
+def plan_solves_2d(shapes, world):
+    """Mode "sample+rows", 2-D form: assign the independent solves of a block (one per DISTINCT Hessian: `shapes` = [(rows, cols), ...])
+    to groups of ranks -- module x rows instead of rows alone.  With rows alone every rank walks all the column loops one after the
+    other, and a loop's time hardly shrinks with fewer rows (it is a chain of `cols` dependent steps); here the loops of a block run
+    side by side on disjoint rank groups and only the rows inside a group are sharded.
+      world >= len(shapes): every solve gets its own contiguous rank group; the spare ranks go, one at a time, to the solve whose
+                            estimated time (solve_cost on its rows / group size) is largest;
+      world <  len(shapes): every rank is a group of one; solves are dealt longest-first to the least-loaded rank.
+    Returns [ranks of solve 0, ranks of solve 1, ...] (lists of group-local ranks, ascending; the first is the solve's leader: it
+    receives the reduced Hessian, factorises it and publishes the results).  Deterministic: every rank computes the same plan."""
+    n = len(shapes)
+    if n == 0:
+        return []
+    plan = _plan_groups(shapes, world)
+    load = {}
+    for (r, c), g in zip(shapes, plan):
+        load[tuple(g)] = load.get(tuple(g), 0.0) + solve_cost(-(-r // len(g)), c)
+    if max(load.values()) > sum(solve_cost(-(-r // world), c) for r, c in shapes):
+        return [list(range(world)) for _ in shapes]  # row-dominated solves: sharding rows alone over all ranks is the better plan
+    return plan
+
+
+def _plan_groups(shapes, world):
+    n = len(shapes)
+    if world >= n:
+        size = [1] * n
+        for _ in range(world - n):
+            t = [solve_cost(-(-r // size[i]), c) for i, (r, c) in enumerate(shapes)]
+            size[max(range(n), key=lambda i: (t[i], -i))] += 1
+        out, nxt = [], 0
+        for sz in size:
+            out.append(list(range(nxt, nxt + sz)))
+            nxt += sz
+        return out
+    load = [0.0] * world
+    out = [None] * n
+    for i in sorted(range(n), key=lambda i: (-solve_cost(*shapes[i]), i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        out[i] = [r]
+        load[r] += solve_cost(*shapes[i])
+    return out
+
+
+_SUBGROUPS = {}
+
+
+def subgroup(ranks, parent=None):
+    """CalibrationGroup over `ranks` (local ranks of `parent`, ascending).  dist.new_group is collective over the parent: every rank
+    must call this with the same rank lists in the same order (the plan is deterministic, so they do); groups are created once."""
+    world = dist.get_world_size(parent)
+    key = (id(parent), tuple(ranks))
+    if key not in _SUBGROUPS:
+        if len(ranks) == world:
+            _SUBGROUPS[key] = CalibrationGroup(parent)
+        else:
+            glob = [r if parent is None else dist.get_global_rank(parent, r) for r in ranks]
+            pg = dist.new_group(ranks=glob, backend=dist.get_backend(parent))
+            me = dist.get_rank(parent)
+            _SUBGROUPS[key] = CalibrationGroup(pg) if me in ranks else None
+    return _SUBGROUPS[key]
+
+
 def shard_samples(n_samples, rank, world):
     """Contiguous, balanced split of calibration sample indices (sample ownership is fixed for the whole run, so
     block outputs never need to be exchanged: rank r forwards its own samples through every block)."""

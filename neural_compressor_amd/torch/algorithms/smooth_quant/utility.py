@@ -406,19 +406,20 @@ class AutoAlpha:
             for d in set(self.absorb_to_layer.keys()).difference(self.input_mins.keys()):
                 del self.absorb_to_layer[d]
         if self.loss_type == "blockwise":  # reference :1304-1322
-            module_names = self._get_sq_layer_names()
-            block_names, self.block_to_module = self.get_blocks(), {}
-            for block in block_names:
-                self.block_to_module[block] = []
-            for module in module_names:
-                checked = False
-                for block in block_names:
-                    if block + "." in module:
-                        self.block_to_module[block].append(module)
-                        checked = True
-                if not checked:
-                    self.block_to_module[module] = [module]
-            self.block_names = list(self.block_to_module.keys())
+            # every transformer block tunes ONE alpha for the smoothable layers inside it; a layer outside all blocks is its own "block".
+            # Same grouping and same key order as the reference's table (blocks first, in model order, then the stragglers as they are
+            # met; a layer whose name contains several block prefixes joins each of them, as there)
+            blocks = self.get_blocks()
+            members = {blk: [] for blk in blocks}
+            stragglers = {}
+            for layer in self._get_sq_layer_names():
+                homes = [blk for blk in blocks if (blk + ".") in layer]
+                for blk in homes:
+                    members[blk].append(layer)
+                if not homes:
+                    stragglers[layer] = [layer]
+            self.block_to_module = {**members, **stragglers}
+            self.block_names = list(self.block_to_module)
             logger.info("Blockwise auto-tuning: %d blocks found", len(self.block_names))
             return self._auto_tune_alpha_blockwise()
         return self._auto_tune_alpha()

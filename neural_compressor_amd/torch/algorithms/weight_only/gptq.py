@@ -104,6 +104,7 @@ _LOOKAHEAD_STREAMS = {}
 # same operands: bit-identical results (a module attribute: tests compare it with every solve in front of the second forward).
 LATE_SOLVE = True
 LAYER_LOOKAHEAD = True  # mode "layer": next round's exchange under this round's solve (tests set it to compare)
+SOLVE_2D = True  # modes "rows" / "sample+rows": a block's solves on disjoint rank groups (False: every solve row-sharded over all ranks)
 _TRACE_RANGES = os.environ.get("INC_MI355X_TRACE_RANGES", "0") == "1"  # roctx ranges around the phases of a block (scripts/step_timeline.py)
 
 
@@ -473,6 +474,8 @@ class HessianAccumulator:
             self._info = torch.zeros(1, dtype=torch.int32, device=self.device)
         # the "not positive definite" status word travels with the factor: every rank raises together in check() instead of the
         # owner alone (the others would walk into the next collective and hang)
+        if ctx.world == 1:  # a rank group of one (2-D form): nothing to send
+            return
         handles = [ctx.broadcast(t, owner, async_op=True) for t in (Hinv, dead, perm, self._info) if t is not None]
         handles = [h for h in handles if h is not None]
         if ctx.rank != owner and handles:
@@ -698,6 +701,9 @@ class RAWGPTQuantizer(object):
         # process group) or a process group; together with hessian_allreduce the Hessians are REDUCED to the owner
         # (samples sharded), without it every rank is expected to have seen all samples.
         self.row_shard_solve = kwargs.get("row_shard_solve", None)
+        # 2-D form of the row-sharded solve (distributed.plan_solves_2d): the independent solves of a block run side by side on disjoint
+        # rank groups (module x rows) instead of one after the other on all ranks (rows alone); same bits either way
+        self.solve_2d = kwargs.get("solve_2d", SOLVE_2D)
         mode = os.environ.get("INC_MI355X_GPTQ_MULTI_GPU", "")
         if mode and (self.hessian_allreduce is None and self.row_shard_solve is None):
             import torch.distributed as dist
@@ -1020,6 +1026,83 @@ class RAWGPTQuantizer(object):
                 acc.reduce_to_owner(ctx, ctx.owner(i), int(round(counts[i])))
         for i, (acc, percdamp, act_order, hyb) in enumerate(distinct):
             acc.exchange_factor(ctx, ctx.owner(i), percdamp, act_order, hyb)
+
+    # -- modes "rows" / "sample+rows", 2-D form (distributed.plan_solves_2d) -------------------------------------------------------
+    def _plan_2d(self, batches, solvers, distinct):
+        """[(names, acc, CalibrationGroup of the batch's ranks or None when this rank is not in it, leader rank), ...] for the block's
+        solves, or None when the 2-D form does not apply (switched off; a world of one; a Hessian that serves several batches -- then
+        its factor would have to reach several groups, and the rows-only form keeps that simple)."""
+        from ....distributed import plan_solves_2d, subgroup
+
+        ctx = self.dist_ctx
+        if not self.solve_2d or ctx.world < 2 or len(batches) < 2:
+            return None
+        accs = [solvers[names[0]].acc for names in batches]
+        if len({id(a) for a in accs}) != len(accs) or len(accs) != len(distinct):
+            return None
+        shapes = [(sum(solvers[n].rows for n in names), solvers[names[0]].columns) for names in batches]
+        ranks = plan_solves_2d(shapes, ctx.world)
+        return [(names, acc, subgroup(r, ctx.group), r[0]) for names, acc, r in zip(batches, accs, ranks)]
+
+    def _exchange_factors_2d(self, plan, distinct):
+        """Every Hessian is reduced to its batch's leader, factorised there and broadcast INSIDE the batch's rank group only; the other
+        ranks drop theirs.  Same collectives in the same order on every rank."""
+        ctx = self.dist_ctx
+        settings = {id(acc): (percdamp, act_order, hyb) for acc, percdamp, act_order, hyb in distinct}
+        if self.hessian_allreduce:
+            for _, acc, _, _ in plan:
+                acc.flush()
+            counts = torch.tensor([float(acc._n) for _, acc, _, _ in plan], dtype=torch.float64,
+                                  device="cpu" if ctx.backend == "gloo" else self.device)
+            counts = ctx.all_reduce(counts).tolist()
+            for i, (_, acc, _, leader) in enumerate(plan):
+                acc.reduce_to_owner(ctx, leader, int(round(counts[i])))
+        for _, acc, sub, _ in plan:
+            if sub is None:  # not this rank's solve: nothing of it is needed here until the results arrive
+                acc.flush()
+                acc._stage, acc.H = None, None
+                continue
+            percdamp, act_order, hyb = settings[id(acc)]
+            acc.exchange_factor(sub, 0, percdamp, act_order, hyb)  # local rank 0 of the group = the leader
+
+    def _solve_2d(self, plan, batches, solvers, layers, run_solve, scatter):
+        """Phase 1: every rank runs the solve(s) of ITS group, rows sharded inside the group (all-gathered there).  Phase 2: each
+        batch's leader publishes the batch -- codes, Q, scales, zero points, the act_order permutation and the factorisation's status
+        word -- to the world, in batch order; every rank ends with the same quantised block, bit-identical to the rows-only form."""
+        ctx = self.dist_ctx
+        stacked = {}
+        for i, (names, acc, sub, _) in enumerate(plan):
+            if sub is None:
+                continue
+            for n in names:
+                solvers[n].row_ctx = sub if sub.world > 1 else None
+            stacked[i] = run_solve(names)
+        for i, (names, acc, sub, leader) in enumerate(plan):
+            sv = solvers[names[0]]
+            cfg = sv.cfg
+            if sub is not None:
+                scale, zp, Q, codes, perm = stacked[i]
+                info = acc._info if acc._info is not None else torch.zeros(1, dtype=torch.int32, device=self.device)
+            else:
+                rows, K = sum(solvers[n].rows for n in names), sv.columns
+                gs_ = cfg["group_size"]
+                G = 1 if (gs_ == -1 or gs_ >= K) else math.ceil(K / int(gs_))
+                w0 = layers[names[0]].weight.data
+                Q = torch.empty(w0.shape if len(names) == 1 else (rows, K), dtype=w0.dtype, device=self.device)
+                scale = torch.empty((rows, G), dtype=torch.float32, device=self.device)
+                zp = torch.empty((rows, G), dtype=torch.float32, device=self.device)
+                codes = torch.empty((rows, K), dtype=torch.uint8, device=self.device)
+                perm = (torch.empty(K, dtype=torch.int64, device=self.device)
+                        if (cfg["act_order"] and not cfg["static_groups"]) else None)
+                info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            Q = Q.contiguous()
+            for t in (codes, Q, scale, zp, perm, info):
+                if t is not None:
+                    ctx.broadcast(t, leader)
+            if sub is None or ctx.rank != leader:
+                # the status word of a factorisation this rank did not run (or received inside the group): every rank raises together
+                acc._info, acc._info_host, acc._info_event = info, None, None
+            scatter(names, (scale, zp, Q, codes, perm))
 
     # -- the main loop (reference :568-887) ----------------------------------------------------------------
     @torch.no_grad()
@@ -1506,10 +1589,30 @@ class RAWGPTQuantizer(object):
                 if id(acc) not in seen:
                     seen.add(id(acc))
                     distinct.append((acc, solvers[name].cfg["percdamp"], solvers[name].cfg["act_order"], hybrid_gs(solvers[name])))
+            # Linears that share one Hessian (q/k/v, gate/up) and one GPTQ setting are stacked along N and solved in ONE pass (Step 2.4)
+            _KEYS = ("bits", "sym", "group_size", "block_size", "percdamp", "act_order", "hybrid_order", "fp8_aware",
+                     "static_groups", "mse", "dtype", "use_double_quant")
+            batches, index = [], {}
+            for name, layer in layers.items():
+                sv = solvers[name]
+                key = None
+                if isinstance(layer, nn.Linear) and self.share_hessians:
+                    key = (id(sv.acc), layer.weight.dtype, tuple(sv.cfg.get(k) for k in _KEYS))
+                if key is not None and key in index:
+                    batches[index[key]].append(name)
+                else:
+                    if key is not None:
+                        index[key] = len(batches)
+                    batches.append([name])
+            plan2d = None
             if self.dist_ctx is not None:
-                self._exchange_factors(distinct)
-                for sv in solvers.values():
-                    sv.row_ctx = self.dist_ctx
+                plan2d = self._plan_2d(batches, solvers, distinct)
+                if plan2d is not None:
+                    self._exchange_factors_2d(plan2d, distinct)
+                else:
+                    self._exchange_factors(distinct)
+                    for sv in solvers.values():
+                        sv.row_ctx = self.dist_ctx
             elif self.hessian_allreduce:
                 group = None if self.hessian_allreduce is True else self.hessian_allreduce
                 for acc, _, _, _ in distinct:  # one all-reduce per DISTINCT accumulator
@@ -1527,20 +1630,6 @@ class RAWGPTQuantizer(object):
             # that share one Hessian (q/k/v, gate/up) and one GPTQ setting are stacked along N and solved in ONE pass:
             # a third of the serial 128-column steps and three times the rows in flight per step, same results.
             results = {}
-            _KEYS = ("bits", "sym", "group_size", "block_size", "percdamp", "act_order", "hybrid_order", "fp8_aware",
-                     "static_groups", "mse", "dtype", "use_double_quant")
-            batches, index = [], {}
-            for name, layer in layers.items():
-                sv = solvers[name]
-                key = None
-                if isinstance(layer, nn.Linear) and self.share_hessians:
-                    key = (id(sv.acc), layer.weight.dtype, tuple(sv.cfg.get(k) for k in _KEYS))
-                if key is not None and key in index:
-                    batches[index[key]].append(name)
-                else:
-                    if key is not None:
-                        index[key] = len(batches)
-                    batches.append([name])
             # The batch whose Linears run LAST in the block's forward (known from the probe forward of the capture pass) is solved
             # on `self._late_stream`; the second forward below starts without it (see LATE_SOLVE).
             late = None
@@ -1552,7 +1641,8 @@ class RAWGPTQuantizer(object):
             late_event = None
             main = torch.cuda.current_stream(self.device) if late is not None else None
 
-            def solve(names):
+            def run_solve(names):
+                """The (N-stacked) solve of one batch -> (scale, zero, Q, codes, perm) over all of its rows."""
                 sv = solvers[names[0]]
                 cfg = sv.cfg
                 if names is late:
@@ -1570,7 +1660,12 @@ class RAWGPTQuantizer(object):
                     act_order=cfg["act_order"], hybrid_order=cfg["hybrid_order"], fp8_aware=cfg["fp8_aware"],
                     static_groups=cfg["static_groups"],
                 )
-                codes, perm = sv.codes, sv.export_perm
+                return scale, zp, Q, sv.codes, sv.export_perm
+
+            def scatter(names, stacked):
+                """Hand the rows of a solved batch back to its Linears."""
+                scale, zp, Q, codes, perm = stacked
+                cfg = solvers[names[0]].cfg
                 r0 = 0
                 for n in names:
                     rows = layers[n].weight.shape[0]
@@ -1582,6 +1677,9 @@ class RAWGPTQuantizer(object):
                                       zero=None if cfg["sym"] else (zp if one else zp[sl].contiguous()), perm=perm,
                                       codes=codes if one else codes[sl].contiguous())
                     solvers[n].perm = perm
+
+            def solve(names):
+                scatter(names, run_solve(names))
 
             with _phase("gptq.solve_issue"):
                 if late is not None:
@@ -1597,9 +1695,12 @@ class RAWGPTQuantizer(object):
                         for t in (layers[n].weight.data, results[n]["scale"], results[n]["zero"], results[n]["codes"], results[n]["perm"]):
                             if isinstance(t, torch.Tensor):
                                 t.record_stream(main)
-                for names in batches:
-                    if names is not late:
-                        solve(names)
+                if plan2d is not None:
+                    self._solve_2d(plan2d, batches, solvers, layers, run_solve, scatter)
+                else:
+                    for names in batches:
+                        if names is not late:
+                            solve(names)
 
             def finish_solves():
                 for acc, _, _, _ in distinct:
@@ -1671,7 +1772,7 @@ class GPTQuantizer(INCQuantizer):
             model, weight_config=self.quant_config, nsamples=nsamples, use_max_length=use_max_length,
             max_seq_length=max_seq_length, device=device, use_layer_wise=use_layer_wise, model_path=model_path,
             quant_lm_head=quant_lm_head, use_block_wise=use_block_wise,
-            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback", "hessian_allreduce", "row_shard_solve", "independent_blocks")},
+            **{k: v for k, v in kwargs.items() if k in ("share_hessians", "block_callback", "hessian_allreduce", "row_shard_solve", "independent_blocks", "solve_2d")},
         )
         self.gptq_quantizer.prepare_for_calibration()
         return self.gptq_quantizer.model

@@ -197,3 +197,78 @@ def test_layer_mode_setup_rejects_batches_it_cannot_exchange(case):
         assert res[0] == res[1] == ("ok", [2, 2], (1, 4, 5))
     else:
         assert res[0][0] == res[1][0] == "raised", res
+
+
+def test_plan_solves_2d_is_a_partition_and_beats_rows_only():
+    """distributed.plan_solves_2d (mode "sample+rows", 2-D form): every solve gets a non-empty, ascending rank list; with at least as
+    many ranks as solves the groups are disjoint and cover the world; with fewer, every rank is used; and the estimated makespan is
+    never worse than sharding rows alone (every rank walking all loops)."""
+    from neural_compressor_amd import distributed as D
+
+    llama = [(12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)]  # qkv-stacked, o_proj, gate+up-stacked, down_proj of Llama-2-7B
+    for shapes in (llama, llama[:1], [(512, 256)] * 7, [(1, 8), (100000, 8)]):
+        for world in (1, 2, 3, 4, 5, 8, 16):
+            plan = D.plan_solves_2d(shapes, world)
+            assert len(plan) == len(shapes) and all(g and g == sorted(g) and 0 <= g[0] and g[-1] < world for g in plan)
+            used = sorted({r for g in plan for r in g})
+            if all(g == list(range(world)) for g in plan):
+                pass  # the plan fell back to rows alone (row-dominated solves): every solve on all ranks
+            elif world >= len(shapes):
+                flat = [r for g in plan for r in g]
+                assert sorted(flat) == list(range(world)), (shapes, world, plan)  # disjoint, contiguous, complete
+                assert all(g == list(range(g[0], g[0] + len(g))) for g in plan)
+            else:
+                assert all(len(g) == 1 for g in plan) and used == list(range(world))
+            load = {}
+            for (r, c), g in zip(shapes, plan):
+                load[tuple(g)] = load.get(tuple(g), 0.0) + D.solve_cost(-(-r // len(g)), c)
+            rows_only = sum(D.solve_cost(-(-r // world), c) for r, c in shapes)
+            assert max(load.values()) <= rows_only * 1.0001, (shapes, world, plan)
+            assert plan == D.plan_solves_2d(shapes, world)  # deterministic: every rank computes the same plan
+    assert D.plan_solves_2d(llama, 8) == [[0], [1], [2, 3], [4, 5, 6, 7]]
+    assert D.plan_solves_2d([], 4) == []
+
+
+def _plan2d_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neural_compressor_amd import distributed as D
+
+    D.init_from_env(backend="gloo")
+    ctx = D.CalibrationGroup()
+    # four "solves" with a row-wise stand-in for the column loop (out[r] = f(in[r]) -- what makes row sharding exact): the 2-D flow of
+    # RAWGPTQuantizer._solve_2d on CPU tensors -- groups from the plan, rows sharded and gathered inside a group, leader -> world
+    shapes = [(192, 8), (70, 8), (330, 8), (64, 24)]
+    g = torch.Generator().manual_seed(0)
+    Ws = [torch.randn(r, c, generator=g) for r, c in shapes]
+    f = lambda w: torch.cumsum(w * 3.0, dim=1)  # row-wise, order-sensitive along the columns
+    plan = D.plan_solves_2d(shapes, world)
+    subs = [D.subgroup(r, None) for r in plan]  # collective creation, same order on every rank
+    done = {}
+    for i, (W, ranks, sub) in enumerate(zip(Ws, plan, subs)):
+        assert (sub is not None) == (rank in ranks)
+        if sub is None:
+            continue
+        r0, r1, shard = D.row_shard(W.shape[0], sub.rank, sub.world)
+        done[i] = sub.all_gather_rows(f(W[r0:r1]).contiguous(), W.shape[0], shard) if sub.world > 1 else f(W)
+    ok = True
+    for i, (W, ranks) in enumerate(zip(Ws, plan)):
+        res = done[i] if i in done else torch.empty_like(W)
+        ctx.broadcast(res, ranks[0])
+        ok = ok and torch.equal(res, f(W))  # bit-identical to the one-process result on every rank
+    out[rank] = (ok, plan)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4, 6])
+def test_solve_2d_flow_gloo_is_bit_identical_to_one_process(world):
+    """World 2 (solves dealt to single ranks), 4 (one solve per rank) and 6 (two solves row-sharded over rank pairs): sub-groups are
+    created collectively, rows gathered inside a group, results published by the group's leader; every rank ends with every solve's
+    full result, equal bit for bit to the unsharded computation."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_plan2d_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert all(res[r][0] for r in range(world)), res
+    assert all(res[r][1] == res[0][1] for r in range(world))

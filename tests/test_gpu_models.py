@@ -977,6 +977,11 @@ def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out, layers=2):
                       INC_MI355X_GPTQ_MULTI_GPU=mode)
     import torch.distributed as dist
 
+    if os.environ.get("TEST_GPTQ_SOLVE_2D") is not None:  # (the parent test's choice of the solve form: a module attribute, not a product switch)
+        import neural_compressor_amd.torch.algorithms.weight_only.gptq as G2
+
+        G2.SOLVE_2D = os.environ["TEST_GPTQ_SOLVE_2D"] == "1"
+
     from neural_compressor_amd import distributed as D
     from neural_compressor_amd.torch.quantization import GPTQConfig, convert, prepare
 
@@ -991,10 +996,20 @@ def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out, layers=2):
     model = prepare(tiny_llama(layers=layers), GPTQConfig(bits=4, group_size=32, block_size=128, **cfg_kw))
     rq = model.quantizer.gptq_quantizer
     assert (rq.layer_ctx if mode == "layer" else rq.dist_ctx) is not None
+    plans = []
+    if mode != "layer":  # record which form of the distributed solve every block took
+        orig_plan = rq._plan_2d
+
+        def spy(batches, solvers, distinct):
+            p2 = orig_plan(batches, solvers, distinct)
+            plans.append(None if p2 is None else [(tuple(names), leader, None if sub is None else sub.world) for names, _, sub, leader in p2])
+            return p2
+
+        rq._plan_2d = spy
     for j in mine:
         model(ids[j])
     q = convert(model)
-    res = {}
+    res = {"__plans__": plans} if mode != "layer" else {}
     for n, m in _woq_modules(q).items():
         res[n] = (m.qweight.cpu(), m.scales.cpu(), m.qzeros.cpu(), None if m.g_idx is None else m.g_idx.cpu())
     with torch.no_grad():
@@ -1003,7 +1018,7 @@ def _multi_gpu_worker(rank, world, port, mode, cfg_kw, out, layers=2):
     dist.destroy_process_group()
 
 
-def _spawn_multi_gpu(mode, cfg_kw, layers=2):
+def _spawn_multi_gpu(mode, cfg_kw, layers=2, world=2):
     import socket
 
     import torch.multiprocessing as mp
@@ -1014,7 +1029,7 @@ def _spawn_multi_gpu(mode, cfg_kw, layers=2):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_multi_gpu_worker, args=(2, port, mode, cfg_kw, out, layers), nprocs=2, join=True)
+        mp.spawn(_multi_gpu_worker, args=(world, port, mode, cfg_kw, out, layers), nprocs=world, join=True)
         return {r: dict(v) for r, v in out.items()}
 
 
@@ -1047,6 +1062,9 @@ def test_gptq_row_sharded_solve_two_ranks_is_bit_identical_to_single_process(cfg
     changes a single bit: both ranks must pack exactly the single-process model (two processes share the one test
     GPU, gloo between them; the production backend is RCCL)."""
     res = _spawn_multi_gpu("rows", cfg_kw)
+    plans = [res[r].pop("__plans__") for r in sorted(res)]
+    # the default form is 2-D: with two ranks the four solves of a block are dealt to single ranks (no row sharding inside a group)
+    assert plans[0] and all(p is not None and all(w in (None, 1) for _, _, w in p) for p in plans[0]), plans[0]
     single = _single_process(cfg_kw)
     assert res[0].keys() == res[1].keys() == single.keys() and len(single) == 15
     for n in single:
@@ -1064,6 +1082,8 @@ def test_gptq_sample_and_row_sharded_two_ranks():
     single-process run only the fp32 summation order of the Hessian differs (rounding-tie flips)."""
     cfg_kw = dict(use_sym=True)
     res = _spawn_multi_gpu("sample+rows", cfg_kw)
+    for r in res:
+        res[r].pop("__plans__")
     single = _single_process(cfg_kw)
     assert res[0].keys() == res[1].keys() == single.keys()
     for n in single:
@@ -1076,6 +1096,38 @@ def test_gptq_sample_and_row_sharded_two_ranks():
     first = min(_nibble_match(res[0][n][0].numpy(), single[n][0].numpy()) for n in single if ".layers.0." in n)
     worst = min(_nibble_match(res[0][n][0].numpy(), single[n][0].numpy()) for n in single if n != "__logits__")
     assert first >= 0.99 and worst >= 0.95, (first, worst)
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("world,form", [(4, "2d"), (3, "2d"), (2, "rows-only")])
+def test_gptq_solve_2d_and_rows_only_forms_are_bit_identical_to_single_process(world, form, monkeypatch):
+    """Mode "rows" in its 2-D form (distributed.plan_solves_2d: module x rows -- four ranks = one solve of a Llama block per rank, three
+    ranks = two solves share a rank) and in its rows-only form (every solve row-sharded over all ranks): every rank packs exactly the
+    single-process model, bit for bit (asym + act_order: permutation, zero points and g_idx travel too).  Ranks share the one test GPU,
+    gloo between them."""
+    cfg_kw = dict(use_sym=False, act_order=True)
+    monkeypatch.setenv("TEST_GPTQ_SOLVE_2D", "1" if form == "2d" else "0")
+    res = _spawn_multi_gpu("rows", cfg_kw, world=world)
+    plans = {r: res[r].pop("__plans__") for r in res}
+    if form == "2d":
+        for r in range(world):
+            assert plans[r] and all(p is not None and len(p) == 4 for p in plans[r])
+            # this rank is a member (group size not None) of exactly the solves the plan gives it
+            leaders = [leader for _, leader, _ in plans[r][0]]
+            assert sorted(set(leaders)) == list(range(min(world, 4)))
+            mine = [w for _, _, w in plans[r][0] if w is not None]
+            assert len(mine) >= 1 and all(w == 1 for w in mine)
+    else:
+        assert all(p is None for p in plans[0])
+    single = _single_process(cfg_kw)
+    for r in range(world):
+        assert res[r].keys() == single.keys()
+        for n in single:
+            if n == "__logits__":
+                assert torch.equal(res[r][n], single[n])
+                continue
+            for a, c in zip(res[r][n], single[n]):
+                assert _same(a, c), (r, n)
 
 
 def _single_process_independent_blocks(cfg_kw, layers=2):
