@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void woq_gemv_w4_body(
       const float sc = f16_bits_to_f32((uint16_t)(sw[c >> 1] >> (16 * (c & 1))));
       uint32_t zz = ((zraw[gi] >> (zsh + 4 * c)) & 15u) + 1u;
       zz = zz > 15u ? 0u : zz;
-      const uint4 bq = dequant8<IS_BF16>(ww[c], sc * inv_u, -(float)zz * sc);
+      const uint4 bq = dequant8<IS_BF16, 1>(ww[c], sc * inv_u, -(float)zz * sc);  // (packed fp32 FMAs: same values; with four MFMAs per step the VALU is the busy pipe here: - 5 % per launch, tools/gemv_lab)
 #pragma unroll
       for (int b = 0; b < MB; ++b) acc[b][c] = mfma16<IS_BF16>(av[b], bq, acc[b][c]);
     }
@@ -1258,19 +1258,6 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
 // (inc_woq_gemm_multi): a decode call of one module is ~2 us of streaming behind ~5 us of launch boundary, first-byte latency and
 // split-K hand-off, and the modules of a group are independent given x.  The strips of the modules occupy consecutive ranges of
 // blockIdx.x; every strip runs exactly the body above on its own module's tensors -> bit-identical to the single launches.
-constexpr int GEMV_MAX_BATCH = 8;
-struct GemvBatch {
-  const uint32_t* qweight[GEMV_MAX_BATCH];
-  const uint16_t* scales[GEMV_MAX_BATCH];
-  const uint32_t* qzeros[GEMV_MAX_BATCH];
-  const uint16_t* bias[GEMV_MAX_BATCH];
-  uint16_t* y[GEMV_MAX_BATCH];
-  int64_t N[GEMV_MAX_BATCH];
-  int64_t part_off[GEMV_MAX_BATCH];  // first float of the module's split-K slabs in the workspace
-  int first[GEMV_MAX_BATCH + 1];     // first strip of every module, then the number of strips
-  int n;
-};
-
 template <bool IS_BF16, bool G128, int VSTEPS, int MB>
 __global__ __launch_bounds__(256) void woq_gemv_w4_multi_kernel(GemvBatch args, const uint16_t* __restrict__ x, float* __restrict__ partial,
                                                                 unsigned* __restrict__ counters, int M, int64_t K, int g_shift, int splitk) {
@@ -1699,7 +1686,7 @@ __global__ __launch_bounds__(64 * GEMV16_WAVES) void woq_gemv16_w4_kernel(
         const float sc = f16_bits_to_f32(sraw[s]);
         uint32_t zz = ((zraw[s] >> zsh) & 15u) + 1u;  // modules.py:407-410 (stored zp - 1; wraps above 15)
         zz = zz > 15u ? 0u : zz;
-        const uint4 bq = dequant8<IS_BF16>(w[s], sc * inv_u, -(float)zz * sc);
+        const uint4 bq = dequant8<IS_BF16, 1>(w[s], sc * inv_u, -(float)zz * sc);
         acc = mfma16<IS_BF16>(a[s], bq, acc);
       }
     }

@@ -18,6 +18,20 @@ int inc_launch_woq_gemm_strip8(const uint16_t* x, const uint32_t* qw, const uint
                                uint16_t* y, int64_t M, int64_t N, int64_t K, int64_t NW, int g_shift, float* part, unsigned* counters,
                                int splitk, bool bf, hipStream_t s);
 
+// modules that share x, one launch (inc_woq_gemm_multi): the per-module tensors of the batch, passed to the kernels by value
+constexpr int GEMV_MAX_BATCH = 8;
+struct GemvBatch {
+  const uint32_t* qweight[GEMV_MAX_BATCH];
+  const uint16_t* scales[GEMV_MAX_BATCH];
+  const uint32_t* qzeros[GEMV_MAX_BATCH];
+  const uint16_t* bias[GEMV_MAX_BATCH];
+  uint16_t* y[GEMV_MAX_BATCH];
+  int64_t N[GEMV_MAX_BATCH];
+  int64_t part_off[GEMV_MAX_BATCH];  // first float of the module's split-K slabs in the workspace
+  int first[GEMV_MAX_BATCH + 1];     // first strip of every module, then the number of strips
+  int n;
+};
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

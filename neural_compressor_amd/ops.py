@@ -355,6 +355,13 @@ class WoqGemmGroupCall:
         self.yarr = (ctypes.c_void_p * n)()
         self.need = {}
 
+    # a cache, not state: copies and pickles of the owning module start without it
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_none, ())
+
     def current(self, parts):
         mine = self.keep[0]
         return (len(parts) == len(mine) and all(a is b for p, q in zip(parts, mine) for a, b in zip(p[:4], q[:4]))

@@ -380,9 +380,6 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
 # the reference's class name for the non-Gaudi device class; code that imports it keeps working
 INCWeightOnlyLinear = MI355XWeightOnlyLinear
 
-_GROUP_CALLS = {}
-
-
 def woq_linear_group(x, modules):
     """[m(x) for m in modules] for packed modules that multiply the SAME activation -- q / k / v of an attention block, gate / up of
     an MLP -- as ONE launch (inc_woq_gemm_multi) when x is a decode-sized batch (<= 64 rows).  Each module keeps its own buffers and
@@ -402,12 +399,15 @@ def woq_linear_group(x, modules):
             if not x2d.is_contiguous():
                 x2d = x2d.contiguous()
             parts = [(m.qweight, m.scales, m.qzeros, m.bias, m.out_features) for m in mods]
-            key = tuple(id(m) for m in mods) + (x.dtype,)
-            call = _GROUP_CALLS.get(key)
+            # the prepared call lives on the group's first module (a cache, not state: it dies with the module, copies and pickles of the
+            # module start without it) and is rebuilt when any buffer of the group is replaced or written to
+            cache = m0.__dict__.setdefault("_group_calls", {})
+            key = tuple(id(m) for m in mods[1:]) + (x.dtype,)
+            call = cache.get(key)
             if call is None or not call.current(parts):
-                if len(_GROUP_CALLS) > 4096:
-                    _GROUP_CALLS.clear()
-                call = _GROUP_CALLS[key] = ops.WoqGemmGroupCall(parts, K, m0.group_size, m0.bits, x.dtype)
+                if len(cache) >= 8:
+                    cache.clear()
+                call = cache[key] = ops.WoqGemmGroupCall(parts, K, m0.group_size, m0.bits, x.dtype)
             ys = call(x2d)
             if ys is not None:
                 return [y.view(*x.shape[:-1], m.out_features) for y, m in zip(ys, mods)]

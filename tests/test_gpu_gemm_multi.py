@@ -134,3 +134,31 @@ def test_gemm_multi_falls_back_to_single_calls_when_not_eligible(hip):
     x = torch.randn(2, K).to(torch.bfloat16).to(hip)
     a, b = call(x), call(x)
     assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
+def test_gemm_multi_cache_is_not_module_state(hip):
+    """The prepared group call is a cache on the group's first module: the state dict, copies and pickles of the module do not carry it,
+    and replacing a buffer of any module of the group rebuilds it."""
+    import copy
+    import pickle
+
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import woq_linear_group
+
+    K = 512
+    mods = [_packed(hip, 256, K, 21), _packed(hip, 128, K, 22)]
+    keys = set(mods[0].state_dict().keys())
+    x = torch.randn(2, K).to(torch.bfloat16).to(hip)
+    y0 = woq_linear_group(x, mods)
+    assert "_group_calls" in mods[0].__dict__ and set(mods[0].state_dict().keys()) == keys
+    clone = copy.deepcopy(mods[0])
+    assert not any(clone.__dict__.get("_group_calls", {}).values())
+    again = pickle.loads(pickle.dumps(mods[0]))
+    assert torch.equal(again.qweight.cpu(), mods[0].qweight.cpu())
+    assert all(torch.equal(a, b) for a, b in zip(woq_linear_group(x, [clone, mods[1]]), y0))
+    # a replaced buffer (re-packing, load_state_dict): the cached addresses must not be used again
+    other = _packed(hip, 128, K, 23)
+    mods[1].qweight = other.qweight.clone()
+    mods[1].scales = other.scales.clone()
+    mods[1].qzeros = other.qzeros.clone()
+    y1 = woq_linear_group(x, mods)
+    assert torch.equal(y1[0], y0[0]) and torch.equal(y1[1], other(x)) and not torch.equal(y1[1], y0[1])
