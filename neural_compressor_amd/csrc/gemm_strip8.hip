@@ -23,6 +23,9 @@ constexpr int S8_WAVES = 4;
 #ifndef S8_RING_DEPTH
 #define S8_RING_DEPTH 3
 #endif
+#ifndef S8_INTERLEAVE
+#define S8_INTERLEAVE 0  // (1: pin "one MFMA, three VALU" with sched_group_barrier -- measured equal to the compiler's own schedule, tools/midm_lab)
+#endif
 #ifndef S8_ABL
 #define S8_ABL 0  // lab builds only (tools/midm_lab): timing-only ablations, WRONG results: 1 no x requests, 2 no W requests, 4 no MFMA / dequantisation, 8 no epilogue
 #endif
@@ -186,16 +189,27 @@ __global__ __launch_bounds__(64 * S8_WAVES) void woq_gemm_w4_strip8_kernel(
         }
     }
   };
+  // One wave per SIMD: nobody else fills the matrix pipe while this wave dequantises, and nobody else feeds the VALU while its MFMAs
+  // queue up.  Left to the compiler the step is dequantise(word) -> 8 MFMAs -> dequantise(next word) ...: 64 x 16 matrix cycles PLUS 8 x ~76
+  // VALU cycles (tools/midm_lab: the K-loop costs the sum).  Here the NEXT word is dequantised between the MFMAs of the current one -- one
+  // MFMA, then up to three VALU instructions, eight times per word (sched_group_barrier: 0x8 = MFMA, 0x2 = VALU).
   auto compute = [&](const Step& t) {
+    const uint32_t ww[8] = {t.w[0].x, t.w[0].y, t.w[0].z, t.w[0].w, t.w[1].x, t.w[1].y, t.w[1].z, t.w[1].w};
+    uint4 bq = dequant8<IS_BF16>(ww[0], scu[0], nzs[0]);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const uint32_t ww[4] = {t.w[nb].x, t.w[nb].y, t.w[nb].z, t.w[nb].w};
+    for (int c = 0; c < 8; ++c) {
+      uint4 bqn = bq;
+      if (c + 1 < 8) bqn = dequant8<IS_BF16>(ww[c + 1], scu[c + 1], nzs[c + 1]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint4 bq = dequant8<IS_BF16>(ww[c], scu[4 * nb + c], nzs[4 * nb + c]);
+      for (int b = 0; b < MB; ++b) acc[b][c] = mfma16<IS_BF16>(t.a[b], bq, acc[b][c]);
+#if S8_INTERLEAVE
 #pragma unroll
-        for (int b = 0; b < MB; ++b) acc[b][4 * nb + c] = mfma16<IS_BF16>(t.a[b], bq, acc[b][4 * nb + c]);
+      for (int b = 0; b < MB; ++b) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
       }
+#endif
+      bq = bqn;
     }
   };
 
