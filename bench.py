@@ -830,6 +830,47 @@ def bench_e2e(device, args, rank, world, note):
     return out
 
 
+def bench_awq_sq_e2e(device, note):
+    """BASELINE configs #3 and #4 un-extrapolated (--e2e-configs; ~4 minutes, not part of the default line): a Llama-2-7B-shaped model
+    (32 blocks) through prepare -> 128 x 2048 calibration tokens -> convert with AWQConfig(INT4 g128, auto-scale + auto-clip), and a
+    Llama-2-13B-shaped model (40 blocks, hidden 5120, ffn 13824) through SmoothQuantConfig(alpha 0.5) with 32 x 2048 tokens; wall-clock."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from neural_compressor_amd.torch.quantization import AWQConfig, SmoothQuantConfig, convert, prepare
+
+    out = {}
+    g = torch.Generator().manual_seed(1)
+    for tag, (hidden, inter, heads, layers), n, seq, cfg in (
+        ("awq_e2e", (4096, 11008, 32, 32), 128, 2048, AWQConfig(bits=4, group_size=128, use_sym=False, use_auto_scale=True, use_auto_clip=True)),
+        ("smoothquant_e2e", (5120, 13824, 40, 40), 32, 2048, SmoothQuantConfig(alpha=0.5, folding=False, scale_sharing=True)),
+    ):
+        mc = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
+                         num_key_value_heads=heads, vocab_size=32000, max_position_embeddings=4096, tie_word_embeddings=False)
+        torch.manual_seed(0)
+        with torch.device(device):
+            model = LlamaForCausalLM(mc)
+        model = model.to(torch.bfloat16).eval()
+        model.config.use_cache = False
+        if tag == "smoothquant_e2e":
+            cfg.set_local("lm_head", SmoothQuantConfig(w_dtype="fp32"))
+        ids = [torch.randint(0, 32000, (1, seq), generator=g) for _ in range(n)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            model = prepare(model, cfg, example_inputs=ids[0].to(device))
+            for x in ids:
+                model(x.to(device))
+            model = convert(model)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[tag] = dict(wall_s=round(dt, 2), blocks=layers, samples=n, seq_len=seq, hidden=hidden, ffn=inter,
+                        what="prepare -> calibration forwards -> convert of the whole model, wall-clock")
+        note(f"{tag}: {dt:.1f}s for {layers} blocks")
+        del model, ids
+        torch.cuda.empty_cache()
+    return out
+
+
 def bench_awq_sq_blocks(device, note):
     """BASELINE configs #3 (AWQ INT4 g128, auto-scale + auto-clip; one Llama-2-7B-shaped block, 128 x 2048 tokens: the headline's set) and #4
     (SmoothQuant W8A8 calibrate + convert; one Llama-2-13B-shaped block, 32 x 2048 tokens): wall-clock per block."""
@@ -1004,6 +1045,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--no-per-layer", action="store_true")
+    ap.add_argument("--e2e-configs", action="store_true", help="also run BASELINE configs #3 (AWQ, 32 blocks) and #4 (SmoothQuant, 40 blocks) end to end (~4 min)")
     ap.add_argument("--mgpu-mode", choices=("layer", "exact"), default="layer", help="N > 1: one block per GPU on float activations (north_star) | exact reference semantics")
     ap.add_argument("--layer-on-one-gpu", action="store_true", help="N = 1: time the layer-per-GPU mode's round (float forward + quantise, no exchange)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="llama2-7b", help="llama2-70b: BASELINE config #5's block shape (hidden 8192, ffn 28672, GQA 64:8)")
@@ -1265,6 +1307,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra_configs:
         result.update(bench_awq_sq_blocks(device, note))
         result["rtn_config1"] = bench_rtn_config1(device, note)
+        if args.e2e_configs:
+            result.update(bench_awq_sq_e2e(device, note))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
         note("cpu baseline done")

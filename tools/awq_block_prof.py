@@ -15,7 +15,8 @@ from neural_compressor_amd.torch.quantization import AWQConfig, convert, prepare
 device = "cuda"
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 g = torch.Generator().manual_seed(1)
-ids = [torch.randint(0, 32000, (1, 512), generator=g) for _ in range(128)]
+SEQ = int(os.environ.get("AWQ_PROF_SEQ", "2048"))  # 2048 = the headline calibration set (bench.py awq_block)
+ids = [torch.randint(0, 32000, (1, SEQ), generator=g) for _ in range(128)]
 for run in range(runs):
     cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32,
                       num_key_value_heads=32, vocab_size=32000, max_position_embeddings=4096, tie_word_embeddings=False)
