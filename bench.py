@@ -279,6 +279,69 @@ def bench_dequant_gemm(device, shapes, iters=20):
     return res
 
 
+def bench_int8_rows(device):
+    """Weight-only INT8 (BASELINE config #1's packed format, bits = 8, per-channel scales) forward at the BASELINE layer sizes: decode (M = 1,
+    cold ring of distinct modules >= 512 MiB, bytes = the packed bytes) and prefill (M = 4096, TFLOP/s)."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    res = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for N, K in ((4096, 4096), (11008, 4096)):
+        torch.manual_seed(0)
+        w = torch.randn(N, K, device=device) * 0.02
+        iw, sc, _ = quant_tensor(w, bits=8, group_size=-1, scheme="sym", return_int=True)
+        m = MI355XWeightOnlyLinear(K, N, bits=8, group_size=-1, device=device)
+        m.pack(iw, sc, None, None)
+        m.bias = None
+        del w, iw
+        per = m.qweight.numel() * 4 + m.scales.numel() * 2 + m.qzeros.numel() * 4
+        row = dict(N=N, K=K, bits=8, group_size=-1, packed_bytes=int(per))
+        try:
+            ring_n = int(max(2, -(-(512 << 20) // per)))
+            ring = [m] + [copy.deepcopy(m) for _ in range(ring_n - 1)]
+            x1 = torch.randn(1, K, device=device, dtype=torch.bfloat16)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    for mod in ring:
+                        mod(x1)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for mod in ring:
+                    mod(x1)
+            graph.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / (5 * ring_n)
+            row.update(decode_cold_ms=round(t, 5), decode_cold_gbs=round(per / t / 1e6, 1), decode_cold_hbm_frac=round(per / t / 1e6 / HBM_PEAK_GBS, 4))
+            del graph, ring
+        except Exception as e:  # pragma: no cover - report, never fake
+            print(f"[bench] INT8 decode timing failed: {type(e).__name__}: {e}", file=sys.stderr)
+        x = torch.randn(4096, K, device=device, dtype=torch.bfloat16)
+        for _ in range(30):
+            m(x)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            m(x)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 20
+        row.update(prefill_M=4096, prefill_ms=round(t, 4), prefill_tflops=round(2.0 * 4096 * N * K / t / 1e9, 1),
+                   prefill_frac=round(2.0 * 4096 * N * K / t / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4))
+        res.append(row)
+        del m, x
+        torch.cuda.empty_cache()
+    return res
+
+
 def bench_gemv_groups(device):
     """Decode (M = 1) of the module groups that share x -- q / k / v and gate / up of a Llama-2-7B block -- as ONE launch per group
     (inc_woq_gemm_multi via woq_linear_group), measured COLD: a hipGraph over a ring of groups with distinct packed weights (>= 512 MiB),
@@ -994,6 +1057,12 @@ def compact_line(full):
             roof[f"gemv_group_{r['group']}_hbm_frac_cold"] = r["cold_graph_frac"]
             roof[f"gemv_group_{r['group']}_us_cold"] = round(r["cold_graph_ms"] * 1e3, 2)
             roof[f"gemv_group_{r['group']}_single_calls_hbm_frac_cold"] = r.get("single_calls_cold_graph_frac")
+    for r in full.get("int8_weight_only") or []:  # weight-only INT8 (config #1's format): cold decode and prefill
+        tag = f"{r['N']}x{r['K']}"
+        if r.get("decode_cold_hbm_frac") is not None:
+            roof[f"int8_gemv_1x{tag}_hbm_frac_cold"] = r["decode_cold_hbm_frac"]
+            roof[f"int8_gemv_1x{tag}_us_cold"] = round(r["decode_cold_ms"] * 1e3, 2)
+        roof[f"int8_gemm_4096x{tag}_frac"] = r.get("prefill_frac")
     per = full.get("per_layer") or {}
     for k, v in per.items():
         if k.startswith("fasterquant_"):
@@ -1292,6 +1361,7 @@ def main():
         result["dequant_gemm"] = bench_dequant_gemm(device, shapes)
         if WORKLOAD == "llama2-7b":
             result["dequant_gemv_groups"] = bench_gemv_groups(device)
+            result["int8_weight_only"] = bench_int8_rows(device)
         note("dequant-GEMM shapes timed")
         result["w8a8_gemm"] = bench_w8a8_gemm(device, [(4096, 5120, 5120), (4096, 13824, 5120), (4096, 5120, 13824)])
         note("W8A8 shapes timed")

@@ -137,11 +137,11 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
 /* Several packed modules that multiply the SAME x, in ONE launch -- the decode path of q / k / v (and of gate / up): n calls of
  * INCWeightOnlyLinear.forward (modules.py:594-610) on one activation, which the reference issues one F.linear after the other.
  *   x [M,K] of `xdtype`, M <= 64; module i: qweight[i] [K/8,N[i]], scales[i] [G,N[i]] fp16, qzeros[i] [G,ceil(N[i]/8)], bias[i] [N[i]] of
- *   `xdtype` or NULL (bias itself may be NULL), y[i] [M,N[i]] of `xdtype`; K, group_size and bits (4) are common, no g_idx.
+ *   `xdtype` or NULL (bias itself may be NULL), y[i] [M,N[i]] of `xdtype`; K, group_size and bits (4, or 8 with M <= 16) are common, no g_idx.
  *   The arrays of pointers / sizes live in HOST memory (like inc_gptq_hessian_accum_multi); the state dict is untouched.
  *   Every 64-column strip is computed exactly as inc_woq_gemm's streaming kernel computes it, so the launch is bit-identical to
  *   inc_woq_gemm on the N-concatenated module (deterministic: fixed-order split-K sum).  INC_ERR_UNSUPPORTED (nothing launched)
- *   when the batch is not eligible (n < 2 or > 8, M > 64, bits != 4, a group size that is not a power of two >= 32 or one
+ *   when the batch is not eligible (n < 2 or > 8, M > 64, bits other than 4 / 8, a group size that is not a power of two >= 32 or one
  *   group, N[i] < 64 or N[i] % 4 != 0, K % 32 != 0, unaligned x, or M > 32 on more than 24 Mi weights, where inc_woq_gemm's
  *   strip kernel is the faster form): call inc_woq_gemm per module then.
  *   `workspace`: inc_woq_gemm_multi_workspace_bytes bytes; its first 16 KiB are arrival counters with the rules of inc_woq_gemm's. */

@@ -1095,7 +1095,10 @@ constexpr int VS = 8;   // largest VSTEPS (sizes the workspace)
 // M <= 16 case -- every dequantised B fragment feeds MB MFMAs -- instead of parking a 256-row tile that is mostly clamped rows.
 // NT (harness A/B, same results): the packed-weight requests carry the non-temporal hint -- every word is read once by one CU
 // The body of one (64-column strip, K-slice) workgroup: `counter` is the strip's arrival counter, `partial` the module's slabs.
-template <bool IS_BF16, bool G128, int VSTEPS, int MB, bool NT = false>
+// BITS = 8 (weight-only INT8, round 6): a step's 32 k of four columns are TWO packed rows per lane (a word = 4 k of one column), the
+// integer -> float step is the int8 wrap of dequant8_from_bytes (bit-identical to inc_woq_dequant); always 4 steps per wave, so a wave
+// streams the same 8 KiB as the 4-bit form with 8 steps.  `NW` = words per row of qzeros (N / 8 for 4 bits, N / 4 for 8).
+template <bool IS_BF16, bool G128, int VSTEPS, int MB, bool NT = false, int BITS = 4>
 __device__ __forceinline__ void woq_gemv_w4_body(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
@@ -1115,12 +1118,17 @@ __device__ __forceinline__ void woq_gemv_w4_body(
   const int step0 = (slice * 4 + wave) * VS;
 
   // ---- issue every load of this wave up front ---------------------------------------------------
-  uint4 w[VS], a[MB][VS];
+  constexpr int WPS = BITS == 8 ? 2 : 1;  // 16-byte weight requests per lane and step
+  static_assert(BITS == 4 || (BITS == 8 && !NT), "4- or 8-bit words");
+  uint4 w[VS * WPS], a[MB][VS];
 #pragma unroll
   for (int s = 0; s < VS; ++s) {
     int st = step0 + s;
     if (st > steps_total - 1) st = steps_total - 1;  // past-the-end steps re-read the last one and are zeroed via A
-    if constexpr (NT) {
+    if constexpr (BITS == 8) {
+      w[2 * s] = *reinterpret_cast<const uint4*>(qweight + ((int64_t)st * 8 + 2 * oct) * N + ncol);
+      w[2 * s + 1] = *reinterpret_cast<const uint4*>(qweight + ((int64_t)st * 8 + 2 * oct + 1) * N + ncol);
+    } else if constexpr (NT) {
       typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
       const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(qweight + ((int64_t)st * 4 + oct) * N + ncol));
       w[s] = make_uint4(v.x, v.y, v.z, v.w);
@@ -1143,7 +1151,7 @@ __device__ __forceinline__ void woq_gemv_w4_body(
     if (st > steps_total - 1) st = steps_total - 1;
     const int64_t g = g_shift >= 0 ? (((int64_t)st * 32) >> g_shift) : 0;
     sraw[i] = *reinterpret_cast<const uint2*>(scales + g * N + ncol);
-    zraw[i] = qzeros[g * NW + (ncol >> 3)];
+    zraw[i] = qzeros[g * NW + (BITS == 8 ? (ncol >> 2) : (ncol >> 3))];
   }
   const int zsh = 4 * (int)(ncol & 7);  // ncol % 4 == 0: the 4 zero nibbles sit at bits zsh .. zsh+15
   // this thread's outputs of the strip: idx = tid + 256*i -> row idx>>6, column idx&63; bias fetched now
@@ -1177,10 +1185,19 @@ __device__ __forceinline__ void woq_gemv_w4_body(
       av[b].x = live ? av[b].x : 0u; av[b].y = live ? av[b].y : 0u; av[b].z = live ? av[b].z : 0u; av[b].w = live ? av[b].w : 0u;
     }
     const uint32_t sw[2] = {sraw[gi].x, sraw[gi].y};
-    const uint32_t ww[4] = {w[s].x, w[s].y, w[s].z, w[s].w};
+    const uint32_t ww[4] = {w[s * WPS].x, w[s * WPS].y, w[s * WPS].z, w[s * WPS].w};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float sc = f16_bits_to_f32((uint16_t)(sw[c >> 1] >> (16 * (c & 1))));
+      if constexpr (BITS == 8) {
+        const uint32_t wh[4] = {w[s * WPS + WPS - 1].x, w[s * WPS + WPS - 1].y, w[s * WPS + WPS - 1].z, w[s * WPS + WPS - 1].w};
+        uint32_t z8 = ((zraw[gi] >> (8 * c)) & 255u) + 1u;  // ncol % 4 == 0: the word holds exactly this lane's four zero points
+        z8 = z8 > 255u ? 0u : z8;
+        const uint4 bq8 = dequant8_from_bytes<IS_BF16>(ww[c], wh[c], sc, (int)z8);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[b][c] = mfma16<IS_BF16>(av[b], bq8, acc[b][c]);
+        continue;
+      }
       uint32_t zz = ((zraw[gi] >> (zsh + 4 * c)) & 15u) + 1u;
       zz = zz > 15u ? 0u : zz;
       const uint4 bq = dequant8<IS_BF16, 1>(ww[c], sc * inv_u, -(float)zz * sc);  // (packed fp32 FMAs: same values; with four MFMAs per step the VALU is the busy pipe here: - 5 % per launch, tools/gemv_lab)
@@ -1244,13 +1261,13 @@ __device__ __forceinline__ void woq_gemv_w4_body(
     }
 }
 
-template <bool IS_BF16, bool G128, int VSTEPS, int MB, bool NT = false>
+template <bool IS_BF16, bool G128, int VSTEPS, int MB, bool NT = false, int BITS = 4>
 __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
     const uint16_t* __restrict__ x, const uint32_t* __restrict__ qweight, const uint16_t* __restrict__ scales,
     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
     float* __restrict__ partial, unsigned* __restrict__ counters, int M, int64_t N, int64_t K, int64_t NW,
     int64_t G, int g_shift, int splitk) {
-  woq_gemv_w4_body<IS_BF16, G128, VSTEPS, MB, NT>(x, qweight, scales, qzeros, bias, y, partial, counters + blockIdx.x, M, N, K, NW, g_shift, splitk,
+  woq_gemv_w4_body<IS_BF16, G128, VSTEPS, MB, NT, BITS>(x, qweight, scales, qzeros, bias, y, partial, counters + blockIdx.x, M, N, K, NW, g_shift, splitk,
                                                  (int)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -1258,7 +1275,7 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_kernel(
 // (inc_woq_gemm_multi): a decode call of one module is ~2 us of streaming behind ~5 us of launch boundary, first-byte latency and
 // split-K hand-off, and the modules of a group are independent given x.  The strips of the modules occupy consecutive ranges of
 // blockIdx.x; every strip runs exactly the body above on its own module's tensors -> bit-identical to the single launches.
-template <bool IS_BF16, bool G128, int VSTEPS, int MB>
+template <bool IS_BF16, bool G128, int VSTEPS, int MB, int BITS = 4>
 __global__ __launch_bounds__(256) void woq_gemv_w4_multi_kernel(GemvBatch args, const uint16_t* __restrict__ x, float* __restrict__ partial,
                                                                 unsigned* __restrict__ counters, int M, int64_t K, int g_shift, int splitk) {
   const int b = (int)blockIdx.x;
@@ -1268,8 +1285,9 @@ __global__ __launch_bounds__(256) void woq_gemv_w4_multi_kernel(GemvBatch args, 
     if (i < args.n && b >= args.first[i]) p = i;
   p = __builtin_amdgcn_readfirstlane(p);
   const int64_t N = args.N[p];
-  woq_gemv_w4_body<IS_BF16, G128, VSTEPS, MB>(x, args.qweight[p], args.scales[p], args.qzeros[p], args.bias[p], args.y[p], partial + args.part_off[p],
-                                              counters + b, M, N, K, (N + 7) / 8, g_shift, splitk, b - args.first[p], (int)blockIdx.y);
+  woq_gemv_w4_body<IS_BF16, G128, VSTEPS, MB, false, BITS>(x, args.qweight[p], args.scales[p], args.qzeros[p], args.bias[p], args.y[p],
+                                                           partial + args.part_off[p], counters + b, M, N, K, BITS == 8 ? (N + 3) / 4 : (N + 7) / 8, g_shift,
+                                                           splitk, b - args.first[p], (int)blockIdx.y);
 }
 
 // =============================================================================================
@@ -2073,6 +2091,22 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     else { if (g128) INC_GEMV2(false, true) else INC_GEMV2(false, false) }
 #undef INC_GEMV2
 #undef INC_GEMV
+  } else if (!g_idx && bits == 8 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && M <= 16 && dbg == 0 &&
+             ceil_div64(N, 64) * 4 <= WS_COUNTER_BYTES && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // weight-only INT8 decode (BASELINE config #1's format): the streaming kernel's 8-bit form -- 64-column strips x K-slices of 512 k,
+    // every wave's 8 KiB of packed weights requested before the first use, same hand-off.  (The generic split-K kernel it replaces
+    // here read 16.8 MB in 20.6 us at 4096^2 and 45 MB in 46.7 us at 11008 x 4096: scripts/w8_gemm_time.py.)
+    const int splitk = (int)ceil_div64(K, 32 * 4 * 4);
+    if (!workspace || workspace_bytes < WS_COUNTER_BYTES + (int64_t)splitk * M * N * 4) return INC_ERR_WORKSPACE;
+    unsigned* counters = (unsigned*)workspace;
+    float* part = (float*)((char*)workspace + WS_COUNTER_BYTES);
+    dim3 grid((unsigned)ceil_div64(N, 64), (unsigned)splitk);
+    const bool g128 = g_shift == -1 || g_shift >= 7;
+    const int64_t NW8 = ceil_div64(N, 4);
+#define INC_GEMV8(F, GG) woq_gemv_w4_kernel<F, GG, 4, 1, false, 8><<<grid, 256, 0, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW8, G, g_shift, splitk)
+    if (bf) { if (g128) INC_GEMV8(true, true); else INC_GEMV8(true, false); }
+    else { if (g128) INC_GEMV8(false, true); else INC_GEMV8(false, false); }
+#undef INC_GEMV8
   } else {
     int kw_per_slice = 0;
     const int slices = small_slices(N, K, bits, &kw_per_slice);
@@ -2096,7 +2130,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
 // the modules' columns together -> the launch is bit-identical to inc_woq_gemm on the N-concatenated module (strips are independent)
 static bool gemv_multi_plan(int n, int64_t M, const int64_t* N, int64_t K, int group_size, int bits, int* g_shift_out, int* vsteps_out,
                             int* splitk_out, int64_t* strips_out) {
-  if (n < 2 || n > GEMV_MAX_BATCH || bits != 4 || M < 1 || M > GEMV_MAX_M || K <= 0 || (K % 32) != 0) return false;
+  if (n < 2 || n > GEMV_MAX_BATCH || !(bits == 4 || (bits == 8 && M <= 16)) || M < 1 || M > GEMV_MAX_M || K <= 0 || (K % 32) != 0) return false;
   int g_shift = -2;
   if (group_size >= K) g_shift = -1;
   else if (group_size >= 32 && (group_size & (group_size - 1)) == 0) { g_shift = 0; while ((1 << g_shift) < group_size) ++g_shift; }
@@ -2111,7 +2145,7 @@ static bool gemv_multi_plan(int n, int64_t M, const int64_t* N, int64_t K, int g
   int64_t ntot = 0;
   for (int i = 0; i < n; ++i) ntot += N[i];
   if (M > 32 && ntot * K > ((int64_t)24 << 20)) return false;  // inc_woq_gemm prefers the strip kernel there (21 vs 29 us at 64 x 11008 x 4096)
-  const bool vs4 = M > 16 || (strips * ceil_div64(K, 32 * 8 * 4) < 512 && ceil_div64(K, 32 * 4 * 4) <= 64);
+  const bool vs4 = bits == 8 || M > 16 || (strips * ceil_div64(K, 32 * 8 * 4) < 512 && ceil_div64(K, 32 * 4 * 4) <= 64);
   *g_shift_out = g_shift;
   *vsteps_out = vs4 ? 4 : 8;
   *splitk_out = (int)ceil_div64(K, 32 * (vs4 ? 4 : 8) * 4);
@@ -2163,6 +2197,13 @@ int inc_woq_gemm_multi(int n, const void* x, int xdtype, const int32_t* const* q
   const bool bf = xdtype == INC_BF16, g128 = g_shift == -1 || g_shift >= 7;
 #define INC_GEMVM(F, GG, V, B) woq_gemv_w4_multi_kernel<F, GG, V, B><<<grid, 256, 0, s>>>(args, xp, part, counters, (int)M, K, g_shift, splitk)
 #define INC_GEMVM2(F, GG) { if (M > 32) INC_GEMVM(F, GG, 4, 4); else if (M > 16) INC_GEMVM(F, GG, 4, 2); else if (vsteps == 4) INC_GEMVM(F, GG, 4, 1); else INC_GEMVM(F, GG, 8, 1); }
+  if (bits == 8) {
+#define INC_GEMVM8(F, GG) woq_gemv_w4_multi_kernel<F, GG, 4, 1, 8><<<grid, 256, 0, s>>>(args, xp, part, counters, (int)M, K, g_shift, splitk)
+    if (bf) { if (g128) INC_GEMVM8(true, true); else INC_GEMVM8(true, false); }
+    else { if (g128) INC_GEMVM8(false, true); else INC_GEMVM8(false, false); }
+#undef INC_GEMVM8
+    INC_LAUNCH_RETURN();
+  }
   if (bf) { if (g128) INC_GEMVM2(true, true) else INC_GEMVM2(true, false) }
   else { if (g128) INC_GEMVM2(false, true) else INC_GEMVM2(false, false) }
 #undef INC_GEMVM2

@@ -390,7 +390,7 @@ def woq_linear_group(x, modules):
     mods = list(modules)
     m0 = mods[0]
     ok = (len(mods) >= 2 and x.dtype in (torch.bfloat16, torch.float16) and x.is_cuda and x.numel() > 0
-          and all(isinstance(m, MI355XWeightOnlyLinear) and m.bits == 4 and m.in_features == m0.in_features and m.group_size == m0.group_size
+          and all(isinstance(m, MI355XWeightOnlyLinear) and m.bits in (4, 8) and m.bits == m0.bits and m.in_features == m0.in_features and m.group_size == m0.group_size
                   and m._forward_plan() == "fused" for m in mods))
     if ok:
         K = m0.in_features

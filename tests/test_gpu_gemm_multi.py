@@ -162,3 +162,70 @@ def test_gemm_multi_cache_is_not_module_state(hip):
     mods[1].qzeros = other.qzeros.clone()
     y1 = woq_linear_group(x, mods)
     assert torch.equal(y1[0], y0[0]) and torch.equal(y1[1], other(x)) and not torch.equal(y1[1], y0[1])
+
+
+def _packed8(hip, N, K, gs, seed, sym=True, bias=False):
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(hip)
+    iw, sc, zp = quant_tensor(w, bits=8, group_size=gs, scheme="sym" if sym else "asym", return_int=True)
+    m = MI355XWeightOnlyLinear(K, N, bits=8, group_size=gs, zp=not sym, bias=bias, device=hip)
+    b = (torch.randn(N, generator=g) * 0.1).to(hip) if bias else None
+    m.pack(iw, sc, zp if not sym else None, b)
+    if not bias:
+        m.bias = None
+    return m
+
+
+@pytest.mark.parametrize("N,K,gs,sym", [(4096, 4096, -1, True), (11008, 4096, 128, True), (1000, 1024, 32, False), (4096, 11008, -1, False)])
+@pytest.mark.parametrize("M", [1, 5, 16])
+def test_int8_decode_streaming_kernel_vs_oracle(hip, N, K, gs, sym, M):
+    """Weight-only INT8 (BASELINE config #1's format) at decode sizes: inc_woq_gemm's 8-bit streaming form (two packed rows per lane and
+    step, int8 wrap of q - z, one rounding to the 16-bit type) against the oracle's forward, against HIP recover() + fp32 matmul, and
+    bit-reproducible; per-channel, g128, g32 asym with ragged N, K = 11008."""
+    m = _packed8(hip, N, K, gs, 31 + N % 7, sym=sym, bias=not sym)
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(hip)
+    y = m(x)
+    assert y.shape == (M, N) and y.dtype == torch.bfloat16
+    w = m.recover(dtype=torch.bfloat16).float()
+    ref = x.float() @ w.t() + (m.bias.float() if m.bias is not None else 0.0)
+    e_dev = float((y.float() - ref.to(torch.bfloat16).float()).norm() / ref.norm())
+    qw, sc, qz = m.qweight.cpu().numpy(), m.scales.cpu().numpy(), m.qzeros.cpu().numpy()
+    gsz = K if gs == -1 else gs
+    rows = torch.arange(M)[:4]
+    oref = O.woq_linear(x[rows].cpu(), qw, sc, qz, None if m.bias is None else m.bias.float().cpu(), N, K, 8, gsz, compute_dtype=torch.bfloat16)
+    e_or = float((y[rows].float().cpu() - oref.to(torch.bfloat16).float()).norm() / oref.norm())
+    print(f"\n[int8 decode {N}x{K} gs={gs} {'sym' if sym else 'asym'} M={M}] vs HIP recover + fp32 matmul {e_dev:.2e}, vs oracle {e_or:.2e}")
+    tol = 1e-3 if m.bias is None else 2e-3  # (the module's fp16 bias is added as a bf16 value: its own rounding on top of the output's)
+    assert e_dev <= tol and e_or <= tol
+    assert torch.equal(m(x), y)
+    if m.bias is None:
+        assert torch.equal(m(x * 2), y * 2)  # linear in x: power-of-two scaling is exact
+
+
+def test_int8_group_is_the_concatenated_single_launch(hip):
+    from neural_compressor_amd import ops
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear, woq_linear_group
+
+    K = 4096
+    mods = [_packed8(hip, 4096, K, 128, 41 + i) for i in range(3)]
+    for M in (1, 16):
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).to(torch.bfloat16).to(hip)
+        call = ops.WoqGemmGroupCall([(m.qweight, m.scales, m.qzeros, m.bias, m.out_features) for m in mods], K, 128, 8, torch.bfloat16)
+        ys = call(x)
+        assert ys is not None, "an INT8 decode group is eligible for the one-launch form"
+        assert all(torch.equal(a, b) for a, b in zip(ys, woq_linear_group(x, mods)))
+        c = MI355XWeightOnlyLinear(K, 3 * 4096, bits=8, group_size=128, zp=True, device=hip)
+        c.qweight = torch.cat([m.qweight for m in mods], dim=1).contiguous()
+        c.scales = torch.cat([m.scales for m in mods], dim=1).contiguous()
+        c.qzeros = torch.cat([m.qzeros for m in mods], dim=1).contiguous()
+        c.bias = None
+        yc = c(x)
+        for i, y in enumerate(ys):
+            assert torch.equal(y, yc[:, 4096 * i:4096 * (i + 1)])
+            assert torch.equal(y, mods[i](x))  # 8-bit: the single call takes the same kernel with the same slices
+    assert ops.WoqGemmGroupCall([(m.qweight, m.scales, m.qzeros, m.bias, m.out_features) for m in mods], K, 128, 8, torch.bfloat16)(
+        torch.randn(17, K).to(torch.bfloat16).to(hip)) is None  # more than 16 rows: declined (the tile kernels are the 8-bit route there)
