@@ -294,7 +294,11 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
             x2d = x2d.contiguous()
         plan = self._forward_plan()
         d["_call"] = None
-        if plan == "fused":
+        if plan == "fused" and self._fused_max_m is not None and x2d.shape[0] > self._fused_max_m:
+            plan = "dense"  # (a group size the fast kernels do not take: see _forward_plan)
+        if plan == "fused" and self._fused_max_m is not None:
+            y = ops.woq_gemm(x2d, self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features, self.group_size, self.bits)
+        elif plan == "fused":
             call = d["_call"] = ops.WoqGemmCall(self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features,
                                                 self.group_size, self.bits, x2d.dtype)
             gi = self.g_idx
@@ -341,6 +345,12 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         # the library GEMM at 4096^2 for every M from 1 to 4096, profiles/r6/anyw_route_time.log -- so it is opt-in: ODD_WIDTH_FUSED)
         fusable = self.use_optimum_format and (self.group_size % self.n_pack == 0 if self.bits in (4, 8) else self.ODD_WIDTH_FUSED)
         self._k_order = self._qweight_sorted = None
+        # group sizes that are neither a power of two >= 32 nor the whole row (e.g. 96) run inc_woq_gemm's general 128 x 128 tile kernel
+        # above 16 rows: 190-245 us at 4096 x 4032 against 34-74 us for HIP recover() + the library GEMM (scripts/route_sweep.py) -- such
+        # modules keep the fused form for decode-sized batches only
+        gs_eff = self.in_features if (self.group_size == -1 or self.group_size >= self.in_features) else self.group_size
+        fast_groups = gs_eff == self.in_features or (gs_eff >= 32 and (gs_eff & (gs_eff - 1)) == 0)
+        self._fused_max_m = None if (fast_groups or self.bits not in (4, 8)) else 16
         if fusable:
             K, gs = self.in_features, self.group_size
             if self.g_idx is None:

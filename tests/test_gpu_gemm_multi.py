@@ -229,3 +229,26 @@ def test_int8_group_is_the_concatenated_single_launch(hip):
             assert torch.equal(y, mods[i](x))  # 8-bit: the single call takes the same kernel with the same slices
     assert ops.WoqGemmGroupCall([(m.qweight, m.scales, m.qzeros, m.bias, m.out_features) for m in mods], K, 128, 8, torch.bfloat16)(
         torch.randn(17, K).to(torch.bfloat16).to(hip)) is None  # more than 16 rows: declined (the tile kernels are the 8-bit route there)
+
+
+def test_group_size_that_is_no_power_of_two_takes_the_dense_route_above_16_rows(hip):
+    """group_size 96 (neither a power of two nor the whole row): decode-sized batches stay fused (the M <= 16 split-K kernel), larger ones
+    go through HIP recover() + the library GEMM -- the general tile kernel they used to take is 3-7 x slower (scripts/route_sweep.py).
+    Both routes agree with the dense reference."""
+    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
+    from neural_compressor_amd.torch.algorithms.weight_only.utility import quant_tensor
+
+    N, K, gs = 512, 960, 96
+    w = (torch.randn(N, K, generator=torch.Generator().manual_seed(3)) * 0.02).to(hip)
+    iw, sc, zp = quant_tensor(w, bits=4, group_size=gs, scheme="asym", return_int=True)
+    m = MI355XWeightOnlyLinear(K, N, bits=4, group_size=gs, zp=True, device=hip)
+    m.pack(iw, sc, zp, None)
+    m.bias = None
+    wd = m.recover(dtype=torch.bfloat16).float()
+    for M in (3, 16, 17, 200):
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).to(torch.bfloat16).to(hip)
+        y = m(x)
+        ref = (x.float() @ wd.t()).to(torch.bfloat16).float()
+        assert m._plan == "fused" and m._fused_max_m == 16
+        assert float((y.float() - ref).norm() / ref.norm()) <= 2e-3, M
+        assert torch.equal(m(x), y)
