@@ -1771,6 +1771,9 @@ static int big_splitk(int64_t M, int64_t N, int64_t K, int* steps_out) {
 }
 
 constexpr int64_t GEMV_MAX_M = 64;  // M <= 64 streams the weights once (woq_gemv_w4_kernel with 1 / 2 / 4 row blocks)
+// the same for 8-bit words: up to 32 rows everywhere, up to 64 rows while N * K <= 2^25 -- measured against the 8-bit tile kernel
+// (scripts/w8_gemm_time.py: 4096^2 M = 48 / 64: 17.3 / 18.5 vs 24.4 us; 11008 x 4096 M = 32: 18.7 vs 32.7 us, M = 48 / 64: 40.8 / 43.8 vs 32.7 us)
+constexpr int64_t GEMV8_MAX_M = 64, GEMV8_WIDE_MAX_M = 32, GEMV8_WIDE_ELEMS = (int64_t)1 << 25;
 
 int64_t inc_woq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   // an upper bound over the routes inc_woq_gemm can take for (M, N, K) (it does not know bits / group size here)
@@ -1831,7 +1834,10 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 8) < (int64_t)1 << 31;
   const int dbg = inc_small_tiles_flag(-1);
   // weight-only INT8 (BASELINE config #1's layers): the 3A2B kernel's 8-bit instantiation, same tiling and split-K plan
-  const bool big8_ok = !g_idx && bits == 8 && (K % 128) == 0 && g_shift != -2 && M > 16 && N >= 64 && dbg == 0 &&
+  // weight-only INT8 at M <= 64: the streaming kernel's 8-bit form (M <= 16 whatever K; 16 < M <= 64 while its K-slices fit the counters' plan)
+  const bool gemv8_ok = !g_idx && bits == 8 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && M <= GEMV8_MAX_M && dbg == 0 &&
+                        (M <= GEMV8_WIDE_MAX_M || N * K <= GEMV8_WIDE_ELEMS) && (M <= 16 || ceil_div64(K, 32 * 4 * 4) <= 64) && ceil_div64(N, 64) * 4 <= WS_COUNTER_BYTES && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  const bool big8_ok = !gemv8_ok && !g_idx && bits == 8 && (K % 128) == 0 && g_shift != -2 && M > 16 && N >= 64 && dbg == 0 &&
                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && N * (K / 4) < (int64_t)1 << 31;
   // 64 < M <= 1024 with at most 64 tiles of 256 x 256: the strip kernel (no 256-row tiles, no slab passes).  With more tiles the
   // producer / consumer kernel fills the chip with <= 2 slabs and wins (M = 512, N = 11008: 71 vs 81 us; tools/kbench strip).
@@ -2039,7 +2045,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     const int y_vec_ok = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 7) == 0);
     if (bf) woq_gemm_w4_big_kernel<true><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
     else woq_gemm_w4_big_kernel<false><<<grid, 512, smem, s>>>(xp, qw, scales, qz, bp, yp, M, N, K, NW, g_shift, y_vec_ok);
-  } else if (M > 16 && !(gemv_ok && ceil_div64(K, 32 * 4 * 4) <= 64)) {
+  } else if (M > 16 && !gemv8_ok && !(gemv_ok && ceil_div64(K, 32 * 4 * 4) <= 64)) {
     const int x_vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const size_t smem = (size_t)2 * 2 * GM * GP * sizeof(uint16_t);
     static std::atomic<uint64_t> attr_set{0};
@@ -2091,8 +2097,7 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     else { if (g128) INC_GEMV2(false, true) else INC_GEMV2(false, false) }
 #undef INC_GEMV2
 #undef INC_GEMV
-  } else if (!g_idx && bits == 8 && g_shift != -2 && (K % 32) == 0 && (N % 4) == 0 && N >= 64 && M <= 16 && dbg == 0 &&
-             ceil_div64(N, 64) * 4 <= WS_COUNTER_BYTES && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+  } else if (gemv8_ok) {
     // weight-only INT8 decode (BASELINE config #1's format): the streaming kernel's 8-bit form -- 64-column strips x K-slices of 512 k,
     // every wave's 8 KiB of packed weights requested before the first use, same hand-off.  (The generic split-K kernel it replaces
     // here read 16.8 MB in 20.6 us at 4096^2 and 45 MB in 46.7 us at 11008 x 4096: scripts/w8_gemm_time.py.)
@@ -2103,10 +2108,12 @@ int inc_woq_gemm(const void* x, int xdtype, const int32_t* qweight, const uint16
     dim3 grid((unsigned)ceil_div64(N, 64), (unsigned)splitk);
     const bool g128 = g_shift == -1 || g_shift >= 7;
     const int64_t NW8 = ceil_div64(N, 4);
-#define INC_GEMV8(F, GG) woq_gemv_w4_kernel<F, GG, 4, 1, false, 8><<<grid, 256, 0, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW8, G, g_shift, splitk)
-    if (bf) { if (g128) INC_GEMV8(true, true); else INC_GEMV8(true, false); }
-    else { if (g128) INC_GEMV8(false, true); else INC_GEMV8(false, false); }
+#define INC_GEMV8B(F, GG, B) woq_gemv_w4_kernel<F, GG, 4, B, false, 8><<<grid, 256, 0, s>>>(xp, qw, scales, qz, bp, yp, part, counters, (int)M, N, K, NW8, G, g_shift, splitk)
+#define INC_GEMV8(F, GG) { if (M > 32) INC_GEMV8B(F, GG, 4); else if (M > 16) INC_GEMV8B(F, GG, 2); else INC_GEMV8B(F, GG, 1); }
+    if (bf) { if (g128) INC_GEMV8(true, true) else INC_GEMV8(true, false) }
+    else { if (g128) INC_GEMV8(false, true) else INC_GEMV8(false, false) }
 #undef INC_GEMV8
+#undef INC_GEMV8B
   } else {
     int kw_per_slice = 0;
     const int slices = small_slices(N, K, bits, &kw_per_slice);

@@ -42,7 +42,7 @@ for N, K in ((4096, 4096), (11008, 4096)):
         m.pack(iw, sc, None, None)
         m.bias = None
         byts = m.qweight.numel() * 4 + m.scales.numel() * 2 + m.qzeros.numel() * 4
-        for M in (1, 16, 64, 256, 4096):
+        for M in (1, 16, 17, 32, 48, 64, 65, 256, 4096):
             x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
             y = m(x)
             ref = x.float() @ m.recover(dtype=torch.bfloat16).float().t()

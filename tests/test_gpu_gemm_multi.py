@@ -180,11 +180,12 @@ def _packed8(hip, N, K, gs, seed, sym=True, bias=False):
 
 
 @pytest.mark.parametrize("N,K,gs,sym", [(4096, 4096, -1, True), (11008, 4096, 128, True), (1000, 1024, 32, False), (4096, 11008, -1, False)])
-@pytest.mark.parametrize("M", [1, 5, 16])
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 33, 64])
 def test_int8_decode_streaming_kernel_vs_oracle(hip, N, K, gs, sym, M):
     """Weight-only INT8 (BASELINE config #1's format) at decode sizes: inc_woq_gemm's 8-bit streaming form (two packed rows per lane and
     step, int8 wrap of q - z, one rounding to the 16-bit type) against the oracle's forward, against HIP recover() + fp32 matmul, and
-    bit-reproducible; per-channel, g128, g32 asym with ragged N, K = 11008."""
+    bit-reproducible; per-channel, g128, g32 asym with ragged N, K = 11008.  M = 17 / 33 / 64 are the 2- and 4-row-block forms (and, at
+    11008 x 4096 above 32 rows, the 8-bit tile kernel the route falls back to)."""
     m = _packed8(hip, N, K, gs, 31 + N % 7, sym=sym, bias=not sym)
     g = torch.Generator().manual_seed(M)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(hip)
