@@ -437,186 +437,11 @@ constexpr int L2T = 128;  // rows / columns of a lazy-update tile
 #include "../../tools/kbench_gptq_3.inc"  // harness flag 106: the lazy update with split (bf16 x 3) products -- an experiment, not the product
 #endif  // INC_KBENCH
 
-// ---------------------------------------------------------------------------------------------
-// lazy update, third generation: ONE [128 rows x CW columns] tile per workgroup, two workgroups per CU
-// ---------------------------------------------------------------------------------------------
-// The second generation parks a 128 KiB double buffer per workgroup: one workgroup of four waves per CU, one wave per SIMD, and
-// each of them runs its phases back to back -- Err slice in, Hinv tile in, W tile in, 256 dependent-by-four fp32 MFMAs (7.5 us),
-// W tile out -- so the matrix pipe idles through every load and the loads idle through every MFMA: 40 TFLOP/s of the 157 the
-// exact-fp32 MFMA has at 4096^2 (tools/kbench colloop), and the 128 KiB exclude the quantisation chain's workgroups (64 KiB) from
-// the CU, which serialised the look-ahead loop's two streams (kernel trace profiles/r3d: the "rest" update of block b-1 ran for
-// 110-130 us and the chain of block b+1 could not start under it).  Here a workgroup owns one tile and stages only that tile's
-// slice of Hinv ([128 k][CW] fp32: 64 KiB at CW = 128, 16 KiB at CW = 32): two workgroups share a CU (<= 256 registers per wave), one
-// multiplies while the other loads or stores, and a chain workgroup still fits next to one of them.  CW = 32 serves the
-// look-ahead loop's "next 128 columns" update, which sits on the critical path with only N / 128 row tiles to spread: four times
-// the workgroups, a quarter of the dependent MFMAs each.  Per output element the products are added in the order of the
-// second generation (k = 2s + (lane >> 5), s ascending, acc from 0, then W - acc): bit-identical W.
-template <int CW>
-__global__ __launch_bounds__(256, 2) void gptq_lazy_update_v3_kernel(float* __restrict__ w, const float* __restrict__ Hinv,
-                                                                     const float* __restrict__ err, int64_t N, int64_t K,
-                                                                     int64_t i1, int64_t c_begin) {
-  constexpr int NF = CW / 32;
-  // LDS: [0, 64 KiB) the four waves' Err1 slices (16 KiB each), then the Hinv slice [128 k][CW].  At CW = 128 the Hinv slice
-  // REUSES the first 64 KiB: wave w's share of it (k rows 32w .. 32w + 31) lands exactly on wave w's own Err1 slice, which that
-  // wave has finished reading by then -- no workgroup barrier in between.
-  constexpr uint32_t HS_OFF = CW == 128 ? 0u : 65536u;
-  // (the quarter tiles serve the "next 128 columns" update, which the next chain waits for: ahead of the rest of the trailing update,
-  // behind the chain itself)
-  if constexpr (CW != 128) __builtin_amdgcn_s_setprio(2);
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t r0 = (int64_t)blockIdx.y * L2T + wave * 32;  // first row of this wave
-  const int64_t c0 = c_begin + (int64_t)blockIdx.x * CW;
-  const float* const hbase = Hinv + i1 * K;
-
-  // Hinv[i1 + k][c0 .. c0 + CW) -> LDS [k][CW]; this wave moves rows wave * 32 .. + 31 (16 KiB / 4 KiB)
-  auto dma_hinv = [&]() {
-    if constexpr (CW == 128) {
-      int64_t col = c0 + 4 * (lane & 31);
-      if (col > K - 4) col = K - 4;  // partial last tile: clamped columns are never stored
-      const uint32_t v = (uint32_t)(((wave * 32 + (lane >> 5)) * K + col) * 4);
-      const uint32_t step = (uint32_t)(2 * K * 4);
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + HS_OFF + wave * 16384);
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
-        lds_dma_4x1k(hbase, dst + q4 * 4096, v + (4 * q4) * step, v + (4 * q4 + 1) * step, v + (4 * q4 + 2) * step, v + (4 * q4 + 3) * step);
-    } else {
-      int64_t col = c0 + 4 * (lane & 7);
-      if (col > K - 4) col = K - 4;
-      const uint32_t v = (uint32_t)(((wave * 32 + (lane >> 3)) * K + col) * 4);
-      const uint32_t step = (uint32_t)(8 * K * 4);
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + HS_OFF + wave * 4096);
-      lds_dma_4x1k(hbase, dst, v, v + step, v + 2 * step, v + 3 * step);
-    }
-  };
-  // Err1 slice of this wave (32 rows x 512 B) -> LDS by LDS-DMA, two full rows per instruction.  A lane of the MFMA wants ONE row
-  // (A operand: row lane & 31, k = 2s + (lane >> 5)); fetched that way from global memory every load instruction touches 32
-  // different lines and the 16 KiB slice costs 128 KiB of L2 -> CU traffic per wave (four times the tile's Hinv and W bytes
-  // together; the second generation did exactly that).  Through LDS the global side is coalesced, and the 16-byte chunk index is
-  // XOR-ed with (row & 7) on the SOURCE side so that the row-per-lane ds_read_b128 below is conflict-free.
-  {
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + wave * 16384);
-    const int64_t rows_here = N - r0 < 32 ? N - r0 : 32;  // >= 1: the grid has no workgroup without rows; a wave may have none
-    const float* ebase = err + (rows_here > 0 ? r0 : N - 1) * QB;
-    uint32_t v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int R = 2 * j + (lane >> 5);
-      const int Rc = rows_here > 0 ? (R < rows_here ? R : (int)rows_here - 1) : 0;  // rows past N: a valid row's bytes, never stored
-      v[j] = (uint32_t)(Rc * (QB * 4)) + (uint32_t)(((lane & 31) ^ (R & 7)) * 16);
-    }
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) lds_dma_4x1k(ebase, dst + q4 * 4096, v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
-  }
-  if constexpr (CW != 128) dma_hinv();  // separate LDS region: both transfers in flight together
-  // W tile -> registers (D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); rows / columns past the edge clamped
-  float wt[NF][16];
-#pragma unroll
-  for (int nf = 0; nf < NF; ++nf) {
-    int64_t col = c0 + nf * 32 + (lane & 31);
-    if (col > K - 1) col = K - 1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row > N - 1) row = N - 1;
-      wt[nf][r] = w[row * K + col];  // (stays between the DMA asm statements around it: they are compiler memory barriers)
-    }
-  }
-  f32x16 acc[NF];
-#pragma unroll
-  for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
-  // the Err1 DMA is the oldest part of the in-order queue: what was issued after it (the Hinv slice at CW = 32, the W loads) may stay out
-  if constexpr (CW == 128) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-  float a[64];
-  {
-    const int R = lane & 31;
-    const char* eb = smem_raw + wave * 16384 + R * 512;
-    const bool hi = (lane >> 5) != 0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const float4 v4 = *reinterpret_cast<const float4*>(eb + ((j ^ (R & 7)) * 16));
-      a[2 * j] = hi ? v4.y : v4.x;
-      a[2 * j + 1] = hi ? v4.w : v4.z;
-    }
-  }
-  if constexpr (CW == 128) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's slice is in registers: its LDS space takes the wave's Hinv rows
-    dma_hinv();
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const float* hs = reinterpret_cast<const float*>(smem_raw + HS_OFF) + (lane >> 5) * CW + (lane & 31);
-  constexpr int BS = NF == 4 ? 4 : 8;  // k-pairs per batch: the B operands of a batch are read together, then multiplied
-#pragma unroll
-  for (int g = 0; g < 64 / BS; ++g) {
-    float b[BS * NF];
-#pragma unroll
-    for (int sb = 0; sb < BS; ++sb)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) b[sb * NF + nf] = hs[(2 * (BS * g + sb)) * CW + nf * 32];
-#pragma unroll
-    for (int sb = 0; sb < BS; ++sb)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[BS * g + sb], b[sb * NF + nf], acc[nf], 0, 0, 0);
-      }
-  }
-  if (r0 + 32 <= N && c0 + CW <= K) {  // wave-uniform: interior tile, unguarded stores
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      float* wp = w + (r0 + 4 * (lane >> 5)) * K + c0 + nf * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) wp[((r & 3) + 8 * (r >> 2)) * K] = wt[nf][r] - acc[nf][r];
-    }
-  } else {
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const int64_t col = c0 + nf * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < N && col < K) w[row * K + col] = wt[nf][r] - acc[nf][r];
-      }
-    }
-  }
-}
-
-#ifdef INC_KBENCH  // the same kernel with its timing-only ablations: harness code
-#include "../../tools/kbench_gptq_lazy_lab.inc"
-#endif
-
-// launch of the third generation over the columns [c_begin, c_end) of the trailing matrix (c_begin on the 128-column tile grid that
-// starts at i2): quarter tiles when whole tiles would leave most CUs without a workgroup
-static void launch_lazy_update_v3(float* w, const float* Hinv, const float* err, int64_t N, int64_t K, int64_t i1, int64_t c_begin,
-                                  int64_t c_end, hipStream_t s) {
-  static std::atomic<uint64_t> attr_set{0};
-  if (inc_attr_needed(attr_set)) {
-    (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + L2T * 32 * 4);
-    inc_attr_done(attr_set);
-  }
-  const int64_t row_tiles = ceil_div64(N, L2T);
-  const int64_t col_tiles = ceil_div64(c_end - c_begin, L2T);
-#ifdef INC_KBENCH
-  const int abl = inc_small_tiles_flag(-1) - 86;  // 87 / 88 / 90: timing-only (no MFMAs / no loads / no stores)
-  if (abl == 1 || abl == 2 || abl == 4) {
-#define INC_L3A(A) { (void)hipFuncSetAttribute((const void*)gptq_lazy_update_v3_lab_kernel<128, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
-                     gptq_lazy_update_v3_lab_kernel<128, A><<<dim3((unsigned)col_tiles, (unsigned)row_tiles), 256, 65536, s>>>(w, Hinv, err, N, K, i1, c_begin); }
-    if (abl == 1) INC_L3A(1) else if (abl == 2) INC_L3A(2) else INC_L3A(4)
-#undef INC_L3A
-    return;
-  }
-#endif
-  if (row_tiles * col_tiles <= 128)
-    gptq_lazy_update_v3_kernel<32><<<dim3((unsigned)ceil_div64(c_end - c_begin, 32), (unsigned)row_tiles), 256, 65536 + L2T * 32 * 4, s>>>(w, Hinv, err, N, K, i1, c_begin);
-  else
-    gptq_lazy_update_v3_kernel<128><<<dim3((unsigned)col_tiles, (unsigned)row_tiles), 256, 65536, s>>>(w, Hinv, err, N, K, i1, c_begin);
-}
+// third / fourth generation of the lazy update: gptq_lazy.hip
+}  // namespace
+void inc_launch_lazy_update_v3(float* w, const float* Hinv, const float* err, int64_t N, int64_t K, int64_t i1, int64_t c_begin,
+                               int64_t c_end, hipStream_t s);
+namespace {
 
 }  // namespace
 
@@ -725,7 +550,7 @@ int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t 
   const int64_t i2 = i1 + count;
   if (i2 >= K) return INC_OK;  // nothing to the right of the block
   if (count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles() && inc_small_tiles_flag(-1) != 86) {
-    launch_lazy_update_v3(w, Hinv, err, N, K, i1, i2, K, inc_s(stream));
+    inc_launch_lazy_update_v3(w, Hinv, err, N, K, i1, i2, K, inc_s(stream));
     INC_LAUNCH_RETURN();
   }
 #ifdef INC_KBENCH
@@ -770,7 +595,7 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
   if (inc_small_tiles_flag(-1) == 106 && launch_lazy_update_x3(w, err, N, K, i1, col_begin, col_end, inc_s(stream))) INC_LAUNCH_RETURN();
 #endif
   if (inc_small_tiles_flag(-1) != 86) {
-    launch_lazy_update_v3(w, Hinv, err, N, K, i1, col_begin, col_end, inc_s(stream));
+    inc_launch_lazy_update_v3(w, Hinv, err, N, K, i1, col_begin, col_end, inc_s(stream));
     INC_LAUNCH_RETURN();
   }
 #ifdef INC_KBENCH  // harness flag 86: second generation

@@ -929,9 +929,9 @@ static int run_colloop_case(int64_t N, int64_t K, int gs, int nblocks, bool time
   const int64_t G = (K + gs - 1) / gs;
   DevBuf<float> Hinv((size_t)K * K), sc(hs.size()), ze(hz.size());
   Hinv.upload(hh); sc.upload(hs); ze.upload(hz);
-  constexpr int NV = 3;
-  const int flag[NV] = {0, 86, 1};
-  const char* label[NV] = {"third generation", "second generation", "first generation"};
+  constexpr int NV = 4;
+  const int flag[NV] = {0, 86, 1, 107};
+  const char* label[NV] = {"product (4th / 3rd)", "second generation", "first generation", "third generation only"};
   std::vector<DevBuf<float>*> W, E;
   std::vector<DevBuf<uint8_t>*> C;
   std::vector<DevBuf<uint16_t>*> Q;
@@ -968,7 +968,7 @@ static int run_colloop_case(int64_t N, int64_t K, int gs, int nblocks, bool time
     for (size_t i = 0; i < e0.size(); ++i) de += memcmp(&e0[i], &e1[i], 4) != 0;
     const bool okm = dw == 0 && de == 0 && dc == 0 && dq == 0;
     ok = ok && okm;
-    printf("COLLOOP N=%ld K=%ld gs=%d blocks=%d: differing W=%ld Err=%ld codes=%ld Q=%ld (third vs %s, bitwise)  %s\n", (long)N,
+    printf("COLLOOP N=%ld K=%ld gs=%d blocks=%d: differing W=%ld Err=%ld codes=%ld Q=%ld (product vs %s, bitwise)  %s\n", (long)N,
            (long)K, gs, nb, (long)dw, (long)de, (long)dc, (long)dq, label[m], okm ? "OK" : "FAIL");
   }
   if (time_it) {
@@ -1055,6 +1055,39 @@ static int run_qlayer_case(int64_t N, int64_t K, int gs) {
     ms[m] = t_all[2];
     codes[m] = C.download();
     scales[m] = sc.download();
+  }
+  // the strip form of the trailing update (fourth generation, the product) against the third generation everywhere (flag 107) and
+  // with strips cut at 4 / 16 tiles instead of 8 (flags 108 / 109): interleaved repeats, codes compared bit for bit
+  {
+    const int vflag[4] = {0, 107, 108, 109};
+    const char* vname[4] = {"strip form (product)", "third generation everywhere", "strips <= 4 tiles", "strips <= 16 tiles"};
+    std::vector<float> vt[4];
+    int64_t vdiff[4] = {0, 0, 0, 0};
+    DevBuf<float> W((size_t)N * K), sc((size_t)N * G), ze((size_t)N * G), ews((size_t)2 * N * 128);
+    DevBuf<uint8_t> C((size_t)N * K);
+    DevBuf<uint16_t> Q((size_t)N * K);
+    for (int rep = 0; rep < 5; ++rep)
+      for (int v = 0; v < 4; ++v) {
+        inc_debug_set_small_tiles(vflag[v]);
+        W.upload(hw);
+        HIPCHECK(hipDeviceSynchronize());
+        Timer t;
+        t.start();
+        INCCHECK(inc_gptq_quantize_layer(W.p, Hinv.p, sc.p, ze.p, G, nullptr, nullptr, 0, C.p, Q.p, INC_BF16, ews.p, N, K, gs, gs, 128, 4, 1,
+                                         INC_GPTQ_DYNAMIC_GROUPS, nullptr, aux));
+        const float ms1 = t.stop_ms();
+        if (rep > 0) vt[v].push_back(ms1);
+        if (rep == 4) {
+          HIPCHECK(hipDeviceSynchronize());
+          std::vector<uint8_t> c = C.download();
+          for (size_t i = 0; i < c.size(); ++i) vdiff[v] += c[i] != codes[0][i];
+        }
+      }
+    for (int v = 0; v < 4; ++v) {
+      std::sort(vt[v].begin(), vt[v].end());
+      printf("QLAYER N=%ld K=%ld lazy-update form [%s]: min %.3f median %.3f ms, codes differing from the product's first run: %ld\n", (long)N, (long)K,
+             vname[v], vt[v][0], vt[v][vt[v].size() / 2], (long)vdiff[v]);
+    }
   }
   inc_debug_set_small_tiles(0);
   INCCHECK(inc_debug_lazy_x3_prepare(nullptr, 0, 0, nullptr, nullptr));
@@ -1328,6 +1361,7 @@ int main(int argc, char** argv) {
     fails += run_colloop_case(200, 512, 32, 4, false);      // ragged rows, 4 groups per block
     fails += run_colloop_case(260, 520, 64, 4, false);      // partial last column tile (8 columns), ragged rows
     fails += run_colloop_case(4100, 1288, 128, 10, false);  // a row tile with 4 rows, partial last tile, whole and quarter tiles
+    fails += run_colloop_case(4100, 2600, 128, 6, false);   // the strip form's edges: a row tile with 4 rows, a last tile of 8 columns
     fails += run_colloop_case(4096, 4096, 128, 32, true);
     fails += run_colloop_case(11008, 4096, 128, 8, true);
     fails += run_colloop_case(4096, 11008, 128, 8, true);
