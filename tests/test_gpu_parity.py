@@ -417,6 +417,39 @@ def test_gptq_column_loop_with_injected_hinv(hip, golden, tag):
         assert np.array_equal(got_codes[:, :128], ref_ints[:, :128])
 
 
+@pytest.mark.parametrize("N,K,i1", [(4096, 4096, 0), (4100, 2600, 128), (12288, 4096, 1024), (300, 640, 128)])
+def test_trailing_update_strip_form_vs_oracle_arithmetic_and_tile_form(hip, N, K, i1):
+    """W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] (gptq.py:1304) at sizes where inc_gptq_lazy_update takes the strip form (a workgroup owns 128
+    rows and walks 32-column tiles, csrc/gptq_lazy.hip) -- incl. a last row tile of 4 rows and a last tile of 8 columns -- against
+    (a) the oracle's arithmetic in fp64 (fp32 sums of 128 products: 1e-6), (b) the same update issued as 128-column pieces, which take the
+    one-tile-per-workgroup form: every element's sum has the same order in both forms, so W must agree bit for bit, and (c) the columns
+    left of i2 must not be touched."""
+    from neural_compressor_amd import ops
+
+    g = torch.Generator().manual_seed(N + K + i1)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(hip)
+    Hinv = (torch.randn(K, K, generator=g) * 0.02).triu(1).add(torch.diag(torch.rand(K, generator=g) + 0.5)).to(hip)
+    err = (torch.randn(N, 128, generator=g) * 0.05).to(hip)
+    i2 = i1 + 128
+    a = W.clone()
+    ops.gptq_lazy_update(a, Hinv, err, i1, 128)
+    ref = W.double()
+    ref[:, i2:] -= err.double() @ Hinv[i1:i2, i2:].double()
+    assert torch.equal(a[:, :i2], W[:, :i2])
+    rel = float((a[:, i2:].double() - ref[:, i2:]).norm() / ref[:, i2:].norm())
+    assert rel <= 1e-6, rel
+    b = W.clone()
+    for c in range(i2, K, 128):
+        assert ops.gptq_lazy_update_cols(b, Hinv, err, i1, 128, c, min(c + 128, K))
+    assert torch.equal(a, b)
+    # and split the way the look-ahead loop issues it: the next 128 columns, then the rest
+    if i2 + 128 < K:
+        c2 = W.clone()
+        assert ops.gptq_lazy_update_cols(c2, Hinv, err, i1, 128, i2, i2 + 128)
+        assert ops.gptq_lazy_update_cols(c2, Hinv, err, i1, 128, i2 + 128, K)
+        assert torch.equal(a, c2)
+
+
 @pytest.mark.parametrize("tag", ["gq_sym_g32", "gq_asym_g32", "gq_sym_pc", "gq_sym_g128_2blk", "gq_sym_act", "gq_sym8_g64", "gq_sym_g32_mse", "gq_asym_g64_mse"])
 def test_gptq_layer_end_to_end(hip, golden, tag):
     """add_batch -> fasterquant -> pack through the Python mirror classes vs the reference's golden outputs."""
