@@ -440,7 +440,7 @@ constexpr int L2T = 128;  // rows / columns of a lazy-update tile
 // third / fourth generation of the lazy update: gptq_lazy.hip
 }  // namespace
 void inc_launch_lazy_update_v3(float* w, const float* Hinv, const float* err, int64_t N, int64_t K, int64_t i1, int64_t c_begin,
-                               int64_t c_end, hipStream_t s);
+                               int64_t c_end, bool exclusive, hipStream_t s);
 namespace {
 
 }  // namespace
@@ -550,7 +550,7 @@ int inc_gptq_lazy_update(float* w, const float* Hinv, const float* err, int64_t 
   const int64_t i2 = i1 + count;
   if (i2 >= K) return INC_OK;  // nothing to the right of the block
   if (count == QB && (i1 % 4) == 0 && (K % 4) == 0 && K * (int64_t)(QB + 1) * 4 < ((int64_t)1 << 32) && !inc_force_small_tiles() && inc_small_tiles_flag(-1) != 86) {
-    inc_launch_lazy_update_v3(w, Hinv, err, N, K, i1, i2, K, inc_s(stream));
+    inc_launch_lazy_update_v3(w, Hinv, err, N, K, i1, i2, K, true, inc_s(stream));
     INC_LAUNCH_RETURN();
   }
 #ifdef INC_KBENCH
@@ -595,7 +595,7 @@ int inc_gptq_lazy_update_cols(float* w, const float* Hinv, const float* err, int
   if (inc_small_tiles_flag(-1) == 106 && launch_lazy_update_x3(w, err, N, K, i1, col_begin, col_end, inc_s(stream))) INC_LAUNCH_RETURN();
 #endif
   if (inc_small_tiles_flag(-1) != 86) {
-    inc_launch_lazy_update_v3(w, Hinv, err, N, K, i1, col_begin, col_end, inc_s(stream));
+    inc_launch_lazy_update_v3(w, Hinv, err, N, K, i1, col_begin, col_end, false, inc_s(stream));
     INC_LAUNCH_RETURN();
   }
 #ifdef INC_KBENCH  // harness flag 86: second generation

@@ -1057,10 +1057,10 @@ static int run_qlayer_case(int64_t N, int64_t K, int gs) {
     scales[m] = sc.download();
   }
   // the strip form of the trailing update (fourth generation, the product) against the third generation everywhere (flag 107) and
-  // with strips cut at 4 / 16 tiles instead of 8 (flags 108 / 109): interleaved repeats, codes compared bit for bit
+  // with short strips everywhere (flag 110) and strips cut at 16 tiles (109): interleaved repeats, codes compared bit for bit
   {
-    const int vflag[4] = {0, 107, 108, 109};
-    const char* vname[4] = {"strip form (product)", "third generation everywhere", "strips <= 4 tiles", "strips <= 16 tiles"};
+    const int vflag[4] = {0, 107, 110, 109};
+    const char* vname[4] = {"strip form (product)", "third generation everywhere", "short strips (<= 8 tiles) everywhere", "strips <= 16 tiles"};
     std::vector<float> vt[4];
     int64_t vdiff[4] = {0, 0, 0, 0};
     DevBuf<float> W((size_t)N * K), sc((size_t)N * G), ze((size_t)N * G), ews((size_t)2 * N * 128);
