@@ -181,6 +181,8 @@ __global__ __launch_bounds__(256, 2) void gptq_lazy_update_v3_kernel(float* __re
 // dependent latency.  All buffers live in what was the wave's own Err1 slice (no barrier between reading Err1 and the first
 // request): 64 KiB of LDS and ~130 registers, two of these or one and a chain workgroup per CU.  Per output element the sum is the
 // third generation's (k = 2s + (lane >> 5), s ascending, acc from 0, then W - acc): bit-identical W.
+// (A form with two accumulators and the neighbours' epilogue / requests spread over the MFMA shadows is faster alone on the chip and slower
+// inside the step -- 214 registers against 180: tools/rejected/gptq_lazy_strip_pipelined.inc, profiles/NOTES.md.)
 constexpr int L4W = 32;  // columns of a fourth-generation tile
 #ifndef INC_LAZY_STRIP_TILES
 #define INC_LAZY_STRIP_TILES 2048
@@ -215,16 +217,11 @@ __global__ __launch_bounds__(256, 2) void gptq_lazy_update_v4_kernel(float* __re
     R = rows_here > 0 ? (R < rows_here ? R : rows_here - 1) : 0;
     w_row[q] = (uint32_t)(R * K * 4);
   }
-  auto request_h = [&](int64_t c0, int b) {  // Hinv slice of the tile at column c0 -> buffer b
+  auto request = [&](int64_t c0, int b) {  // tile at column c0 -> buffers b
     int64_t col = c0 + 4 * (lane & 7);
     if (col > K - 4) col = K - 4;  // partial last tile: clamped columns are never stored
     const uint32_t cb = (uint32_t)(col * 4);
     lds_dma_4x1k(hbase, slice + b * 4096, h_row + cb, h_row + h_step + cb, h_row + 2 * h_step + cb, h_row + 3 * h_step + cb);
-  };
-  auto request_w = [&](int64_t c0, int b) {  // this wave's W patch of the tile at column c0 -> buffer b
-    int64_t col = c0 + 4 * (lane & 7);
-    if (col > K - 4) col = K - 4;
-    const uint32_t cb = (uint32_t)(col * 4);
     lds_dma_4x1k(wbase, slice + 8192 + b * 4096, w_row[0] + cb, w_row[1] + cb, w_row[2] + cb, w_row[3] + cb);
   };
 
@@ -255,45 +252,26 @@ __global__ __launch_bounds__(256, 2) void gptq_lazy_update_v4_kernel(float* __re
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is in registers: its LDS space takes the wave's buffers
-  request_h(col0, 0);
-  request_w(col0, 0);
+  request(col0, 0);
 
   const char* const hs0 = smem_raw + lane * 4;  // B operand: k = 2s + (lane >> 5), column lane & 31 -> byte (lane >> 5) * 128 + (lane & 31) * 4
   const char* const ws0 = smem_raw + wave * 16384 + 8192 + (lane >> 5) * 512 + (lane & 31) * 4;  // D layout: + ((r & 3) + 8 (r >> 2)) * 128
   float* const wp0 = w + (r0 + 4 * (lane >> 5)) * K + (lane & 31);
-  const bool rows_full = r0 + 32 <= N;
-  // W - acc of one tile element (D layout): interior tiles store unguarded -- exactly one store instruction per element, which the counted wait relies on
-  auto store_elem = [&](int r, int64_t c0, bool interior, float v) {
-    if (interior) {
-      wp0[c0 + ((r & 3) + 8 * (r >> 2)) * K] = v;
-    } else {
-      const int64_t col = c0 + (lane & 31), row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < N && col < K) w[row * K + col] = v;
-    }
-  };
-  // One tile: its 64 MFMAs run as ONE dependent stream (issue interval = latency = 64 cycles), and everything else the strip has to do
-  // sits in the shadows of those MFMAs, one piece per MFMA: the request for tile t + 1, and the read-back / subtraction / stores of
-  // tile t - 1 (whose accumulator is the other of two).  `sched_barrier` after every piece: the scheduler must not gather them.
-  bool counted = false;  // the queue's youngest entries are exactly 16 stores (the previous tile's epilogue was an interior one)
-  auto tile_body = [&](int t, f32x16& acc, const f32x16& pacc, auto hp) {
-    constexpr bool have_prev = decltype(hp)::value;  // (the strip's first tile has no predecessor to finish)
+  bool counted = false;  // the previous tile issued exactly 16 stores (an interior tile)
+  for (int t = 0; t < tiles; ++t) {
     const int b = t & 1;
-    const int64_t c0 = col0 + (int64_t)t * L4W, pc0 = c0 - L4W;
-    const bool more = t + 1 < tiles;
-    const bool prev_interior = rows_full && pc0 + L4W <= K;
-    // in-order queue here: [Hinv(t) 4 pieces] [W(t) 4 pieces] [the stores issued during tile t - 1].  Only Hinv(t) is needed now: the
-    // patch W(t) is read back during tile t + 1 and has until that tile's wait (an HBM round trip under load is longer than a tile)
-    if (counted) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    const int64_t c0 = col0 + (int64_t)t * L4W;
+    // in-order queue here: [Hinv(t) 4 pieces] [W(t) 4 pieces] [the stores of tile t - 1]
+    if (counted) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave's share of Hinv(t) has landed, and every wave is done reading the buffer Hinv(t + 1) goes to
+    if (t + 1 < tiles) request(c0 + L4W, b ^ 1);
+    f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const char* hs = hs0 + b * 4096;
-    const char* pws = ws0 + (b ^ 1) * 4096;  // the W patch of tile t - 1
     constexpr int BS = 8;  // k-pairs per batch: the B operands of the next batch are read before this batch is multiplied
-    float bq[2][BS], wt[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) wt[r] = 0.f;
+    float bq[2][BS];
 #pragma unroll
     for (int sb = 0; sb < BS; ++sb) bq[0][sb] = *reinterpret_cast<const float*>(hs + ((2 * sb) >> 5) * 16384 + ((2 * sb) & 31) * 128);
 #pragma unroll
@@ -307,49 +285,27 @@ __global__ __launch_bounds__(256, 2) void gptq_lazy_update_v4_kernel(float* __re
       }
       __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler sinks every read to just before its MFMA and waits for it there)
 #pragma unroll
-      for (int sb = 0; sb < BS; ++sb) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[BS * g + sb], bq[g & 1][sb], acc, 0, 0, 0);
-        const int k = BS * g + sb;  // the piece in this MFMA's shadow
-        if (k < 16) {
-          if constexpr (have_prev) wt[k] = *reinterpret_cast<const float*>(pws + ((k & 3) + 8 * (k >> 2)) * 128);
-        } else if (k == 17) {
-          if (more) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch of tile t - 1 is in registers: its buffer takes the patch of t + 1
-            request_h(c0 + L4W, b ^ 1);
-            request_w(c0 + L4W, b ^ 1);
-          }
-        } else if (k >= 20 && k < 36) {
-          if constexpr (have_prev) store_elem(k - 20, pc0, prev_interior, wt[k - 20] - pacc[k - 20]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int sb = 0; sb < BS; ++sb) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[BS * g + sb], bq[g & 1][sb], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    counted = have_prev && prev_interior;
-    asm volatile("" ::: "memory");
-  };
-  f32x16 acc_a, acc_b;
-  tile_body(0, acc_a, acc_b, std::false_type{});
-  for (int t = 1; t < tiles; t += 2) {
-    tile_body(t, acc_b, acc_a, std::true_type{});
-    if (t + 1 < tiles) tile_body(t + 1, acc_a, acc_b, std::true_type{});
-  }
-  // the last tile's epilogue
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its patch may still have been on its way at that tile's counted wait
-  {
-    const int t = tiles - 1;
-    const int64_t c0 = col0 + (int64_t)t * L4W;
-    const bool interior = rows_full && c0 + L4W <= K;
-    const char* ws = ws0 + (t & 1) * 4096;
+    const char* ws = ws0 + b * 4096;
     float wt[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) wt[r] = *reinterpret_cast<const float*>(ws + ((r & 3) + 8 * (r >> 2)) * 128);
-    if (t & 1) {
+    counted = r0 + 32 <= N && c0 + L4W <= K;  // wave-uniform: an interior tile
+    if (counted) {
+      float* wp = wp0 + c0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) store_elem(r, c0, interior, wt[r] - acc_b[r]);
+      for (int r = 0; r < 16; ++r) wp[((r & 3) + 8 * (r >> 2)) * K] = wt[r] - acc[r];
     } else {
+      const int64_t col = c0 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) store_elem(r, c0, interior, wt[r] - acc_a[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < N && col < K) w[row * K + col] = wt[r] - acc[r];
+      }
     }
+    asm volatile("" ::: "memory");
   }
 }
 
