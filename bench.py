@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 HBM_PEAK_GBS = 8000.0           # HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.0    # exact-fp32 matrix instruction (SURVEY 8(d) peak denominators); the bare loop measures 154.6 (tools/f32mfma_lab, profiles/r6)
 
 
 class KernelClock:
@@ -683,7 +684,11 @@ def bench_per_layer(device, cpu):
         lo, med = min(t_loop[i]), sorted(t_loop[i])[len(t_loop[i]) // 2]
         out[f"fasterquant_{N}x{K}"] = dict(gpu_s=round(min(t_solve[i]), 5), cpu_s=c(f"t_fq_{N}x{K}"), column_loop_s_min=round(lo, 5), column_loop_s_median=round(med, 5),
                                            column_loop_us_per_column_min=round(lo * 1e6 / K, 3), column_loop_us_per_column_median=round(med * 1e6 / K, 3),
-                                           column_loop_hbm_frac=round(2.0 * N * K * 4 / med / 1e9 / HBM_PEAK_GBS, 4), reps=REPS)
+                                           column_loop_hbm_frac=round(2.0 * N * K * 4 / med / 1e9 / HBM_PEAK_GBS, 4),
+                                           # the loop's flops are its trailing update (gptq.py:1304), N * 128 * (K - i2) * 2 per block on the exact-fp32 MFMA
+                                           trailing_update_tflops=round(sum(2.0 * N * 128 * (K - i2) for i2 in range(128, K, 128)) / med / 1e12, 1),
+                                           trailing_update_f32_mfma_frac=round(sum(2.0 * N * 128 * (K - i2) for i2 in range(128, K, 128)) / med / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                           reps=REPS)
     del setups
     torch.cuda.empty_cache()
     # pack / unpack / recover / quant_tensor of one 4096 x 4096 g128 layer (bytes: SURVEY 8(d))
@@ -1068,6 +1073,7 @@ def compact_line(full):
         if k.startswith("fasterquant_"):
             roof[f"column_loop_{k[12:]}_us_per_column_median"] = v.get("column_loop_us_per_column_median")
             roof[f"column_loop_{k[12:]}_us_per_column_min"] = v.get("column_loop_us_per_column_min")
+            roof[f"column_loop_{k[12:]}_f32_mfma_frac"] = v.get("trailing_update_f32_mfma_frac")
         elif k.startswith(("unpack", "recover", "pack", "quant_tensor")):
             roof[f"{k}_hbm_frac_cold"] = v.get("hbm_frac")
     ceil_ = full.get("ceilings") or {}
