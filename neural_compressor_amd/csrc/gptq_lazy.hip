@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void gptq_lazy_update_v3_kernel(float* __re
 // lazy update, fourth generation (the "rest" of the trailing update): a workgroup OWNS a 128-row strip and walks column tiles
 // ---------------------------------------------------------------------------------------------
 // The third generation brings Err1 in once per TILE (64 KiB through LDS for 4.2 MFLOP) and runs its phases back to back -- loads,
-// 256 MFMAs, stores -- so the matrix pipe is busy only while the CU's other workgroup happens to be loading: 45-60 TFLOP/s of the
-// ~100 the exact-fp32 MFMA sustains on this chip (profiles/NOTES.md).  Here a workgroup keeps its rows' Err1 fragment in registers
+// 256 MFMAs, stores -- so the matrix pipe is busy only while the CU's other workgroup happens to be loading: 78 TFLOP/s alone on the
+// chip, of the 155 the bare exact-fp32 MFMA sustains (tools/f32mfma_lab; profiles/NOTES.md).  Here a workgroup keeps its rows' Err1 fragment in registers
 // (the A operand: 64 VGPRs, loaded ONCE) and walks `tiles_per_wg` column tiles of 32 columns.  Everything a tile needs arrives by
 // LDS-DMA one tile ahead: the Hinv slice ([128 k][32] fp32 = 16 KiB, wave w moves k rows 32w .. 32w + 31) and the wave's own 32 x 32
 // patch of W (4 KiB; read back in the MFMA's D layout) into the other half of two double buffers, requested before the 64 MFMAs of
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void gptq_lazy_update_v3_kernel(float* __re
 // tile, and no register-destination load the compiler's own wait-count bookkeeping could serialise (a form with W in registers got
 // `vmcnt(6)` from it behind every DMA burst).  One accumulator: the 32x32x2 fp32 MFMA issues every 64 cycles, which is also its
 // dependent latency.  All buffers live in what was the wave's own Err1 slice (no barrier between reading Err1 and the first
-// request): 64 KiB of LDS and ~130 registers, two of these or one and a chain workgroup per CU.  Per output element the sum is the
+// request): 64 KiB of LDS and 180 registers, two of these or one and a chain workgroup per CU.  Per output element the sum is the
 // third generation's (k = 2s + (lane >> 5), s ascending, acc from 0, then W - acc): bit-identical W.
 // (A form with two accumulators and the neighbours' epilogue / requests spread over the MFMA shadows is faster alone on the chip and slower
 // inside the step -- 214 registers against 180: tools/rejected/gptq_lazy_strip_pipelined.inc, profiles/NOTES.md.)
