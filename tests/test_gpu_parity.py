@@ -817,6 +817,38 @@ def test_gptq_fasterquant_raises_on_a_non_positive_definite_hessian(hip):
 
 
 @pytest.mark.gpu
+def test_gptq_column_loop_forms_agree_where_the_strip_form_runs(hip, monkeypatch):
+    """6144 x 2048: large enough for the trailing update's strip form (rows / 128 x columns / 32 >= 2048 in the first blocks).  The look-ahead
+    loop (short strips beside the chain), the one-stream loop (long strips: the update has the chip to itself) and the Python loops that issue
+    the same launches one by one must produce identical codes, scales and Q -- the strip, tile and quarter-tile kernels sum every element
+    in the same order (csrc/gptq_lazy.hip)."""
+    import neural_compressor_amd.torch.algorithms.weight_only.gptq as G
+    from tests.ab_partners import python_column_loop
+
+    N, K = 6144, 2048
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(N, K, generator=g) * 0.05
+    X = torch.randn(4, 1024, K, generator=g)
+    outs = []
+    product_loop = G.GPTQ.column_loop
+    for look, one_call in ((True, True), (False, True), (True, False), (False, False)):
+        monkeypatch.setattr(G.GPTQ, "lookahead", look)
+        monkeypatch.setattr(G.GPTQ, "column_loop", product_loop if one_call else python_column_loop(look))
+        layer = torch.nn.Linear(K, N, bias=False).to(hip)
+        layer.weight.data.copy_(W)
+        gq = G.GPTQ(layer, device=hip)
+        gq.configure(dict(bits=4, sym=True, dtype="int", mse=False))
+        for j in range(X.shape[0]):
+            gq.add_batch(X[j : j + 1].to(hip))
+        scale, _, _, Q = gq.fasterquant(layer.weight.data, blocksize=128, percdamp=0.01, groupsize=128)
+        torch.cuda.synchronize()
+        outs.append((gq.codes.clone(), scale.clone(), Q.clone()))
+    for b in outs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(outs[0], b))
+    assert int(outs[0][0].max()) <= 15 and outs[0][0].float().std() > 1.0  # real codes, not a constant
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("groupsize,blocksize,sym", [(128, 128, True), (32, 128, False), (256, 128, True), (128, 256, False), (-1, 128, True)])
 def test_gptq_lookahead_column_loop_is_bit_identical(hip, monkeypatch, groupsize, blocksize, sym):
     """The look-ahead column loop (next block's 128 columns first, the rest of the lazy update on a second stream) against the
