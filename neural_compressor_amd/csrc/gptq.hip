@@ -17,7 +17,8 @@
 //                       panel lives in 128 VGPRs (fully unrolled), the 128x128 Hinv tile is broadcast
 //                       out of LDS.  Arithmetic is kept un-fused (mul then sub, true divisions) so that
 //                       one block is bit-identical to the reference's torch ops.
-//   gptq_lazy_update    W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] with the exact fp32 MFMA.
+//   gptq_lazy_update    W[:, i2:] -= Err1 @ Hinv[i1:i2, i2:] with the exact fp32 MFMA (first generation here; the product kernels -- tile and
+//                       strip form -- live in gptq_lazy.hip, the Hessian syrk in gptq_hessian.hip).
 #include <math.h>
 
 #include <type_traits>
