@@ -25,7 +25,7 @@ def classify(name):
         return "marker"
     if "hessian_syrk" in n or "hessian_tail" in n or "hessian_final" in n:
         return "hessian (own)"
-    if "chol_" in n or "ifac_" in n or "f32gemm" in n:
+    if "chol_" in n or "ifac_" in n or "f32gemm" in n or "bf16x3_gemm" in n or "hessian_mirror" in n or "hessian_diag" in n:
         return "factorisation (own)"
     if "gptq_quant_block" in n or "gptq_lazy_update" in n or "gptq_find_params" in n or "gptq_prepare" in n or "gptq_hessian_finalize" in n:
         return "column loop (own)"
