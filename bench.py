@@ -336,7 +336,6 @@ def bench_int8_rows(device):
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 20
         row.update(prefill_M=4096, prefill_ms=round(t, 4), prefill_tflops=round(2.0 * 4096 * N * K / t / 1e9, 1),
-                   prefill_route="HIP recover + library GEMM (small layer: modules.DENSE_ROUTE_MAX_ELEMS)" if m._dense_is_faster(4096) else "fused",
                    prefill_frac=round(2.0 * 4096 * N * K / t / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4))
         res.append(row)
         del m, x

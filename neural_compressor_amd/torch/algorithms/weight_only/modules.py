@@ -296,8 +296,6 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         d["_call"] = None
         if plan == "fused" and self._fused_max_m is not None and x2d.shape[0] > self._fused_max_m:
             plan = "dense"  # (a group size the fast kernels do not take: see _forward_plan)
-        elif plan == "fused" and self._dense_is_faster(x2d.shape[0]):
-            plan = "dense"  # (a large batch on a small layer: see DENSE_ROUTE_MAX_ELEMS)
         if plan == "fused" and self._fused_max_m is not None:
             y = ops.woq_gemm(x2d, self.qweight, self.scales, self.qzeros, self.bias, self.out_features, self.in_features, self.group_size, self.bits)
         elif plan == "fused":
@@ -325,23 +323,6 @@ class MI355XWeightOnlyLinear(WeightOnlyLinear):
         if input.dtype == torch.float32:
             y = y.float()
         return y.reshape(*lead, self.out_features)
-
-    # Large batches on SMALL layers take HIP recover() into a transient dense weight + the library GEMM: measured on layers from 768 x 768
-    # to 4096 x 4096 (scripts/small_layer_sweep.py, profiles/r6/small_layer_sweep.log) the fused kernels are 1.1-1.75 x slower there -- 4-bit
-    # between 1024 and 3072 rows (the 256-row tile kernels with a handful of tiles) and on layers up to 1.25 Mi weights for every larger batch,
-    # 8-bit from 256 rows on.  Above this many weights (a 32 MiB transient) the fused form stays: at large sizes it wins or ties and no dense
-    # weight ever exists.  None = always fused.
-    DENSE_ROUTE_MAX_ELEMS = 16 << 20
-
-    def _dense_is_faster(self, M):
-        nk = self.in_features * self.out_features
-        if self.DENSE_ROUTE_MAX_ELEMS is None or nk > self.DENSE_ROUTE_MAX_ELEMS:
-            return False
-        if self.bits == 8:
-            return M >= 256
-        if self.bits == 4:
-            return M > 1024 and (M <= 3072 or nk <= (5 << 18))
-        return False
 
     # widths other than 4 / 8 bits: True = multiply through inc_woq_gemm's per-element tile form (no dense weight ever exists; 8-10 x
     # slower), False = HIP recover() into a transient dense weight + the library GEMM (what the reference's forward does on its CPU)

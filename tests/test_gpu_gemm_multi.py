@@ -253,25 +253,3 @@ def test_group_size_that_is_no_power_of_two_takes_the_dense_route_above_16_rows(
         assert m._plan == "fused" and m._fused_max_m == 16
         assert float((y.float() - ref).norm() / ref.norm()) <= 2e-3, M
         assert torch.equal(m(x), y)
-
-
-def test_large_batches_on_small_layers_take_the_dense_route(hip):
-    """modules.DENSE_ROUTE_MAX_ELEMS: a 1000 x 1024 layer (config #1's OPT-125M-like sizes) at 2048 rows multiplies through HIP recover() + the
-    library GEMM (1.3-1.7 x faster there, scripts/small_layer_sweep.py) -- the same values as recover() + F.linear bit for bit, and the
-    fused kernels' values within the forward's tolerance; decode / mid-size batches and large layers stay fused."""
-    from neural_compressor_amd.torch.algorithms.weight_only.modules import MI355XWeightOnlyLinear
-
-    for bits, m in ((4, _packed(hip, 1000, 1024, 3)), (8, _packed8(hip, 1000, 1024, 128, 9))):
-        assert m.bits == bits and m.bias is None
-        x = torch.randn(2048, 1024, generator=torch.Generator().manual_seed(bits)).to(torch.bfloat16).to(hip)
-        assert m._dense_is_faster(2048) and not m._dense_is_faster(64) and m._dense_is_faster(512) == (bits == 8)
-        y = m(x)
-        assert torch.equal(y, torch.nn.functional.linear(x, m.recover(dtype=torch.bfloat16)))
-        try:
-            MI355XWeightOnlyLinear.DENSE_ROUTE_MAX_ELEMS = None
-            yf = m(x)
-        finally:
-            MI355XWeightOnlyLinear.DENSE_ROUTE_MAX_ELEMS = 16 << 20
-        assert float((y.float() - yf.float()).norm() / yf.float().norm()) <= 4e-3  # (two bf16 roundings of nearly equal fp32 sums)
-    big = _packed(hip, 4096, 4096 + 128, 5)
-    assert not big._dense_is_faster(2048)  # above 16 Mi weights: fused whatever the batch
